@@ -1,0 +1,196 @@
+"""Oracle (TEST INFRASTRUCTURE ONLY — see oracle/__init__.py): two-level pointer-network
+greedy inference, restated on PyTorch-CPU fp32 from /root/reference/src/models/modelPN.py.
+
+Pinned against the imported reference by tests/golden/make_golden.py (fixtures
+tests/golden/pn_*.npz): identical idxs, identical logits bit-for-bit when both run on
+this image's torch CPU build.
+
+Everything here works on a plain ``state_dict`` (name -> tensor) with the reference's
+key names (modelPN.py:154-163, prefixed ``actor.`` by CombinatorialRL, modelPN.py:267):
+    actor.decoder_start_input [H]
+    actor.embedding2.{weight [H,8], bias [H]}
+    actor.encoder.{weight_ih_l0 [4H,H], weight_hh_l0 [4H,H], bias_ih_l0 [4H], bias_hh_l0 [4H]}
+    actor.decoder.{...same...}
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+QOS_NUM = 4    # modelPN.py:11
+CONS_NUM = 2   # modelPN.py:12
+NEG_INF = float("-inf")
+
+
+def make_state_dict(hidden, seed, in_features=8):
+    """Deterministic weights in the reference's state_dict layout (PyTorch default-init
+    ranges: U(-1/sqrt(H), 1/sqrt(H)) for LSTM and decoder_start_input, modelPN.py:163;
+    U(-1/sqrt(in), 1/sqrt(in)) for the Linear).  Build-owned generator so that fixtures
+    can be regenerated from a seed instead of storing 4 MB of weights."""
+    g = torch.Generator().manual_seed(seed)
+
+    def u(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    kh = 1.0 / math.sqrt(hidden)
+    ke = 1.0 / math.sqrt(in_features)
+    sd = {
+        "actor.decoder_start_input": u((hidden,), kh),
+        "actor.embedding2.weight": u((hidden, in_features), ke),
+        "actor.embedding2.bias": u((hidden,), ke),
+    }
+    for name in ("encoder", "decoder"):
+        sd[f"actor.{name}.weight_ih_l0"] = u((4 * hidden, hidden), kh)
+        sd[f"actor.{name}.weight_hh_l0"] = u((4 * hidden, hidden), kh)
+        sd[f"actor.{name}.bias_ih_l0"] = u((4 * hidden,), kh)
+        sd[f"actor.{name}.bias_hh_l0"] = u((4 * hidden,), kh)
+    return sd
+
+
+def _lstm_module(sd, which, hidden):
+    """nn.LSTM(hidden, hidden, batch_first=True) (modelPN.py:157-158) loaded from ``sd``."""
+    m = torch.nn.LSTM(hidden, hidden, batch_first=True)
+    with torch.no_grad():
+        for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            getattr(m, k).copy_(sd[f"actor.{which}.{k}"])
+    m.eval()
+    return m
+
+
+def lstm_cell_explicit(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """One LSTM cell step written out (gate order i,f,g,o as in torch.nn.LSTM).  Used by
+    tests to document the arithmetic the HIP kernels implement; the oracle proper uses
+    nn.LSTM so that it is bit-identical to the reference on CPU."""
+    gates = F.linear(h, w_hh, b_hh) + F.linear(x, w_ih, b_ih)
+    i, f, g, o = gates.chunk(4, dim=1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    return h2, c2
+
+
+@torch.no_grad()
+def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True):
+    """PointerNet.forward, greedy, 'Dot' attention, n_glimpses=0 (modelPN.py:175-241).
+
+    inputs  [B, L, 8] fp32 with L = n_cat * n_per (assert at modelPN.py:182)
+    latent  None (Low net) or list of n_cat [B, L] tensors = the Low net's returned logits
+    returns (probs list T x [B,L], idxs list T x [B] int64, logits list T x [B,L]).
+    ``logits`` carries -inf at every previously selected position (in-place mask,
+    modelPN.py:165-173,214) but NOT the latent bias nor the window mask (modelPN.py:239).
+    """
+    B, L, _ = inputs.shape
+    assert L == n_cat * n_per
+    hidden = sd["actor.decoder_start_input"].numel()
+    enc = _lstm_module(sd, "encoder", hidden)
+    dec = _lstm_module(sd, "decoder", hidden)
+
+    embedded = F.linear(inputs, sd["actor.embedding2.weight"], sd["actor.embedding2.bias"])  # :190
+    enc_out, (h, c) = enc(embedded)                                                        # :191
+
+    chosen = torch.zeros(B, L, dtype=torch.bool)                                           # :196
+    rows = torch.arange(B)
+    idx = None
+    x = sd["actor.decoder_start_input"].unsqueeze(0).repeat(B, 1)                          # :202
+    all_probs, all_idx, all_logits = [], [], []
+    for k in range(n_cat):                                                                  # :204
+        _, (h, c) = dec(x.unsqueeze(1), (h, c))                                             # :205
+        query = h.squeeze(0)                                                                # :207
+        logits = torch.bmm(enc_out, query.unsqueeze(2)).squeeze(2)                          # :112-113
+        if use_tanh:
+            logits = C * torch.tanh(logits)                                                 # :119-120
+        if idx is not None:                                                                 # :169-172
+            chosen[rows, idx] = True
+            logits[chosen] = NEG_INF
+        biased = logits + latent[k] if latent else logits.clone()                           # :215-218
+        biased[:, : k * n_per] = NEG_INF                                                    # :220-222
+        biased[:, (k + 1) * n_per:] = NEG_INF
+        probs = F.softmax(biased, dim=1)                                                    # :224
+        _, idx = torch.max(probs, dim=1)                                                    # :226 (first max wins)
+        x = embedded[rows, idx, :]                                                          # :235
+        all_probs.append(probs)
+        all_idx.append(idx)
+        all_logits.append(logits)
+    return all_probs, all_idx, all_logits
+
+
+def qos_calc(rows_qos, cons):
+    """calc (modelPN.py:15-32) for ONE problem.
+
+    rows_qos  float32 [T,4] = the selected candidates' (q0,q1,q2,q3)
+    cons      [(lo0,hi0),(lo1,hi1)] python floats read from the step-0 action row (:51-54)
+    returns (violate int, objFunc float)
+    """
+    ind = [np.asarray(rows_qos[:, j], dtype=np.float32) for j in range(QOS_NUM)]           # :19
+    violate = 0
+    for i in range(CONS_NUM):
+        prod = np.cumprod(ind[i + 2])[-1]                                                   # :20
+        lo, hi = cons[i]
+        if prod < lo or prod > hi:                                                          # :23
+            violate += 1
+    n_real = int((ind[0] > 0).sum())                                                        # :26-28
+    with np.errstate(divide="ignore", invalid="ignore"):   # n_real == 0 -> nan/inf, as numpy does
+        obj = (np.sum(ind[0]) / n_real + 1 - np.min(ind[1])) / 2                            # :29
+    return violate, float(obj)
+
+
+def reward(actions, level="High", tag=0):
+    """reward (modelPN.py:35-72) without the print (:67).  actions: list T x [B,8]."""
+    B = actions[0].shape[0]
+    act = torch.stack(actions, dim=1).numpy()                                               # [B,T,8]
+    out = []
+    for b in range(B):
+        first = act[b, 0]
+        cons = [(float(first[tag + QOS_NUM + 2 * kk]), float(first[tag + 1 + QOS_NUM + 2 * kk]))
+                for kk in range(CONS_NUM)]                                                  # :51-54
+        violate, obj = qos_calc(act[b, :, tag: tag + QOS_NUM], cons)
+        out.append(violate if level == "Low" else round(violate + obj, 5))                  # :58-61
+    return torch.FloatTensor(out)                                                           # :68
+
+
+@torch.no_grad()
+def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", training="RL",
+                          C=10.0, use_tanh=True):
+    """CombinatorialRL.forward (modelPN.py:282-306), sample='greedy'."""
+    B = inputs.shape[0]
+    probs, idxs, logits = pointer_forward(sd, inputs, n_cat, n_per, latent, C, use_tanh)
+    rows = torch.arange(B)
+    actions = [inputs[rows, i, :] for i in idxs]                                            # :293-295
+    action_probs = [p[rows, i] for p, i in zip(probs, idxs)]                                # :297-299
+    if training == "RL":
+        R = reward(actions, level=level)                                                    # :301-304
+        return R, action_probs, actions, idxs, logits
+    return probs, action_probs, actions, idxs, logits
+
+
+@torch.no_grad()
+def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=True):
+    """The eval block of trainPNHigh.py:138-139: Low greedy ("SL") -> latent -> High greedy ("RL").
+
+    Returns dict with idx_low/idx_high [B,T] int64, R [B] fp32, actions [B,T,8], action_probs [B,T],
+    win_low/win_high [B,T,K] (in-window logits: Low's raw, High's after adding Low's), margin
+    [B,T] (top-1 minus top-2 of the High decision; +inf when K == 1).
+    """
+    B, L, _ = inputs.shape
+    _, _, _, idx_low, latent = combinatorial_forward(sd_low, inputs, n_cat, n_per, None, "Low", "SL",
+                                                     C, use_tanh)
+    R, aprob, actions, idx_high, logits_high = combinatorial_forward(
+        sd_high, inputs, n_cat, n_per, latent, "High", "RL", C, use_tanh)
+    win_low = torch.stack([latent[k][:, k * n_per:(k + 1) * n_per] for k in range(n_cat)], 1)
+    win_high = torch.stack([(logits_high[k] + latent[k])[:, k * n_per:(k + 1) * n_per]
+                            for k in range(n_cat)], 1)
+    return {
+        "idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
+        "actions": torch.stack(actions, 1), "action_probs": torch.stack(aprob, 1),
+        "win_low": win_low, "win_high": win_high,
+        "margin_low": decision_margin(win_low), "margin_high": decision_margin(win_high),
+        "latent": latent,
+    }
+
+
+def decision_margin(win):
+    """top-1 minus top-2 of each [.., K] window (how far a decision is from flipping)."""
+    if win.shape[-1] == 1:
+        return torch.full(win.shape[:-1], float("inf"))
+    top2 = win.topk(2, dim=-1).values
+    return top2[..., 0] - top2[..., 1]
