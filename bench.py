@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""ML+2PN inference throughput on MI355X (BASELINE.json metric: service-composition problems/sec).
+
+    python bench.py --gpus N --steps K --warmup W [--workload qws|normal|synth4] [--batch B]
+
+A "step" = one pass of the whole hot path over one batch of B synthetic problems that is already
+resident in HBM: GNN scores -> per-category top-K feasible candidates -> Low/High pointer-network
+encode + greedy decode -> QoS reward (+ at N>1 the single all-gather of the selected indices).
+One process per GPU; at N>1 every rank owns its own B problems (weak scaling, no data-path
+collective besides that all-gather).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     : the dominant kernel by time, priced against the bound that applies to it
+  kernels      : every timed kernel of the step (avg ms, algorithmic bytes/flops, fraction of peak)
+  cpu_baseline : the CPU oracle (oracle/, a torch-CPU port of the reference algorithm) timed on this
+                 box's host cores over a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec; 6.29 TB/s is the measured copy ceiling
+PEAK_F32_TFLOPS = 157.3        # fp32 matrix (= fp32 vector) dense peak
+
+WORKLOADS = {
+    # name: T, K, S, per-GPU batch, task nodes per problem, GCN layers   
+    "qws": dict(T=47, K=5, S=2507, B=256, n_t=10, n_gcn=2,
+                desc="QWS shape: T=47 K=5 L=235 S=2507(assumed) H=256, batch=256 (BASELINE configs[1])"),
+    "normal": dict(T=50, K=10, S=5000, B=1024, n_t=10, n_gcn=4,
+                   desc="Normal shape: T=50 K=10 L=500 S=5000(assumed) H=256, batch=1024 (configs[2])"),
+    "synth4": dict(T=1000, K=5, S=5000, B=512, n_t=1000, n_gcn=2,
+                   desc="synthetic 1000-task/5000-candidate, batch=512 per GPU (configs[3] = 4096 over 8)"),
+}
+
+
+def build_models(T, S, K, dev, n_gcn=2, hidden_pn=256, seed=0):
+    """Random-init weights of the reference architecture (there are no checkpoints offline):
+    Net per environment.ini:[QWS-ML]/[Normal-ML], two CombinatorialRL per [*-PNHigh]."""
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    torch.manual_seed(seed)
+    net = Net(128, S, 20, 2, n_gcn, vocab=max(100, T + 1))
+    low = CombinatorialRL(0, hidden_pn, T * K, 0, 10, 1, reward, "Dot", K, T, level="Low")
+    high = CombinatorialRL(0, hidden_pn, T * K, 0, 10, 1, reward, "Dot", K, T, level="High")
+    return net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval()
+
+
+def algorithmic_cost(name, w, B):
+    """Algorithmic bytes / flops of ONE launch of each timed kernel."""
+    T, K, H = w["T"], w["K"], 256
+    L = T * K
+    if name == "lstm_encode":       # both nets in one launch: recurrent matmul flops
+        return dict(bound="mfma", work=2 * B * L * 2 * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
+    if name == "pointer_decode":    # one net: window rows of enc_out + embedded pick + state + outputs
+        byt = B * (L * H * 4 + T * (H * 4 + 2 * H * 4) + T * (8 * 4 + K * 4 + 8 + 32))
+        return dict(bound="hbm", work=byt, unit="GB/s", peak=PEAK_HBM_GBS)
+    if name == "pregates_gemm":     # [B*L,256] x [256,1024] per net
+        return dict(bound="mfma", work=2 * B * L * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
+    if name == "csr_aggregate_gcn":  # 2*S*C*4 + E*(4+4) + (S+1)*4, C=256
+        S, E = w["S"], w["E"]
+        return dict(bound="hbm", work=2 * S * 256 * 4 + E * 8 + (S + 1) * 4, unit="GB/s", peak=PEAK_HBM_GBS)
+    raise KeyError(name)
+
+
+class KernelTimers:
+    """HIP-event pairs around chosen C-ABI calls, recorded on the stream the kernels run on
+    (torch's current stream, which is the stream handed to the C ABI)."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, module, fn_name, label, select=None):
+        orig = getattr(module, fn_name)
+
+        def timed(*a, **k):
+            if not self.enabled or (select is not None and not select(*a, **k)):
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **k)
+            e1.record()
+            self.events.setdefault(label, []).append((e0, e1))
+            return out
+        setattr(module, fn_name, timed)
+
+    def summary(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.events.items()}
+
+
+def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
+    """The CPU oracle chain on the same batch, all host cores, repeated until ~budget_s elapsed."""
+    import numpy as np
+    from oracle import data as odata   # noqa: F401  (checker / baseline use only)
+    from oracle import ml as oml
+    from oracle import pn as opn
+    T, K, B = w["T"], w["K"], pb.n_problems
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_ml = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    sd_low = {k: v.detach().cpu() for k, v in low.state_dict().items()}
+    sd_high = {k: v.detach().cpu() for k, v in high.state_dict().items()}
+    data = oml.make_data(torch.from_numpy(pb.x), torch.from_numpy(pb.edge_index), torch.from_numpy(pb.batch),
+                         torch.from_numpy(table.x_service), torch.from_numpy(table.edge_index),
+                         torch.from_numpy(table.edge_attr))
+    cat_of = np.repeat(np.arange(T), np.diff(table.cat_ptr))
+    from gnnpn_sc_amd.loadData import reduce_from_ranking
+
+    def one_pass():
+        scores = oml.net_forward(sd_ml, data, 2, w["n_gcn"])
+        rank = oml.rank_services(scores).numpy()
+        rows = [reduce_from_ranking(rank[b], pb.local_bounds[b], pb.present[b], pb.global_bounds[b], cat_of,
+                                    table.qos, K) for b in range(B)]
+        x = torch.tensor(rows, dtype=torch.float32)[:, :, 1:]
+        return opn.two_level_greedy(sd_low, sd_high, x, T, K)
+
+    one_pass()                       # warm-up (MKL thread pool, allocator)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_pass()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": B * n / el, "unit": "problems/s", "cores": cores, "kind": "port",
+            "sample": f"{n} pass(es) of the same {B}-problem batch through oracle/ (torch-CPU fp32 port of the "
+                      f"reference algorithm: GNN forward, stable ranking, candidate reduction, Low+High greedy "
+                      f"decode with full-L attention, reward), torch {torch.__version__}, {cores} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ML+2PN hot path has no CPU implementation")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd import dist as gdist
+    from gnnpn_sc_amd import modelPN, ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
+
+    if world > 1:
+        gdist.init_process_group("nccl", dev)
+
+    w = dict(WORKLOADS[args.workload])
+    if args.batch:
+        w["B"] = args.batch
+    T, K, S, B = w["T"], w["K"], w["S"], w["B"]
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    w["E"] = int(table.edge_index.shape[1]) + S            # + self loops
+    pb = synth.make_problem_batch(table, B, seed=1 + rank, tasks_per_problem=w["n_t"])
+    net, low, high = build_models(T, S, K, dev, w["n_gcn"])
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
+
+    timers = KernelTimers()
+    if not args.no_kernel_timers:
+        timers.wrap(ops, "lstm_encode", "lstm_encode")
+        timers.wrap(ops, "pointer_decode", "pointer_decode")
+        timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: wt.shape == (1024, 256))
+        timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
+
+    def step():
+        out = pipe.run(svc, batch)
+        if world > 1:
+            return gdist.all_gather_indices(out["idx_high"]), out["R"]
+        return out["idx_high"], out["R"]
+
+    for _ in range(args.warmup):
+        step()
+    timers.enabled = True
+    gdist.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, R = step()
+    torch.cuda.synchronize()
+    gdist.barrier(world)
+    elapsed = time.perf_counter() - t0
+    timers.enabled = False
+    elapsed = gdist.max_over_ranks(elapsed, dev, world)
+
+    if rank != 0:
+        gdist.destroy(world)
+        return
+    value = world * B * args.steps / elapsed
+    kernels = []
+    for name, (avg_ms, n) in sorted(timers.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        c = algorithmic_cost(name, w, B)
+        achieved = c["work"] / (avg_ms * 1e-3) / (1e12 if c["bound"] == "mfma" else 1e9)
+        kernels.append({"kernel": name, "launches_per_step": n // args.steps, "avg_ms": round(avg_ms, 4),
+                        "bound": c["bound"], "achieved": round(achieved, 3), "peak": c["peak"], "unit": c["unit"],
+                        "frac": round(achieved / c["peak"], 5)})
+    roof = None
+    if kernels:
+        k0 = kernels[0]
+        roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
+                "unit": k0["unit"], "frac": k0["frac"], "traffic": None}
+    line = {
+        "metric": "service-composition problems/sec (ML+2PN inference)", "value": round(value, 2),
+        "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
+                   "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}"},
+        "roofline": roof, "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(w, table, pb, net, low, high)
+    print(json.dumps(line), flush=True)
+    gdist.destroy(world)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI declared in ``include/gnnpn_hip.h`` (libgnnpn_hip.so).
+
+There is NO fallback: if the library is missing, or an operand is not a contiguous CUDA tensor of
+the right dtype, the call raises.  PyTorch is used only for device memory and the current HIP
+stream; tensors cross the boundary as raw device pointers + sizes.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnnpn_hip.so")
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+_P = c_void_p
+_SIGNATURES = {
+    "gnnpn_abi_version": (c_int, []),
+    "gnnpn_last_error": (c_char_p, []),
+    "gnnpn_linear_f32": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int, c_int, _P]),
+    "gnnpn_embed_concat_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
+    "gnnpn_csr_aggregate_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
+                                        c_int32, _P]),
+    "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
+    "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_rank_rows": (c_int, [_P, c_int64, _P, c_int32, c_int32, _P]),
+    "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_pointer_decode_f32": (c_int, [_P] * 11 + [c_float, c_int] + [_P] * 5 + [c_int32] * 4 + [_P]),
+    "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
+                                           c_int32, c_int32, _P]),
+    "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class GnnpnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgnnpn_hip.so (once) and declare every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnnpnError(
+            f"{LIB_PATH} is missing: build it with `python gnnpn-sc_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU fallback for the ML+2PN hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = the .so does not export the header's symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.gnnpn_abi_version() != ABI_VERSION:
+        raise GnnpnError(f"ABI mismatch: library {lib.gnnpn_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gnnpn_last_error().decode("utf-8", "replace")
+        raise GnnpnError(f"{what} failed ({rc}): {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t, dtype, name, allow_none=False):
+    """Raw device pointer of a contiguous CUDA tensor (validated), or NULL."""
+    if t is None:
+        if allow_none:
+            return None
+        raise GnnpnError(f"{name}: tensor required")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GnnpnError(f"{name}: expected a CUDA tensor (the hot path has no CPU implementation), got "
+                         f"{type(t).__name__} on {getattr(t, 'device', '?')}")
+    if t.dtype != dtype:
+        raise GnnpnError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise GnnpnError(f"{name}: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors, dtype, name):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = dev_ptr(t, dtype, f"{name}[{i}]").value
+    return arr

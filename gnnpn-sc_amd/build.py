@@ -1,0 +1,55 @@
+"""Build recipe for libgnnpn_hip.so (explicit hipcc, gfx950 only, in-tree so that the .so travels
+to the GPU box with the repo snapshot).
+
+    python gnnpn-sc_amd/build.py [--force]
+
+Flags of note: ``-ffp-contract=off`` — every fused multiply-add in the kernels is an explicit
+``fmaf`` and every place that must round a product before adding says ``__fmul_rn/__fadd_rn``;
+the compiler is not allowed to change either.  No fast-math.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgnnpn_hip.so")
+SOURCES = ["api.hip", "dense.hip", "graph.hip", "select.hip", "lstm.hip", "decode.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "recurrent.h"),
+           os.path.join(ROOT, "include", "gnnpn_hip.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + HEADERS):
+        subprocess.run(["hipcc"] + FLAGS + ["-c", path, "-o", obj], check=True)
+    return obj
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 and link libgnnpn_hip.so.  Returns the library path."""
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    if force:
+        for f in os.listdir(os.path.join(HERE, "build")):
+            os.remove(os.path.join(HERE, "build", f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if force or _stale(LIB, objs):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

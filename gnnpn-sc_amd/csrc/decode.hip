@@ -1,0 +1,287 @@
+// Greedy pointer decode of one pointer network (v1) and the QoS reward of the decoded
+// compositions.
+//
+// One workgroup owns BT problems for all T steps (no inter-workgroup communication).  Per step:
+//   decoder LSTM cell  : two k-ordered fmaf-chain GEMVs (W_ih.x, W_hh.h) streamed from L2
+//   attention          : only the step's n_per candidate rows of enc_out matter (everything
+//                        outside the window is -inf in the reference, modelPN.py:220-222), so the
+//                        kernel reads exactly those rows: one wavefront per (problem,row) dot
+//                        product, 16 B per lane, fixed butterfly reduction
+//   C*tanh, + latent (High net), softmax over the window, first-max argmax (torch.max on CPU
+//   returns the first maximal index), gather of the next decoder input and of the action row.
+#include "common.h"
+#include "recurrent.h"
+
+template <int H, int BT>
+__global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_kernel(
+    const float* __restrict__ embedded, const float* __restrict__ enc_out, const float* __restrict__ h0,
+    const float* __restrict__ c0, const float* __restrict__ start, const float* __restrict__ wih,
+    const float* __restrict__ whh, const float* __restrict__ bih, const float* __restrict__ bhh,
+    const float* __restrict__ latent_win, const float* __restrict__ inputs, float tanh_c, int use_tanh,
+    int32_t* __restrict__ idx_out, float* __restrict__ win_logits, float* __restrict__ pick_prob,
+    float* __restrict__ actions, float* __restrict__ queries, int32_t B, int32_t T, int32_t n_per) {
+    constexpr int NT = H < 64 ? 64 : H;
+    constexpr int NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) float xs[BT][H];
+    __shared__ __attribute__((aligned(16))) float hs[2][BT][H];
+    __shared__ float lg[BT][64];
+    __shared__ int sel[BT];
+
+    const int j = threadIdx.x;
+    const bool owner = j < H;
+    const int lane = j & 63, wave = j >> 6;
+    const int b0 = blockIdx.x * BT;
+    const int L = T * n_per;
+    const float4* __restrict__ Wi = reinterpret_cast<const float4*>(wih);
+    const float4* __restrict__ Wh = reinterpret_cast<const float4*>(whh);
+
+    float bi[4], bh[4], c[BT], h[BT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bi[g] = owner ? bih[g * H + j] : 0.0f;
+        bh[g] = owner ? bhh[g * H + j] : 0.0f;
+    }
+#pragma unroll
+    for (int p = 0; p < BT; ++p) {
+        const bool ok = owner && (b0 + p < B);
+        c[p] = ok ? c0[(int64_t)(b0 + p) * H + j] : 0.0f;
+        h[p] = ok ? h0[(int64_t)(b0 + p) * H + j] : 0.0f;
+        if (owner) {
+            hs[0][p][j] = h[p];
+            xs[p][j] = start[j];
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int k = 0; k < T; ++k) {
+        // ---- decoder LSTM cell (modelPN.py:205)
+        if (owner) {
+            float ai[BT][4], ah[BT][4];
+#pragma unroll
+            for (int p = 0; p < BT; ++p)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ai[p][g] = ah[p][g] = 0.0f;
+            gemv_chain<H, BT>(Wi, xs, j, ai);
+            gemv_chain<H, BT>(Wh, hs[cur], j, ah);
+#pragma unroll
+            for (int p = 0; p < BT; ++p) {
+                float gate[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    gate[g] = __fadd_rn(__fadd_rn(ah[p][g], bh[g]), __fadd_rn(ai[p][g], bi[g]));
+                lstm_cell_update(gate[0], gate[1], gate[2], gate[3], c[p], h[p]);
+                hs[cur ^ 1][p][j] = h[p];
+                if (queries && b0 + p < B) queries[((int64_t)(b0 + p) * T + k) * H + j] = h[p];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+
+        // ---- dot-attention logits over the window rows (modelPN.py:111-114): wave per (p,row)
+        for (int q = wave; q < BT * n_per; q += NW) {
+            const int p = q / n_per, r = q - p * n_per;
+            float part = 0.0f;
+            if (b0 + p < B) {
+                const float* row = enc_out + ((int64_t)(b0 + p) * L + (int64_t)k * n_per + r) * H;
+                for (int e = lane * 4; e < H; e += 256) {
+                    const float4 ev = *reinterpret_cast<const float4*>(row + e);
+                    const float4 hv = *reinterpret_cast<const float4*>(&hs[cur][p][e]);
+                    part = fmaf(ev.x, hv.x, part);
+                    part = fmaf(ev.y, hv.y, part);
+                    part = fmaf(ev.z, hv.z, part);
+                    part = fmaf(ev.w, hv.w, part);
+                }
+            }
+            const float dot = wave_sum(part);
+            if (lane == 0) lg[p][r] = dot;
+        }
+        __syncthreads();
+
+        // ---- C*tanh, latent bias, softmax, first-max argmax: one thread per problem (n_per <= 64)
+        if (j < BT && b0 + j < B) {
+            const int p = j;
+            const int64_t wbase = ((int64_t)(b0 + p) * T + k) * n_per;
+            float best = 0.0f;
+            int best_r = -1;
+            for (int r = 0; r < n_per; ++r) {
+                float v = lg[p][r];
+                if (use_tanh) v = __fmul_rn(tanh_c, tanhf(v));
+                win_logits[wbase + r] = v;
+                if (latent_win) v = __fadd_rn(v, latent_win[wbase + r]);
+                lg[p][r] = v;
+                if (best_r < 0 || v > best) {   // strict '>' keeps the first maximum
+                    best = v;
+                    best_r = r;
+                }
+            }
+            float denom = 0.0f;
+            for (int r = 0; r < n_per; ++r) denom = __fadd_rn(denom, expf(__fsub_rn(lg[p][r], best)));
+            pick_prob[(int64_t)(b0 + p) * T + k] = 1.0f / denom;   // exp(best-best)/sum
+            idx_out[(int64_t)(b0 + p) * T + k] = k * n_per + best_r;
+            sel[p] = k * n_per + best_r;
+        }
+        __syncthreads();
+
+        // ---- gathers: next decoder input (modelPN.py:235) and the action row (:293-295)
+#pragma unroll
+        for (int p = 0; p < BT; ++p) {
+            if (b0 + p < B) {
+                const int64_t row = (int64_t)(b0 + p) * L + sel[p];
+                if (owner) xs[p][j] = embedded[row * H + j];
+                if (j < 8) actions[((int64_t)(b0 + p) * T + k) * 8 + j] = inputs[row * 8 + j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int H>
+static void launch_decode(const float* embedded, const float* enc_out, const float* h0, const float* c0,
+                          const float* start, const float* wih, const float* whh, const float* bih,
+                          const float* bhh, const float* latent_win, const float* inputs, float tanh_c,
+                          int use_tanh, int32_t* idx, float* win_logits, float* pick_prob, float* actions,
+                          float* queries, int32_t B, int32_t T, int32_t n_per, hipStream_t s) {
+    constexpr int NT = H < 64 ? 64 : H;
+    int bt = 1;
+    while (bt < 4 && B / (bt * 2) >= 256) bt *= 2;
+    dim3 grid((B + bt - 1) / bt), block(NT);
+#define GNNPN_LAUNCH_DEC(BT_)                                                                                  \
+    hipLaunchKernelGGL((pointer_decode_kernel<H, BT_>), grid, block, 0, s, embedded, enc_out, h0, c0, start, wih, \
+                       whh, bih, bhh, latent_win, inputs, tanh_c, use_tanh, idx, win_logits, pick_prob, actions,  \
+                       queries, B, T, n_per)
+    switch (bt) {
+        case 1: GNNPN_LAUNCH_DEC(1); break;
+        case 2: GNNPN_LAUNCH_DEC(2); break;
+        default: GNNPN_LAUNCH_DEC(4); break;
+    }
+#undef GNNPN_LAUNCH_DEC
+}
+
+extern "C" int gnnpn_pointer_decode_f32(const float* embedded, const float* enc_out, const float* h0,
+                                        const float* c0, const float* start, const float* wih_packed,
+                                        const float* whh_packed, const float* bih, const float* bhh,
+                                        const float* latent_win, const float* inputs, float tanh_c, int use_tanh,
+                                        int32_t* idx, float* win_logits, float* pick_prob, float* actions,
+                                        float* queries, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                        void* stream) {
+    GNNPN_REQUIRE(embedded && enc_out && h0 && c0 && start && wih_packed && whh_packed && bih && bhh && inputs,
+                  "pointer_decode: null input");
+    GNNPN_REQUIRE(idx && win_logits && pick_prob && actions, "pointer_decode: null output");
+    GNNPN_REQUIRE(B >= 0 && T > 0, "pointer_decode: bad shape");
+    GNNPN_REQUIRE(n_per >= 1 && n_per <= 64, "pointer_decode: n_per must be in [1,64], got %d", n_per);
+    GNNPN_REQUIRE(gnnpn_aligned(wih_packed, 16) && gnnpn_aligned(whh_packed, 16) && gnnpn_aligned(enc_out, 16),
+                  "pointer_decode: weights / enc_out must be 16-byte aligned");
+    if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: hidden size %d not built (256, 32)", H);
+    if (B == 0) return GNNPN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 256)
+        launch_decode<256>(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, latent_win, inputs,
+                           tanh_c, use_tanh, idx, win_logits, pick_prob, actions, queries, B, T, n_per, s);
+    else
+        launch_decode<32>(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, latent_win, inputs,
+                          tanh_c, use_tanh, idx, win_logits, pick_prob, actions, queries, B, T, n_per, s);
+    GNNPN_CHECK_LAUNCH("pointer_decode_f32");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full-length logits of one step (API-compat, not on the fast path): wave per (b,l) row.
+__global__ __launch_bounds__(256) void attention_logits_kernel(const float* __restrict__ enc_out,
+                                                               const float* __restrict__ queries, int64_t ld_q,
+                                                               float tanh_c, int use_tanh, float* __restrict__ logits,
+                                                               int64_t n_rows, int32_t L, int32_t H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t b = row / L;
+    const float* e = enc_out + row * H;
+    const float* q = queries + b * ld_q;
+    float part = 0.0f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + i);
+        const float4 qv = *reinterpret_cast<const float4*>(q + i);
+        part = fmaf(ev.x, qv.x, part);
+        part = fmaf(ev.y, qv.y, part);
+        part = fmaf(ev.z, qv.z, part);
+        part = fmaf(ev.w, qv.w, part);
+    }
+    float v = wave_sum(part);
+    if (use_tanh) v = __fmul_rn(tanh_c, tanhf(v));
+    if (lane == 0) logits[row] = v;
+}
+
+__global__ void mask_logits_kernel(const int32_t* __restrict__ masked_idx, float* __restrict__ logits, int32_t B,
+                                   int32_t L, int32_t n_masked, int32_t ld_idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_masked) return;
+    const int b = i / n_masked, m = i - b * n_masked;
+    const int pos = masked_idx[(int64_t)b * ld_idx + m];
+    if (pos >= 0 && pos < L) logits[(int64_t)b * L + pos] = -INFINITY;
+}
+
+extern "C" int gnnpn_attention_logits_f32(const float* enc_out, const float* queries, int64_t ld_q,
+                                          const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits,
+                                          int32_t B, int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx,
+                                          void* stream) {
+    GNNPN_REQUIRE(enc_out && queries && logits, "attention_logits: null operand");
+    GNNPN_REQUIRE(B >= 0 && L > 0 && H > 0 && H % 4 == 0 && ld_q >= H && ld_q % 4 == 0, "attention_logits: bad shape");
+    GNNPN_REQUIRE(n_masked == 0 || (masked_idx && ld_idx >= n_masked), "attention_logits: bad mask list");
+    GNNPN_REQUIRE(gnnpn_aligned(enc_out, 16) && gnnpn_aligned(queries, 16), "attention_logits: 16-byte alignment");
+    if (B == 0) return GNNPN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_rows = (int64_t)B * L;
+    hipLaunchKernelGGL(attention_logits_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, enc_out, queries,
+                       ld_q, tanh_c, use_tanh, logits, n_rows, L, H);
+    if (n_masked > 0)
+        hipLaunchKernelGGL(mask_logits_kernel, dim3((B * n_masked + 255) / 256), dim3(256), 0, s, masked_idx, logits,
+                           B, L, n_masked, ld_idx);
+    GNNPN_CHECK_LAUNCH("attention_logits_f32");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// QoS reward (modelPN.py:15-72): one thread per problem, T sequential steps over 32 B rows.
+__global__ void qos_reward_kernel(const float* __restrict__ actions, float* __restrict__ R, int32_t B, int32_t T,
+                                  int level) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* a = actions + (int64_t)b * T * 8;
+    const float lo0 = a[4], hi0 = a[5], lo1 = a[6], hi1 = a[7];   // step-0 row (:51-54)
+    float prod2 = 1.0f, prod3 = 1.0f, mn = INFINITY;
+    double sum0 = 0.0;
+    int n_real = 0;
+    for (int t = 0; t < T; ++t) {
+        const float q0 = a[t * 8 + 0], q1 = a[t * 8 + 1], q2 = a[t * 8 + 2], q3 = a[t * 8 + 3];
+        sum0 += (double)q0;                       // np.sum(float32) is pairwise; fp64 then one rounding
+        n_real += q0 > 0.0f;                      // :26-28
+        mn = fminf(mn, q1);
+        prod2 = t == 0 ? q2 : __fmul_rn(prod2, q2);   // np.cumprod float32 (:20)
+        prod3 = t == 0 ? q3 : __fmul_rn(prod3, q3);
+    }
+    int violate = 0;
+    if (prod2 < lo0 || prod2 > hi0) ++violate;    // :23
+    if (prod3 < lo1 || prod3 > hi1) ++violate;
+    if (level == 0) {
+        R[b] = (float)violate;
+        return;
+    }
+    // objFunc = (sum/n + 1 - min)/2 in fp32 (:29), then round(violate + obj, 5) (:61)
+    float obj = (float)sum0 / (float)n_real;
+    obj = __fadd_rn(obj, 1.0f);
+    obj = __fsub_rn(obj, mn);
+    obj = obj / 2.0f;
+    const double v = (double)violate + (double)obj;
+    R[b] = (float)(rint(v * 1e5) / 1e5);
+}
+
+extern "C" int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, int level,
+                                    void* stream) {
+    GNNPN_REQUIRE(actions && R, "qos_reward: null operand");
+    GNNPN_REQUIRE(B >= 0 && T > 0 && (level == 0 || level == 1), "qos_reward: bad argument");
+    if (B == 0) return GNNPN_OK;
+    hipLaunchKernelGGL(qos_reward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, actions, R, B, T,
+                       level);
+    GNNPN_CHECK_LAUNCH("qos_reward_f32");
+    return GNNPN_OK;
+}

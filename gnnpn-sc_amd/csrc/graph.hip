@@ -1,0 +1,182 @@
+// Graph kernels of the GNN stage: CSR gather-aggregate (GIN / GCN message passing), GCN symmetric
+// normalisation, contiguous-segment mean.  All HBM/L2-bound gathers: one 64-lane wavefront per
+// destination row, the row's neighbour list (col, w) fetched 64 entries at a time with one
+// coalesced load per array and broadcast lane-by-lane, feature rows read as whole 16 B/lane
+// coalesced rows, 4 neighbour rows in flight per wave, accumulation strictly in CSR order with
+// separate multiply and add (the rounding of a materialised message followed by scatter_add).
+#include "common.h"
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void csr_aggregate_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef,
+    const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    float* __restrict__ y, int64_t ldy, int32_t n_rows, int32_t C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int e_begin = rowptr[row], e_end = rowptr[row + 1];
+    constexpr int V = VEC4 ? 4 : 1;
+    const float one_plus_eps = self_coef ? __fadd_rn(1.0f, *self_coef) : 0.0f;
+
+    for (int c0 = 0; c0 < C; c0 += 64 * V) {   // one pass covers 256 (VEC4) or 64 channels
+        const int c = c0 + lane * V;
+        const bool live = c < C;
+        float acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = 0.0f;
+
+        for (int e0 = e_begin; e0 < e_end; e0 += 64) {
+            const int cnt = min(64, e_end - e0);
+            int my_col = 0;
+            float my_w = 1.0f;
+            if (lane < cnt) {
+                my_col = col[e0 + lane];
+                if (w) my_w = w[e0 + lane];
+            }
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {   // 4 neighbour rows in flight, summed in order
+                float xv[4][V];
+                float wj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cj = __shfl(my_col, j + u, 64);
+                    wj[u] = __shfl(my_w, j + u, 64);
+                    const float* src = x + (int64_t)cj * ldx + c;
+                    if (live) {
+                        if (VEC4) {
+                            const float4 t = *reinterpret_cast<const float4*>(src);
+                            xv[u][0] = t.x; xv[u][V > 1 ? 1 : 0] = t.y; xv[u][V > 2 ? 2 : 0] = t.z; xv[u][V > 3 ? 3 : 0] = t.w;
+                        } else {
+                            xv[u][0] = src[0];
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) xv[u][v] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        acc[v] = __fadd_rn(acc[v], w ? __fmul_rn(wj[u], xv[u][v]) : xv[u][v]);
+            }
+            for (; j < cnt; ++j) {
+                const int cj = __shfl(my_col, j, 64);
+                const float wv = __shfl(my_w, j, 64);
+                if (live) {
+                    const float* src = x + (int64_t)cj * ldx + c;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float t = src[v];
+                        acc[v] = __fadd_rn(acc[v], w ? __fmul_rn(wv, t) : t);
+                    }
+                }
+            }
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float r = acc[v];
+            if (self_coef) r = __fadd_rn(r, __fmul_rn(one_plus_eps, x[(int64_t)row * ldx + c + v]));
+            if (bias) r = __fadd_rn(r, bias[c + v]);
+            if (scale) r = __fadd_rn(__fmul_rn(r, scale[c + v]), shift[c + v]);
+            acc[v] = apply_act(r, act);
+        }
+        float* dst = y + (int64_t)row * ldy + c;
+        if (VEC4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[V > 1 ? 1 : 0], acc[V > 2 ? 2 : 0], acc[V > 3 ? 3 : 0]);
+        } else {
+            dst[0] = acc[0];
+        }
+    }
+}
+
+extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
+                                       int64_t ldx, const float* self_coef, const float* bias,
+                                       const float* scale, const float* shift, int act, float* y, int64_t ldy,
+                                       int32_t n_rows, int32_t C, void* stream) {
+    GNNPN_REQUIRE(rowptr && x && y, "csr_aggregate: null operand");
+    GNNPN_REQUIRE(n_rows >= 0 && C > 0 && ldx >= C && ldy >= C, "csr_aggregate: bad shape");
+    GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "csr_aggregate: scale and shift go together");
+    GNNPN_REQUIRE(x != y, "csr_aggregate: in-place aggregation is not supported");
+    if (n_rows == 0) return GNNPN_OK;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gnnpn_aligned(x, 16) && gnnpn_aligned(y, 16);
+    dim3 grid((n_rows + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(csr_aggregate_kernel<true>, grid, block, 0, s, rowptr, col, w, x, ldx, self_coef, bias,
+                           scale, shift, act, y, ldy, n_rows, C);
+    else
+        hipLaunchKernelGGL(csr_aggregate_kernel<false>, grid, block, 0, s, rowptr, col, w, x, ldx, self_coef, bias,
+                           scale, shift, act, y, ldy, n_rows, C);
+    GNNPN_CHECK_LAUNCH("csr_aggregate_f32");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GCN normalisation.  deg: one wave per row would waste lanes on short rows; rows are summed
+// sequentially (scatter_add order) by one lane each — the arrays are tiny next to the features.
+__global__ void gcn_deg_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ w_raw,
+                               float* __restrict__ dis, int32_t n_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    float deg = 0.0f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) deg = __fadd_rn(deg, w_raw[e]);
+    // deg.pow(-0.5) is rsqrt = 1/sqrt (both correctly rounded on the CPU); inf -> 0
+    const float r = 1.0f / sqrtf(deg);
+    dis[i] = isinf(r) ? 0.0f : r;
+}
+
+__global__ void gcn_edge_norm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                     const float* __restrict__ w_raw, const float* __restrict__ dis,
+                                     float* __restrict__ norm, int32_t n_rows) {
+    // one wave per destination row: dis[src] * w * dis[dst], left to right
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float d_dst = dis[row];
+    for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64)
+        norm[e] = __fmul_rn(__fmul_rn(dis[col[e]], w_raw[e]), d_dst);
+}
+
+extern "C" int gnnpn_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, const float* w_raw,
+                                  float* deg_inv_sqrt, float* norm, int32_t n_rows, void* stream) {
+    GNNPN_REQUIRE(rowptr && col && w_raw && deg_inv_sqrt && norm, "gcn_norm: null operand");
+    GNNPN_REQUIRE(n_rows >= 0, "gcn_norm: bad shape");
+    if (n_rows == 0) return GNNPN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gcn_deg_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rowptr, w_raw, deg_inv_sqrt, n_rows);
+    hipLaunchKernelGGL(gcn_edge_norm_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, rowptr, col, w_raw,
+                       deg_inv_sqrt, norm, n_rows);
+    GNNPN_CHECK_LAUNCH("gcn_norm_f32");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_mean_kernel(const int32_t* __restrict__ segptr,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           float* __restrict__ out, int64_t ldo, int32_t n_seg,
+                                                           int32_t C) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_seg) return;
+    const int b = segptr[g], e = segptr[g + 1];
+    const float cnt = (float)max(e - b, 1);
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.0f;
+        for (int n = b; n < e; ++n) acc = __fadd_rn(acc, x[(int64_t)n * ldx + c]);
+        out[(int64_t)g * ldo + c] = acc / cnt;
+    }
+}
+
+extern "C" int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, float* out, int64_t ldo,
+                                      int32_t n_seg, int32_t C, void* stream) {
+    GNNPN_REQUIRE(segptr && x && out, "segment_mean: null operand");
+    GNNPN_REQUIRE(n_seg >= 0 && C > 0 && ldx >= C && ldo >= C, "segment_mean: bad shape");
+    if (n_seg == 0) return GNNPN_OK;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, (hipStream_t)stream, segptr, x,
+                       ldx, out, ldo, n_seg, C);
+    GNNPN_CHECK_LAUNCH("segment_mean_f32");
+    return GNNPN_OK;
+}

@@ -1,0 +1,128 @@
+// Candidate reduction (per problem x category top-K of the feasible services) and the full
+// per-row ranking.  Integer/compare work, HBM-bound on the score rows: one wavefront per
+// (problem, category) segment, each lane scanning a strided share of the segment; the K picks are
+// K wave-wide max-reductions over 64-bit keys (score order bits : inverted id), so ties resolve to
+// the lowest service id and the result does not depend on lane count or launch geometry.
+#include "common.h"
+
+__device__ __forceinline__ unsigned long long rank_key(float score, uint32_t id) {
+    return ((unsigned long long)float_order_key(score) << 32) | (0xffffffffu - id);
+}
+
+__global__ __launch_bounds__(256) void select_candidates_kernel(
+    const float* __restrict__ scores, int64_t ld_scores, const int32_t* __restrict__ cat_ptr,
+    const double* __restrict__ qos, const double* __restrict__ local_bounds, const uint8_t* __restrict__ present,
+    const double* __restrict__ global_bounds, float* __restrict__ out_rows, int32_t* __restrict__ out_ids,
+    int32_t B, int32_t T, int32_t n_per) {
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= (int64_t)B * T) return;
+    const int b = (int)(seg / T), c = (int)(seg - (int64_t)b * T);
+    const int s_begin = cat_ptr[c], s_end = cat_ptr[c + 1];
+    const bool pres = present[seg] != 0;
+    const double* lb = local_bounds + seg * 4;
+    const double lo_c = lb[0], hi_c = lb[1], lo_q = lb[2], hi_q = lb[3];
+    const float* srow = scores + (int64_t)b * ld_scores;
+
+    unsigned long long last = ~0ull;
+    int my_pick = -1;   // lane r keeps the r-th pick
+    int n_found = 0;
+    if (pres) {
+        for (int r = 0; r < n_per; ++r) {
+            unsigned long long best = 0ull;
+            for (int s = s_begin + lane; s < s_end; s += 64) {
+                const double cost = qos[(int64_t)s * 4 + 2], qual = qos[(int64_t)s * 4 + 3];
+                const bool feas = lo_c <= cost && cost <= hi_c && lo_q <= qual && qual <= hi_q;
+                const unsigned long long key = rank_key(srow[s], (uint32_t)s);
+                if (feas && key < last && key > best) best = key;
+            }
+            best = wave_max_u64(best);
+            if (best == 0ull) break;
+            if (lane == r) my_pick = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            last = best;
+            ++n_found;
+        }
+    }
+    // emit n_per rows: picks repeated cyclically (loadData.py:137-141), dummy rows otherwise (:148)
+    const int src_lane = n_found > 0 ? lane % n_found : 0;
+    const int id = __shfl(my_pick, src_lane, 64);
+    if (lane < n_per) {
+        const int64_t pos = (int64_t)b * T * n_per + (int64_t)c * n_per + lane;
+        float4 q, tail = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n_found > 0) {
+            const double* qs = qos + (int64_t)id * 4;
+            q = make_float4((float)qs[0], (float)qs[1], (float)qs[2], (float)qs[3]);
+        } else {
+            q = make_float4(0.f, 1.f, 1.f, 1.f);
+        }
+        if (c == 0) {
+            const double* g = global_bounds + (int64_t)b * 4;
+            tail = make_float4((float)g[0], (float)g[1], (float)g[2], (float)g[3]);
+        }
+        float4* dst = reinterpret_cast<float4*>(out_rows + pos * 8);
+        dst[0] = q;
+        dst[1] = tail;
+        out_ids[pos] = n_found > 0 ? id : -1;
+    }
+}
+
+extern "C" int gnnpn_select_candidates(const float* scores, int64_t ld_scores, const int32_t* cat_ptr,
+                                       const double* qos, const double* local_bounds, const uint8_t* present,
+                                       const double* global_bounds, float* out_rows, int32_t* out_ids, int32_t B,
+                                       int32_t T, int32_t n_per, void* stream) {
+    GNNPN_REQUIRE(scores && cat_ptr && qos && local_bounds && present && global_bounds && out_rows && out_ids,
+                  "select_candidates: null operand");
+    GNNPN_REQUIRE(B >= 0 && T > 0, "select_candidates: bad shape");
+    GNNPN_REQUIRE(n_per >= 1 && n_per <= 64, "select_candidates: n_per must be in [1,64], got %d", n_per);
+    GNNPN_REQUIRE(gnnpn_aligned(out_rows, 16), "select_candidates: out_rows must be 16-byte aligned");
+    if (B == 0) return GNNPN_OK;
+    const int64_t n_seg = (int64_t)B * T;
+    hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
+                       out_rows, out_ids, B, T, n_per);
+    GNNPN_CHECK_LAUNCH("select_candidates");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full ranking of one score row per workgroup: bitonic sort of 64-bit keys in LDS (descending).
+__global__ __launch_bounds__(1024) void rank_rows_kernel(const float* __restrict__ scores, int64_t ld_scores,
+                                                         int32_t* __restrict__ ranking, int32_t S, int32_t P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const float* srow = scores + (int64_t)blockIdx.x * ld_scores;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < S ? rank_key(srow[i], (uint32_t)i) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));   // lower index of the pair (bit j clear)
+                const int p = i + j;
+                const bool desc = (i & k) == 0;        // descending blocks first -> overall descending
+                const unsigned long long a = keys[i], b = keys[p];
+                if ((a < b) == desc) {
+                    keys[i] = b;
+                    keys[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int32_t* out = ranking + (int64_t)blockIdx.x * S;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) out[i] = (int32_t)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffu));
+}
+
+extern "C" int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
+                               void* stream) {
+    GNNPN_REQUIRE(scores && ranking, "rank_rows: null operand");
+    GNNPN_REQUIRE(B >= 0 && S > 0 && ld_scores >= S, "rank_rows: bad shape");
+    if (S > 16384) GNNPN_FAIL(GNNPN_E_UNSUP, "rank_rows: S=%d exceeds the single-workgroup LDS sort (16384)", S);
+    if (B == 0) return GNNPN_OK;
+    int P = 2;
+    while (P < S) P <<= 1;
+    const size_t lds = (size_t)P * sizeof(unsigned long long);
+    hipError_t e = hipFuncSetAttribute((const void*)rank_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) GNNPN_FAIL(GNNPN_E_LAUNCH, "rank_rows: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(rank_rows_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, ld_scores, ranking, S, P);
+    GNNPN_CHECK_LAUNCH("rank_rows");
+    return GNNPN_OK;
+}

@@ -1,0 +1,61 @@
+"""One process per GPU.  Composition problems are independent given the (replicated) weights and
+service table, so a batch shards contiguously across ranks with NO collective inside the path;
+the only exchange is ONE all-gather of the selected indices [B/N, T] int32 at the end
+(RCCL over xGMI on the GPU box — backend "nccl" is RCCL on ROCm; gloo in the CPU tests).
+The reference has no multi-device code; this module is new.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def init_process_group(backend, device=None):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not td.is_initialized():
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        td.init_process_group(backend=backend, **kw)
+    return td.get_rank(), td.get_world_size()
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n problems for ``rank`` (same split as DeviceBatch.shard)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def all_gather_indices(idx_local, sizes=None):
+    """idx_local [b_r, T] int32 -> [sum b_r, T] on every rank, rank order = problem order.
+    Equal shards use one all_gather_into_tensor; ragged shards pad to the largest."""
+    world = td.get_world_size()
+    if sizes is None or len(set(sizes)) == 1:
+        out = torch.empty((world * idx_local.shape[0],) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype,
+                          device=idx_local.device)
+        td.all_gather_into_tensor(out, idx_local.contiguous())
+        return out
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype, device=idx_local.device)
+    pad[: idx_local.shape[0]] = idx_local
+    out = torch.empty((world * m,) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype, device=idx_local.device)
+    td.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
+
+
+def barrier(world):
+    if world > 1:
+        td.barrier()
+
+
+def max_over_ranks(value, device, world):
+    if world <= 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def destroy(world):
+    if world > 1 and td.is_initialized():
+        td.destroy_process_group()

@@ -1,0 +1,213 @@
+"""GNN candidate-ranking model of the ML+2PN path behind the reference's entry point
+(/root/reference/src/models/modelML.py): ``Net(hiddenChannels, outChannels, embeddingChannels,
+numLayersGIN, numLayersGCN, isServices=True, dropout=0.0)`` with ``forward(data) -> [B,S]`` sigmoid
+scores, same ``state_dict`` keys/shapes (``nodeConvs.i.{eps,nn.0,nn.1,nn.3}``, ``serviceConvs.i.
+{weight [in,out], bias}``, ...).  torch modules are parameter containers only; the arithmetic runs in
+libgnnpn_hip.so:
+
+  GIN  (workflow graph) : csr_aggregate(sum_j x_j + (1+eps) x_i) -> linear+BN+ReLU -> linear+BN+ReLU
+  GCN  (service graph)  : gcn_norm -> linear (X.W, transform first) -> csr_aggregate(+bias,BN,ReLU)
+  head                  : linear, segment_mean, linear(score) + sigmoid
+
+Service-branch semantics: the service embedding is problem independent
+and is computed ONCE per forward from the first ``outChannels`` rows of ``data.x_service`` — the
+reference's B-fold replication inside a PyG batch (modelML.py:145-156,167-172) averages B copies
+of the same thing.
+"""
+import torch
+from torch import nn
+
+from . import graph, ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+BN_EPS = 1e-5
+
+
+class NodeEncoder(nn.Module):
+    """modelML.py:9-29 — nine Embedding(vocab, c) tables, of which callers only ever use table 0
+    (they pass one column, :134,146).  ``vocab`` defaults to the reference's 100 (:16)."""
+
+    def __init__(self, hiddenChannels, vocab=100):
+        super().__init__()
+        self.embeddings = nn.ModuleList(nn.Embedding(vocab, hiddenChannels) for _ in range(9))
+
+    def reset_parameters(self):
+        for e in self.embeddings:
+            e.reset_parameters()
+
+
+class GINConv(nn.Module):
+    """Parameter container with torch_geometric 1.7.0's GINConv(nn, train_eps=True) layout."""
+
+    def __init__(self, mlp):
+        super().__init__()
+        self.nn = mlp
+        self.eps = nn.Parameter(torch.zeros(1))
+
+    def reset_parameters(self):
+        for m in self.nn:
+            if hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        self.eps.data.zero_()
+
+
+class GCNConv(nn.Module):
+    """Parameter container with torch_geometric 1.7.0's GCNConv layout (weight stored in x out)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight)
+        nn.init.zeros_(self.bias)
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm1d as y = x*alpha + beta, computed the way ATen's CPU kernel does
+    (alpha = weight * 1/sqrt(var+eps); beta = bias - mean*alpha), in fp32 on the host, once."""
+    var, mean = bn.running_var.detach().float().cpu(), bn.running_mean.detach().float().cpu()
+    w, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+    alpha = w * (1.0 / torch.sqrt(var + bn.eps))
+    beta = b - mean * alpha
+    return alpha, beta
+
+
+class Net(nn.Module):
+    def __init__(self, hiddenChannels, outChannels, embeddingChannels, numLayersGIN, numLayersGCN,
+                 isServices=True, dropout=0.0, vocab=100):
+        super().__init__()
+        if not isServices:
+            raise NotImplementedError("isServices=False (noServicesLins branch, modelML.py:157-162) is not on the "
+                                      "ML+2PN path (trainML.py:125-126 always passes True)")
+        self.numLayersGIN, self.numLayersGCN = numLayersGIN, numLayersGCN
+        self.dropout, self.outChannels = dropout, outChannels
+        self.reqAndServiceChannels = embeddingChannels
+        self.qosNumber, self.constraintNumber, self.isService = 4, 2, isServices
+        h, c = hiddenChannels, embeddingChannels
+
+        self.nodeEncoder = NodeEncoder(c, vocab)
+        self.serviceEncoder = NodeEncoder(c, vocab)
+        self.nodeConvs, self.nodeBatchNorms = nn.ModuleList(), nn.ModuleList()
+        for i in range(numLayersGIN):                                              # :75-92
+            in_f = c + self.constraintNumber * 3 if i == 0 else h
+            self.nodeConvs.append(GINConv(nn.Sequential(nn.Linear(in_f, 2 * h), nn.BatchNorm1d(2 * h), nn.ReLU(),
+                                                        nn.Linear(2 * h, h))))
+            self.nodeBatchNorms.append(nn.BatchNorm1d(h))
+        self.nodeLin = nn.Linear(h, h)                                             # :93
+        self.serviceConvs, self.serviceBatchNorms = nn.ModuleList(), nn.ModuleList()
+        for i in range(numLayersGCN):                                              # :98-104
+            self.serviceConvs.append(GCNConv(c + self.qosNumber if i == 0 else 2 * h, 2 * h))
+            self.serviceBatchNorms.append(nn.BatchNorm1d(2 * h))
+        self.serviceLin = nn.Linear(2 * h, h)                                      # :106
+        self.noServicesLins = nn.ModuleList(                                       # :108-115 (state_dict parity)
+            nn.Linear(c + self.qosNumber if i == 0 else 2 * h, 2 * h) for i in range(numLayersGCN))
+        self._prep = None
+
+    def reset_parameters(self):                                                    # :117-129
+        self.nodeEncoder.reset_parameters()
+        self.serviceEncoder.reset_parameters()
+        for conv, bn in zip(self.nodeConvs, self.nodeBatchNorms):
+            conv.reset_parameters()
+            bn.reset_parameters()
+        self.nodeLin.reset_parameters()
+        for conv, bn in zip(self.serviceConvs, self.serviceBatchNorms):
+            conv.reset_parameters()
+            bn.reset_parameters()
+        self.serviceLin.reset_parameters()
+        self._prep = None
+
+    def _load_from_state_dict(self, *a, **k):
+        self._prep = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def prepared(self, device):
+        """Kernel-ready constants (BN folded to alpha/beta, GCN weights as [out,in]) on ``device``."""
+        if self._prep is not None and self._prep["device"] == device:
+            return self._prep
+        f = lambda t: t.detach().float().contiguous().to(device)   # noqa: E731
+        p = {"device": device, "gin": [], "gcn": [],
+             "node_table": f(self.nodeEncoder.embeddings[0].weight),
+             "service_table": f(self.serviceEncoder.embeddings[0].weight)}
+        for conv, bn in zip(self.nodeConvs, self.nodeBatchNorms):
+            a1, b1 = _bn_affine(conv.nn[1])
+            a2, b2 = _bn_affine(bn)
+            p["gin"].append({"eps": f(conv.eps), "w0": f(conv.nn[0].weight), "b0": f(conv.nn[0].bias),
+                             "a1": a1.to(device), "s1": b1.to(device), "w3": f(conv.nn[3].weight),
+                             "b3": f(conv.nn[3].bias), "a2": a2.to(device), "s2": b2.to(device)})
+        for conv, bn in zip(self.serviceConvs, self.serviceBatchNorms):
+            a, b = _bn_affine(bn)
+            p["gcn"].append({"wt": f(conv.weight.detach().t()), "bias": f(conv.bias), "a": a.to(device),
+                             "s": b.to(device)})
+        p["nodeLin"] = (f(self.nodeLin.weight), f(self.nodeLin.bias))
+        p["serviceLin"] = (f(self.serviceLin.weight), f(self.serviceLin.bias))
+        self._prep = p
+        return p
+
+    # ---- the two branches + head, on kernel-ready inputs ---------------------------------------
+    @torch.no_grad()
+    def request_embedding(self, x, wf_csr, seg_ptr):
+        """Workflow branch (modelML.py:133-143,165-166): x [N,7], CSR of the batched workflow graphs,
+        graph segment pointer -> [B, hidden]."""
+        p = self.prepared(x.device)
+        h = ops.embed_concat(x, p["node_table"])                                               # :134-137
+        for lp in p["gin"]:                                                                     # :139-142
+            agg = ops.csr_aggregate(wf_csr.rowptr, wf_csr.col, None, h, self_coef=lp["eps"])
+            t = ops.linear(agg, lp["w0"], lp["b0"], lp["a1"], lp["s1"], ACT_RELU)
+            h = ops.linear(t, lp["w3"], lp["b3"], lp["a2"], lp["s2"], ACT_RELU)
+        h = ops.linear(h, *p["nodeLin"])                                                        # :165
+        return ops.segment_mean(seg_ptr, h)                                                     # :166
+
+    @torch.no_grad()
+    def service_embedding(self, x_service, svc_csr):
+        """Service branch (modelML.py:145-156,164): x_service [S,5], self-loop-complete CSR with RAW
+        edge weights -> [S, hidden]."""
+        p = self.prepared(x_service.device)
+        xs = ops.embed_concat(x_service, p["service_table"])                                    # :146-149
+        norm = ops.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
+        for lp in p["gcn"]:                                                                     # :152-155
+            xw = ops.linear(xs, lp["wt"])                                                       # transform first
+            xs = ops.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
+                                   shift=lp["s"], act=ACT_RELU)
+        return ops.linear(xs, *p["serviceLin"])                                                 # :164
+
+    @torch.no_grad()
+    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr):
+        xr = self.request_embedding(x, wf_csr, seg_ptr)
+        xs = self.service_embedding(x_service, svc_csr)
+        return ops.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176
+
+    def forward(self, data):
+        """Net.forward (modelML.py:131-176) on a PyG-style ``data`` object with attributes x,
+        edge_index, batch, x_service, edge_index_service, edge_attr_service (device tensors).
+        The CSR layouts are cached on ``data`` (``_gnnpn_csr``) so repeated forwards skip the sort."""
+        if self.training:
+            raise NotImplementedError("training mode: this build is the inference path only")
+        x = data.x.squeeze().float().contiguous()
+        cache = getattr(data, "_gnnpn_csr", None)
+        if cache is None:
+            S = self.outChannels
+            n_graphs = int(data.batch.max().item()) + 1
+            ei_s, ea_s = data.edge_index_service, data.edge_attr_service
+            if data.x_service.shape[0] > S:                      # B replicated copies: keep copy 0
+                m = (ei_s[0] < S) & (ei_s[1] < S)
+                ei_s, ea_s = ei_s[:, m], ea_s[m]
+            cache = {"wf": graph.csr_by_destination(data.edge_index, x.shape[0]),
+                     "seg": graph.segment_ptr(data.batch, n_graphs),
+                     "svc": graph.gcn_csr(ei_s, ea_s, S),
+                     "xs": data.x_service.squeeze()[:S].float().contiguous()}
+            try:
+                data._gnnpn_csr = cache
+            except AttributeError:
+                pass
+        return self.scores(x, cache["wf"], cache["seg"], cache["xs"], cache["svc"])

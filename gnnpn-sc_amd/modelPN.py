@@ -1,0 +1,255 @@
+"""Pointer-network side of the ML+2PN path, behind the reference's entry points
+(/root/reference/src/models/modelPN.py): ``CombinatorialRL`` (:244-306), ``PointerNet``
+(:126-241), ``reward`` (:35-72), ``calc`` (:15-32).  Same constructor arguments, same
+``state_dict`` keys/shapes (``actor.embedding2.*``, ``actor.encoder.*_l0``, ``actor.decoder.*_l0``,
+``actor.decoder_start_input``), same 5-tuple from ``forward`` — but every tensor operation runs
+in the hand-written gfx950 kernels of libgnnpn_hip.so (``ops.py``); torch modules are used here
+only as parameter containers.
+
+Scope of this build = the inference configuration the reference ships
+(/root/reference/environment.ini:49-79, src/models/trainPNHigh.py:208-236):
+``embedding_size=0``, ``n_glimpses=0``, ``attention='Dot'``, ``sample='greedy'``.  Anything else
+raises ``NotImplementedError`` (sampling / training are SURVEY.md §8f "next" rows).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+qosandcons = 8   # modelPN.py:10
+qosNum = 4       # modelPN.py:11
+consNum = 2      # modelPN.py:12
+
+
+class LatentWindows:
+    """What a Low-level forward hands to the High-level forward (`latent`, trainPNHigh.py:138-139).
+
+    The reference passes a python list of T full-length ``[B, L]`` logits tensors although only
+    the ``[k*K,(k+1)*K)`` window of entry k can influence anything (modelPN.py:216,220-222).
+    This object keeps the compact ``win [B,T,K]`` tensor the kernels exchange and behaves like
+    that list on demand: ``len()``, iteration and ``[k]`` materialise the reference's full-length
+    tensor for step k (window logits in place, -inf at previously chosen positions, the remaining
+    positions computed by gnnpn_attention_logits_f32)."""
+
+    def __init__(self, win, idx, enc_out, queries, tanh_c, use_tanh):
+        self.win, self.idx = win, idx
+        self._enc_out, self._queries = enc_out, queries
+        self._tanh_c, self._use_tanh = tanh_c, use_tanh
+
+    def __len__(self):
+        return self.win.shape[1]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        return ops.attention_logits(self._enc_out, self._queries, k, self.idx, self._tanh_c, self._use_tanh)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def copy(self):      # modelPN.py:291 calls logits.copy()
+        return self
+
+
+def _window_tensor(latent, n_cat, n_per):
+    """Accept the reference's list-of-[B,L] form as well as LatentWindows."""
+    if latent is None:
+        return None
+    if isinstance(latent, LatentWindows):
+        return latent.win
+    if len(latent) != n_cat:
+        raise ValueError(f"latent has {len(latent)} steps, expected {n_cat}")
+    return torch.stack([latent[k][:, k * n_per:(k + 1) * n_per] for k in range(n_cat)], 1).contiguous()
+
+
+class PointerNet(nn.Module):
+    """Parameter container + kernel driver for PointerNet (modelPN.py:126-241)."""
+
+    def __init__(self, embedding_size, hidden_size, seq_len, n_glimpses, tanh_exploration, use_tanh, attention,
+                 sNumber, sCategory, use_cuda=True, level="low", mask=False):
+        super().__init__()
+        if embedding_size != 0:
+            raise NotImplementedError("embedding_size != 0 (embeddingTag=1) is outside the ML+2PN inference "
+                                      "configuration (environment.ini:50,66)")
+        if n_glimpses != 0:
+            raise NotImplementedError("n_glimpses != 0 is outside the shipped configuration (environment.ini:56)")
+        if attention != "Dot":
+            raise NotImplementedError(f"attention {attention!r}: only 'Dot' is used on the path "
+                                      "(trainPNHigh.py:216,233)")
+        self.embedding_size, self.hidden_size, self.n_glimpses = embedding_size, hidden_size, n_glimpses
+        self.seq_len, self.use_cuda, self.level = seq_len, use_cuda, level
+        self.serNumber, self.serCategory = sNumber, sCategory
+        self.C, self.use_tanh, self.mask = float(tanh_exploration), bool(use_tanh), mask
+        self.embedding2 = nn.Linear(embedding_size + qosandcons, hidden_size)          # :155
+        self.encoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :157 (container)
+        self.decoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :158 (container)
+        self.decoder_start_input = nn.Parameter(torch.FloatTensor(hidden_size))        # :162-163
+        self.decoder_start_input.data.uniform_(-(1. / math.sqrt(hidden_size)), 1. / math.sqrt(hidden_size))
+        self._packed = None
+
+    # weights are re-laid-out once (k-major float4 packing for the recurrent kernels)
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def packed(self):
+        if self._packed is None:
+            f = lambda t: t.detach().float().contiguous()   # noqa: E731
+            self._packed = {
+                "emb_w": f(self.embedding2.weight), "emb_b": f(self.embedding2.bias),
+                "enc_wih": f(self.encoder.weight_ih_l0), "enc_bih": f(self.encoder.bias_ih_l0),
+                "enc_whh": ops.pack_lstm_weight(f(self.encoder.weight_hh_l0)), "enc_bhh": f(self.encoder.bias_hh_l0),
+                "dec_wih": ops.pack_lstm_weight(f(self.decoder.weight_ih_l0)), "dec_bih": f(self.decoder.bias_ih_l0),
+                "dec_whh": ops.pack_lstm_weight(f(self.decoder.weight_hh_l0)), "dec_bhh": f(self.decoder.bias_hh_l0),
+                "start": f(self.decoder_start_input),
+            }
+        return self._packed
+
+    def embed(self, inputs):
+        """embedding2 (:190) and the encoder's input projection x_t.W_ih^T + b_ih (inside :191)."""
+        B, L, F = inputs.shape
+        assert L == self.seq_len                                                        # :182
+        w = self.packed()
+        embedded = ops.linear(inputs.reshape(B * L, F), w["emb_w"], w["emb_b"])
+        pregates = ops.linear(embedded, w["enc_wih"], w["enc_bih"])
+        H = self.hidden_size
+        return embedded.view(B, L, H), pregates.view(B, L, 4 * H)
+
+    def decode(self, inputs, embedded, enc_out, h_n, c_n, latent_win, want_queries=False):
+        w = self.packed()
+        return ops.pointer_decode(embedded, enc_out, h_n, c_n, w["start"], w["dec_wih"], w["dec_whh"], w["dec_bih"],
+                                  w["dec_bhh"], inputs, self.serCategory, self.serNumber, latent_win, self.C,
+                                  self.use_tanh, want_queries)
+
+    @torch.no_grad()
+    def run(self, inputs, latent=None, want_queries=False):
+        """Encode + greedy decode; returns the decode dict of ops.pointer_decode plus enc_out."""
+        inputs = inputs.contiguous()
+        embedded, pregates = self.embed(inputs)
+        w = self.packed()
+        enc, h_n, c_n = ops.lstm_encode([pregates], [w["enc_whh"]], [w["enc_bhh"]])
+        out = self.decode(inputs, embedded, enc[0], h_n[0], c_n[0],
+                          _window_tensor(latent, self.serCategory, self.serNumber), want_queries)
+        out["enc_out"] = enc[0]
+        return out
+
+    def forward(self, inputs, latent, sample="sample"):
+        """(probs, idxs, logits) lists as PointerNet.forward returns them (:241).  probs / logits
+        are lazily materialised full-length views (see LatentWindows)."""
+        if sample != "greedy":
+            raise NotImplementedError("only sample='greedy' (the inference path, trainPNHigh.py:138-139)")
+        out = self.run(inputs, latent, want_queries=True)
+        lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.C, self.use_tanh)
+        idxs = [out["idx"][:, k].long() for k in range(self.serCategory)]
+        return _ProbList(out, latent, self.serCategory, self.serNumber), idxs, lat
+
+
+class _ProbList:
+    """The reference's ``probs`` list (T x [B,L] softmax rows, zero outside the step's window)."""
+
+    def __init__(self, out, latent, n_cat, n_per):
+        win = out["win_logits"]
+        lw = _window_tensor(latent, n_cat, n_per)
+        self._p = torch.softmax(win if lw is None else win + lw, dim=2)   # [B,T,K], compat path only
+        self._n_per, self._L = n_per, n_cat * n_per
+
+    def __len__(self):
+        return self._p.shape[1]
+
+    def __getitem__(self, k):
+        B = self._p.shape[0]
+        full = torch.zeros((B, self._L), dtype=self._p.dtype, device=self._p.device)
+        full[:, k * self._n_per:(k + 1) * self._n_per] = self._p[:, k]
+        return full
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+def calc(services, constraints, sCategory):
+    """calc (modelPN.py:15-32) for ONE problem given as the reference passes it (list of T rows of
+    >= 4 values, constraints [[lo,hi]] per global constraint).  Host helper kept for API parity;
+    the batched device version is ops.qos_reward."""
+    rows = torch.stack([torch.as_tensor(s)[:qosNum].float().cpu() for s in services]).unsqueeze(0)
+    act = torch.zeros((1, rows.shape[1], 8), dtype=torch.float32)
+    act[0, :, :qosNum] = rows[0]
+    for i in range(consNum):
+        act[0, 0, qosNum + 2 * i], act[0, 0, qosNum + 2 * i + 1] = constraints[i][0][-2], constraints[i][0][-1]
+    dev = torch.device("cuda")
+    violate = int(ops.qos_reward(act.to(dev), "Low").item())
+    total = float(ops.qos_reward(act.to(dev), "High").item())
+    return violate, total - violate, []
+
+
+def reward(sample_solution, optSolutions, sCategory, USE_CUDA=False, level="Low", embedding_size=20,
+           verbose=False):
+    """reward (modelPN.py:35-72): list of T ``[B, 8]`` action tensors -> FloatTensor [B].
+    The reference prints the whole list (:67); here only with ``verbose=True``."""
+    if embedding_size != 0:
+        raise NotImplementedError("embedding_size != 0 is outside the ML+2PN inference configuration")
+    actions = torch.stack(list(sample_solution), dim=1).contiguous()
+    R = ops.qos_reward(actions, level)
+    if verbose:
+        lst = R.tolist()
+        print(f"{level}, {sum(1 for v in lst if v >= 1)}, {sum(lst) / max(len(lst), 1)}: ", lst)
+    return R
+
+
+class CombinatorialRL(nn.Module):
+    """CombinatorialRL (modelPN.py:244-306)."""
+
+    def __init__(self, embedding_size, hidden_size, seq_len, n_glimpses, tanh_exploration, use_tanh, reward,
+                 attention, sNumber, sCategory, use_cuda=True, level="Low", mask=False):
+        super().__init__()
+        self.reward = reward
+        self.use_cuda, self.level, self.embedding_size = use_cuda, level, embedding_size
+        self.sNumber, self.serCategory = sNumber, sCategory
+        self.actor = PointerNet(embedding_size, hidden_size, seq_len, n_glimpses, tanh_exploration, use_tanh,
+                                attention, sNumber, sCategory, use_cuda, level=level, mask=mask)
+
+    @torch.no_grad()
+    def forward(self, inputs, labs, latent=None, sample="sample", training="RL"):
+        """-> (R | probs, action_probs T x [B], actions T x [B,8], action_idxs T x [B] int64, latent_p)."""
+        if sample != "greedy":
+            raise NotImplementedError("only sample='greedy' (the inference path, trainPNHigh.py:138-139)")
+        out = self.actor.run(inputs, latent, want_queries=True)
+        T = self.serCategory
+        action_idxs = [out["idx"][:, k].long() for k in range(T)]
+        actions = [out["actions"][:, k, :] for k in range(T)]                       # :293-295
+        action_probs = [out["pick_prob"][:, k] for k in range(T)]                   # :297-299
+        latent_p = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.actor.C,
+                                 self.actor.use_tanh)
+        if training == "RL":                                                        # :301-304
+            R = self.reward(actions, labs, self.serCategory, USE_CUDA=self.use_cuda, level=self.level,
+                            embedding_size=self.embedding_size)
+            return R, action_probs, actions, action_idxs, latent_p
+        return (_ProbList(out, latent, T, self.sNumber), action_probs, actions, action_idxs, latent_p)
+
+
+@torch.no_grad()
+def two_level_greedy(low, high, inputs):
+    """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
+    ONE launch (they are independent), Low decode, High decode biased by Low's window logits,
+    QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
+    action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
+    win_high_raw + win_low (modelPN.py:216)."""
+    inputs = inputs.contiguous()
+    la, ha = low.actor, high.actor
+    emb_l, pre_l = la.embed(inputs)
+    emb_h, pre_h = ha.embed(inputs)
+    wl, wh = la.packed(), ha.packed()
+    enc, h_n, c_n = ops.lstm_encode([pre_l, pre_h], [wl["enc_whh"], wh["enc_whh"]], [wl["enc_bhh"], wh["enc_bhh"]])
+    del pre_l, pre_h
+    dl = la.decode(inputs, emb_l, enc[0], h_n[0], c_n[0], None)
+    dh = ha.decode(inputs, emb_h, enc[1], h_n[1], c_n[1], dl["win_logits"])
+    R = ops.qos_reward(dh["actions"], high.level)
+    return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
+            "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -1,0 +1,180 @@
+"""Thin tensor-level wrappers over the C ABI (``include/gnnpn_hip.h``): validate, allocate the
+output with torch (device memory only), pass raw pointers + the current HIP stream.  No compute
+happens in Python; there is no CPU path — non-CUDA tensors raise ``GnnpnError``.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, GnnpnError, check, dev_ptr, ptr_array, stream_ptr  # noqa: F401
+
+F32, I32, F64, U8 = torch.float32, torch.int32, torch.float64, torch.uint8
+
+
+def _rows2d(t, name):
+    if t.dim() != 2:
+        raise GnnpnError(f"{name}: expected a 2-D tensor, got shape {tuple(t.shape)}")
+    return t
+
+
+def linear(a, weight, bias=None, scale=None, shift=None, act=ACT_NONE, out=None):
+    """out[M,N] = act((a[M,K] @ weight[N,K]^T + bias) * scale + shift)   (gnnpn_linear_f32)."""
+    a, weight = _rows2d(a, "linear.a"), _rows2d(weight, "linear.weight")
+    M, K = a.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise GnnpnError(f"linear: K mismatch {a.shape} x {weight.shape}")
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=a.device)
+    lib = _lib.load()
+    check(lib.gnnpn_linear_f32(dev_ptr(a, F32, "a"), K, dev_ptr(weight, F32, "weight"), K,
+                               dev_ptr(bias, F32, "bias", True), dev_ptr(scale, F32, "scale", True),
+                               dev_ptr(shift, F32, "shift", True), act, dev_ptr(out, F32, "out"), N, M, N, K,
+                               stream_ptr()), "gnnpn_linear_f32")
+    return out
+
+
+def embed_concat(x, table):
+    """[n, 1+f] rows ``[id, f floats]`` -> [n, emb+f] = [table[id] | floats]   (gnnpn_embed_concat_f32)."""
+    x, table = _rows2d(x, "embed_concat.x"), _rows2d(table, "embed_concat.table")
+    n, nfeat = x.shape[0], x.shape[1] - 1
+    vocab, emb = table.shape
+    out = torch.empty((n, emb + nfeat), dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_embed_concat_f32(dev_ptr(x, F32, "x"), dev_ptr(table, F32, "table"), vocab, emb, nfeat,
+                                             dev_ptr(out, F32, "out"), n, stream_ptr()), "gnnpn_embed_concat_f32")
+    return out
+
+
+def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE):
+    """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32)."""
+    x = _rows2d(x, "csr_aggregate.x")
+    n = rowptr.numel() - 1
+    C = x.shape[1]
+    y = torch.empty((n, C), dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_csr_aggregate_f32(
+        dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
+        dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
+        dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act, dev_ptr(y, F32, "y"), C, n, C,
+        stream_ptr()), "gnnpn_csr_aggregate_f32")
+    return y
+
+
+def gcn_norm(rowptr, col, w_raw):
+    """Symmetric GCN normalisation on a self-loop-complete destination-major CSR -> norm[e]."""
+    n = rowptr.numel() - 1
+    dis = torch.empty(n, dtype=F32, device=w_raw.device)
+    norm = torch.empty_like(w_raw)
+    check(_lib.load().gnnpn_gcn_norm_f32(dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"),
+                                         dev_ptr(w_raw, F32, "w_raw"), dev_ptr(dis, F32, "dis"),
+                                         dev_ptr(norm, F32, "norm"), n, stream_ptr()), "gnnpn_gcn_norm_f32")
+    return norm
+
+
+def segment_mean(segptr, x):
+    x = _rows2d(x, "segment_mean.x")
+    n_seg, C = segptr.numel() - 1, x.shape[1]
+    out = torch.empty((n_seg, C), dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_segment_mean_f32(dev_ptr(segptr, I32, "segptr"), dev_ptr(x, F32, "x"), C,
+                                             dev_ptr(out, F32, "out"), C, n_seg, C, stream_ptr()),
+          "gnnpn_segment_mean_f32")
+    return out
+
+
+def select_candidates(scores, cat_ptr, qos, local_bounds, present, global_bounds, n_per):
+    """Per (problem, category) top-``n_per`` feasible services -> (rows [B,L,8] fp32, ids [B,L] int32)."""
+    scores = _rows2d(scores, "select.scores")
+    B, S = scores.shape
+    T = cat_ptr.numel() - 1
+    if qos.shape != (S, 4) or local_bounds.shape != (B, T, 4) or present.shape != (B, T) \
+            or global_bounds.shape != (B, 4):
+        raise GnnpnError("select_candidates: inconsistent shapes")
+    rows = torch.empty((B, T * n_per, 8), dtype=F32, device=scores.device)
+    ids = torch.empty((B, T * n_per), dtype=I32, device=scores.device)
+    check(_lib.load().gnnpn_select_candidates(
+        dev_ptr(scores, F32, "scores"), S, dev_ptr(cat_ptr, I32, "cat_ptr"), dev_ptr(qos, F64, "qos"),
+        dev_ptr(local_bounds, F64, "local_bounds"), dev_ptr(present, U8, "present"),
+        dev_ptr(global_bounds, F64, "global_bounds"), dev_ptr(rows, F32, "rows"), dev_ptr(ids, I32, "ids"), B, T,
+        n_per, stream_ptr()), "gnnpn_select_candidates")
+    return rows, ids
+
+
+def rank_rows(scores):
+    """Full descending ranking per row, ties -> lowest id (int32 [B,S])."""
+    scores = _rows2d(scores, "rank_rows.scores")
+    B, S = scores.shape
+    ranking = torch.empty((B, S), dtype=I32, device=scores.device)
+    check(_lib.load().gnnpn_rank_rows(dev_ptr(scores, F32, "scores"), S, dev_ptr(ranking, I32, "ranking"), B, S,
+                                      stream_ptr()), "gnnpn_rank_rows")
+    return ranking
+
+
+def pack_lstm_weight(w):
+    """[4H, H] (gate-major rows, torch.nn.LSTM layout) -> [H/4, 4, H, 4]: element [k4][g][j][i] =
+    w[g*H + j][4*k4 + i].  A one-time layout change at weight-load time (no arithmetic)."""
+    H = w.shape[1]
+    if w.shape[0] != 4 * H or H % 4:
+        raise GnnpnError(f"pack_lstm_weight: expected [4H,H], got {tuple(w.shape)}")
+    return w.reshape(4, H, H // 4, 4).permute(2, 0, 1, 3).contiguous()
+
+
+def lstm_encode(pregates, whh_packed, bhh):
+    """Run the encoder recurrence of len(pregates) nets in ONE launch.
+    pregates[n] [B,L,4H] -> (enc_out[n] [B,L,H], h_n[n] [B,H], c_n[n] [B,H])."""
+    n = len(pregates)
+    B, L, H4 = pregates[0].shape
+    H = H4 // 4
+    dev = pregates[0].device
+    enc = [torch.empty((B, L, H), dtype=F32, device=dev) for _ in range(n)]
+    h_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
+    c_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
+    check(_lib.load().gnnpn_lstm_encode_f32(
+        n, ptr_array(pregates, F32, "pregates"), ptr_array(whh_packed, F32, "whh"), ptr_array(bhh, F32, "bhh"),
+        ptr_array(enc, F32, "enc_out"), ptr_array(h_n, F32, "h_n"), ptr_array(c_n, F32, "c_n"), B, L, H,
+        stream_ptr()), "gnnpn_lstm_encode_f32")
+    return enc, h_n, c_n
+
+
+def pointer_decode(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, inputs, n_cat, n_per,
+                   latent_win=None, tanh_c=10.0, use_tanh=True, want_queries=False):
+    """Greedy decode of one net -> dict(idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T],
+    actions [B,T,8], queries [B,T,H] | None)."""
+    B, L, H = enc_out.shape
+    if L != n_cat * n_per:
+        raise GnnpnError(f"pointer_decode: seq_len {L} != {n_cat}*{n_per}")   # modelPN.py:182
+    dev = enc_out.device
+    idx = torch.empty((B, n_cat), dtype=I32, device=dev)
+    win = torch.empty((B, n_cat, n_per), dtype=F32, device=dev)
+    prob = torch.empty((B, n_cat), dtype=F32, device=dev)
+    actions = torch.empty((B, n_cat, 8), dtype=F32, device=dev)
+    queries = torch.empty((B, n_cat, H), dtype=F32, device=dev) if want_queries else None
+    check(_lib.load().gnnpn_pointer_decode_f32(
+        dev_ptr(embedded, F32, "embedded"), dev_ptr(enc_out, F32, "enc_out"), dev_ptr(h0, F32, "h0"),
+        dev_ptr(c0, F32, "c0"), dev_ptr(start, F32, "start"), dev_ptr(wih_packed, F32, "wih"),
+        dev_ptr(whh_packed, F32, "whh"), dev_ptr(bih, F32, "bih"), dev_ptr(bhh, F32, "bhh"),
+        dev_ptr(latent_win, F32, "latent_win", True), dev_ptr(inputs, F32, "inputs"), float(tanh_c),
+        int(bool(use_tanh)), dev_ptr(idx, I32, "idx"), dev_ptr(win, F32, "win"), dev_ptr(prob, F32, "prob"),
+        dev_ptr(actions, F32, "actions"), dev_ptr(queries, F32, "queries", True), B, n_cat, n_per, H,
+        stream_ptr()), "gnnpn_pointer_decode_f32")
+    return {"idx": idx, "win_logits": win, "pick_prob": prob, "actions": actions, "queries": queries}
+
+
+def attention_logits(enc_out, queries, step, idx, tanh_c=10.0, use_tanh=True):
+    """Full [B,L] logits of decode step ``step`` with -inf at the ``step`` previously chosen
+    positions (API-compat path, see gnnpn_attention_logits_f32)."""
+    B, L, H = enc_out.shape
+    T = queries.shape[1]
+    out = torch.empty((B, L), dtype=F32, device=enc_out.device)
+    q = queries[:, step, :]
+    check(_lib.load().gnnpn_attention_logits_f32(
+        dev_ptr(enc_out, F32, "enc_out"), _lib.ctypes.c_void_p(q.data_ptr()), T * H, dev_ptr(idx, I32, "idx"),
+        float(tanh_c), int(bool(use_tanh)), dev_ptr(out, F32, "logits"), B, L, H, step, T, stream_ptr()),
+        "gnnpn_attention_logits_f32")
+    return out
+
+
+def qos_reward(actions, level):
+    """actions [B,T,8] -> R [B]; level 'Low' -> #violations, 'High' -> round(violations + objective, 5)."""
+    B, T, _ = actions.shape
+    R = torch.empty(B, dtype=F32, device=actions.device)
+    check(_lib.load().gnnpn_qos_reward_f32(dev_ptr(actions, F32, "actions"), dev_ptr(R, F32, "R"), B, T,
+                                           0 if level == "Low" else 1, stream_ptr()), "gnnpn_qos_reward_f32")
+    return R

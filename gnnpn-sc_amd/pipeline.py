@@ -1,0 +1,108 @@
+"""Device-resident end-to-end ML+2PN inference: what the reference spreads over
+``TrainML.test`` (/root/reference/src/models/trainML.py:49-72) -> JSON -> ``loadDataPN``
+(src/loadData.py:72-152) -> JSON -> the eval block of ``TrainModel.train_and_validate``
+(src/models/trainPNHigh.py:131-150), as one stream of kernels with nothing leaving HBM between
+the stages:
+
+    GNN scores [B,S] -> per-category top-K feasible candidates -> PN input rows [B,L,8]
+    -> Low/High encoders (one launch) -> Low decode -> High decode -> QoS reward
+
+Inputs are ``DeviceBatch``/``DeviceServices`` (packed once from the host structures of synth.py /
+loadData.py); outputs stay on the device.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import graph, ops
+from .modelPN import two_level_greedy
+
+
+@dataclass
+class DeviceServices:
+    """Problem-independent service side, resident in HBM."""
+    x_service: torch.Tensor      # f32 [S,5]
+    csr: graph.CSR               # self-loop-complete destination-major CSR, raw weights
+    cat_ptr: torch.Tensor        # i32 [T+1]
+    qos: torch.Tensor            # f64 [S,4]
+
+    @staticmethod
+    def from_table(table, device):
+        ei = torch.from_numpy(np.ascontiguousarray(table.edge_index))
+        ea = torch.from_numpy(np.ascontiguousarray(table.edge_attr))
+        csr = graph.gcn_csr(ei, ea, table.n_services).to(device)
+        return DeviceServices(torch.from_numpy(table.x_service).to(device), csr,
+                              torch.from_numpy(np.ascontiguousarray(table.cat_ptr)).to(device),
+                              torch.from_numpy(np.ascontiguousarray(table.qos)).to(device))
+
+
+@dataclass
+class DeviceBatch:
+    """B composition requests, resident in HBM."""
+    x: torch.Tensor              # f32 [N,7]
+    wf_csr: graph.CSR
+    seg_ptr: torch.Tensor        # i32 [B+1]
+    local_bounds: torch.Tensor   # f64 [B,T,4]
+    present: torch.Tensor        # u8  [B,T]
+    global_bounds: torch.Tensor  # f64 [B,4]
+
+    @property
+    def n_problems(self):
+        return self.present.shape[0]
+
+    @staticmethod
+    def from_problems(pb, device):
+        ei = torch.from_numpy(np.ascontiguousarray(pb.edge_index))
+        batch = torch.from_numpy(np.ascontiguousarray(pb.batch))
+        n = pb.x.shape[0]
+        return DeviceBatch(torch.from_numpy(pb.x).to(device), graph.csr_by_destination(ei, n).to(device),
+                           graph.segment_ptr(batch, pb.n_problems).to(device),
+                           torch.from_numpy(np.ascontiguousarray(pb.local_bounds)).to(device),
+                           torch.from_numpy(np.ascontiguousarray(pb.present)).to(device),
+                           torch.from_numpy(np.ascontiguousarray(pb.global_bounds)).to(device))
+
+    def shard(self, rank, world):
+        """Contiguous shard of the problems for one rank (dist.py); graphs stay whole."""
+        B = self.n_problems
+        lo, hi = B * rank // world, B * (rank + 1) // world
+        seg = self.seg_ptr.cpu()
+        n0, n1 = int(seg[lo]), int(seg[hi])
+        rp = self.wf_csr.rowptr.cpu()
+        e0, e1 = int(rp[n0]), int(rp[n1])
+        dev = self.x.device
+        csr = graph.CSR((rp[n0:n1 + 1] - e0).to(dev), (self.wf_csr.col[e0:e1] - n0).contiguous(), None, n1 - n0)
+        return DeviceBatch(self.x[n0:n1].contiguous(), csr, (seg[lo:hi + 1] - n0).to(dev),
+                           self.local_bounds[lo:hi].contiguous(), self.present[lo:hi].contiguous(),
+                           self.global_bounds[lo:hi].contiguous())
+
+
+class ML2PNPipeline:
+    """net: modelML.Net; low/high: modelPN.CombinatorialRL (levels "Low"/"High")."""
+
+    def __init__(self, net, low, high, n_per):
+        self.net, self.low, self.high, self.n_per = net, low, high, n_per
+
+    @torch.no_grad()
+    def scores(self, services, batch):
+        """TrainML.test's forward (trainML.py:56-58)."""
+        return self.net.scores(batch.x, batch.wf_csr, batch.seg_ptr, services.x_service, services.csr)
+
+    @torch.no_grad()
+    def candidates(self, services, batch, scores):
+        """sort + loadDataPN + SCDataset, fused (trainML.py:62; loadData.py:101-149; trainPNHigh.py:23-31)."""
+        return ops.select_candidates(scores, services.cat_ptr, services.qos, batch.local_bounds, batch.present,
+                                     batch.global_bounds, self.n_per)
+
+    @torch.no_grad()
+    def run(self, services, batch):
+        scores = self.scores(services, batch)
+        rows, ids = self.candidates(services, batch, scores)
+        out = two_level_greedy(self.low, self.high, rows)
+        out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
+        return out
+
+    @torch.no_grad()
+    def rankings(self, services, batch):
+        """The artefact TrainML.test writes (trainML.py:62-68,148-149): full ranking per problem."""
+        return ops.rank_rows(self.scores(services, batch))

@@ -1,0 +1,174 @@
+/*
+ * gnnpn_hip.h — C ABI of libgnnpn_hip.so: the MI355X (gfx950) implementation of the ML+2PN
+ * inference hot path of wangxiaohit/GNNPN-SC.
+ *
+ * The reference is pure Python on stock PyTorch/PyG ops and has no FFI layer; these entry points
+ * are what a binding for this path would bind.  Each one names the reference code it replaces
+ * (paths relative to the reference repository root).  Conventions:
+ *
+ *   - every pointer is a DEVICE pointer into caller-owned, contiguous memory (borrowed for the
+ *     duration of the call, never retained); sizes are element counts unless stated;
+ *   - float = IEEE fp32, indices = int32 unless stated; row-major everywhere;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     on it and the call returns without synchronising;
+ *   - return 0 on success, a negative GNNPN_E_* code on failure (nothing was enqueued);
+ *     gnnpn_last_error() returns a thread-local message for the last failure.
+ *   - no internal host threads, no hidden allocation: workspaces are explicit arguments.
+ */
+#ifndef GNNPN_HIP_H
+#define GNNPN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNPN_ABI_VERSION 1
+
+#define GNNPN_OK 0
+#define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
+#define GNNPN_E_UNSUP (-2)   /* shape outside what the kernels are built for */
+#define GNNPN_E_LAUNCH (-3)  /* HIP reported a launch error */
+
+#define GNNPN_ACT_NONE 0
+#define GNNPN_ACT_RELU 1
+#define GNNPN_ACT_SIGMOID 2
+
+int gnnpn_abi_version(void);
+const char* gnnpn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layer: C[M,N] = act( (A[M,K] . W[N,K]^T + bias[N]) * scale[N] + shift[N] ), fp32 MFMA.
+ * bias / scale / shift may be NULL.  scale/shift carry an eval-mode BatchNorm1d folded to
+ * y = x*alpha + beta (alpha = gamma/sqrt(var+eps), beta = b - mean*alpha).
+ * Replaces: torch.nn.Linear / BatchNorm1d / ReLU / Sigmoid chains at
+ *   src/models/modelML.py:77-90 (GIN MLP), :141,:154 (BN+ReLU), :164-165 (serviceLin, nodeLin),
+ *   :173-176 (score matmul + sigmoid), torch.matmul(x, weight) inside GCNConv (:153),
+ *   src/models/modelPN.py:190 (embedding2) and the LSTM input projection of :191.
+ * lda/ldw/ldc are row strides in elements.
+ */
+int gnnpn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                     const float* scale, const float* shift, int act, float* C, int64_t ldc,
+                     int64_t M, int N, int K, void* stream);
+
+/* Embedding lookup + concat: out[n, 0:emb] = table[(int)x[n,0], :], out[n, emb:emb+nfeat] =
+ * x[n, 1:1+nfeat].  x is [n_rows, 1+nfeat], out is [n_rows, emb+nfeat].  Category ids outside
+ * [0, vocab) make the call fail on the device side by writing NaN rows (checked by callers).
+ * Replaces NodeEncoder.forward + torch.cat at src/models/modelML.py:22-29,133-137,145-149. */
+int gnnpn_embed_concat_f32(const float* x, const float* table, int vocab, int emb, int nfeat,
+                           float* out, int64_t n_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CSR gather-aggregate (one wavefront per destination row, neighbour list read coalesced):
+ *   y[i,:] = epi( sum_{e in [rowptr[i], rowptr[i+1])} w[e] * x[col[e],:]  (+ self_coef * x[i,:]) )
+ * summed strictly in CSR order with separate multiply and add (the order and rounding of
+ * scatter_add over materialised messages).  w == NULL means weight 1 (no multiply).
+ * self_coef: pointer to ONE device float added as (1 + *self_coef) * x[i,:] AFTER the neighbour
+ * sum, or NULL.  epi: + bias[C] (or NULL), then * scale + shift (or NULL), then act.
+ * Replaces: GINConv.propagate + "(1+eps)*x_r" and GCNConv.propagate + bias (torch_geometric 1.7.0;
+ * call sites src/models/modelML.py:140,153) fused with BatchNorm1d+ReLU (:154-155).
+ */
+int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* w,
+                            const float* x, int64_t ldx, const float* self_coef, const float* bias,
+                            const float* scale, const float* shift, int act, float* y, int64_t ldy,
+                            int32_t n_rows, int32_t C, void* stream);
+
+/* GCN symmetric normalisation on a destination-major CSR that already contains one self-loop
+ * entry per node (add_remaining_self_loops, fill 1): deg[i] = sum of w_raw over row i (CSR order),
+ * dis = deg^-1/2 (inf -> 0), norm[e] = dis[src[e]] * w_raw[e] * dis[dst[e]].
+ * deg_inv_sqrt is an [n] workspace/output.  Replaces gcn_norm of torch_geometric 1.7.0 invoked
+ * by GCNConv.forward (call site src/models/modelML.py:153). */
+int gnnpn_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, const float* w_raw,
+                       float* deg_inv_sqrt, float* norm, int32_t n_rows, void* stream);
+
+/* Segment mean over contiguous segments: out[g,:] = sum_{n in [segptr[g], segptr[g+1])} x[n,:]
+ * / max(count,1).  Replaces torch_scatter.scatter(reduce='mean') at src/models/modelML.py:166. */
+int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, float* out,
+                           int64_t ldo, int32_t n_seg, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Candidate reduction: for every (problem b, category c) choose the n_per best-scored services
+ * of that category that satisfy the problem's local bounds, best first (score descending, ties
+ * by lowest service id), pad cyclically when fewer than n_per are feasible, and emit the
+ * pointer-net input rows.
+ *   scores        [B, S] fp32 (sigmoid scores of Net.forward)
+ *   cat_ptr       [T+1]  services of category c are ids [cat_ptr[c], cat_ptr[c+1])
+ *   qos           [S, 4] fp64 (q0,q1,q2=cost,q3=quality) — fp64 because the reference compares
+ *                 the JSON doubles (src/loadData.py:123-124)
+ *   local_bounds  [B, T, 4] fp64 cost_lo,cost_hi,quality_lo,quality_hi;  present [B,T] uint8
+ *   global_bounds [B, 4] fp64
+ *   out_rows      [B, T*n_per, 8] fp32 = q0,q1,q2,q3,c0lo,c0hi,c1lo,c1hi (constraint columns
+ *                 non-zero only in category 0); absent / infeasible categories -> 0,1,1,1
+ *   out_ids       [B, T*n_per] int32 chosen service id, -1 for dummy rows
+ * Replaces: the per-row sort of TrainML.test (src/models/trainML.py:60-68) + loadDataPN
+ * (src/loadData.py:101-149) + SCDataset's column drop (src/models/trainPNHigh.py:23-31).
+ */
+int gnnpn_select_candidates(const float* scores, int64_t ld_scores, const int32_t* cat_ptr,
+                            const double* qos, const double* local_bounds,
+                            const uint8_t* present, const double* global_bounds, float* out_rows,
+                            int32_t* out_ids, int32_t B, int32_t T, int32_t n_per, void* stream);
+
+/* Full descending ranking of every score row (ties: lowest id first): ranking [B,S] int32.
+ * S <= 32768.  Replaces `_x.sort(dim=0, descending=True)` of src/models/trainML.py:62 (whose tie
+ * order is undefined). */
+int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointer-network LSTM encoder recurrence for `n_nets` independent nets in one launch
+ * (Low and High encoders are independent given the inputs).
+ *   pregates[n]  [B, L, 4H] fp32 = x_t . W_ih^T + b_ih (gate order i,f,g,o)
+ *   whh_packed[n][k/4][gate][j][4] fp32  = W_hh[gate*H + j][k..k+3]   (gnnpn packing, see .py)
+ *   bhh[n]       [4H]
+ *   enc_out[n]   [B, L, H];  h_n[n], c_n[n]  [B, H]
+ * H must be 256 or 32 (the configurations of environment.ini:55 and of the unit fixtures).
+ * Pointer arrays are HOST arrays of device pointers.
+ * Replaces: nn.LSTM encoder at src/models/modelPN.py:157,191. */
+int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float* const* whh_packed,
+                          const float* const* bhh, float* const* enc_out, float* const* h_n,
+                          float* const* c_n, int32_t B, int32_t L, int32_t H, void* stream);
+
+/* Greedy pointer decode of ONE net: T steps of {decoder LSTM cell; dot-attention logits over the
+ * step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent window (High net) ; softmax;
+ * first-max argmax; next input = embedded row of the pick}.
+ *   embedded [B,L,H]  enc_out [B,L,H]  h0,c0 [B,H]  start [H]
+ *   wih_packed / whh_packed / bih / bhh : decoder LSTM (packed as for the encoder)
+ *   latent_win  [B,T,n_per] or NULL : the Low net's in-window logits, added before the argmax
+ *   inputs   [B,L,8] : rows gathered into `actions`
+ * outputs: idx [B,T] int32; win_logits [B,T,n_per] (C*tanh(dot), before latent);
+ *          pick_prob [B,T] softmax prob of the pick; actions [B,T,8]; queries [B,T,H] or NULL.
+ * Replaces: PointerNet.forward's decode loop src/models/modelPN.py:193-241 incl. Attention 'Dot'
+ * (:111-114,119-120), the window mask loop (:220-222), softmax/max (:224-226), the gathers at
+ * :235 and CombinatorialRL.forward :293-299. */
+int gnnpn_pointer_decode_f32(const float* embedded, const float* enc_out, const float* h0,
+                             const float* c0, const float* start, const float* wih_packed,
+                             const float* whh_packed, const float* bih, const float* bhh,
+                             const float* latent_win, const float* inputs, float tanh_c,
+                             int use_tanh, int32_t* idx, float* win_logits, float* pick_prob,
+                             float* actions, float* queries, int32_t B, int32_t T, int32_t n_per,
+                             int32_t H, void* stream);
+
+/* Full-length attention logits of ONE decode step, for callers that need the reference's
+ * return values verbatim (the reference returns every step's whole [B,L] logits tensor,
+ * src/models/modelPN.py:239,291; only the window part feeds the decision):
+ *   logits[b,l] = C*tanh(dot(enc_out[b,l,:], q[b,:]))  for all l, then -inf at the n_masked
+ *   previously chosen positions masked_idx[b*ld_idx + 0..n_masked) (in-place mask of :165-173).
+ * queries: row b at queries + b*ld_q.  Not on the fast path. */
+int gnnpn_attention_logits_f32(const float* enc_out, const float* queries, int64_t ld_q,
+                               const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits,
+                               int32_t B, int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx,
+                               void* stream);
+
+/* QoS reward of decoded compositions: per problem, violate = #global constraints whose product
+ * QoS (q2, q3 over the T actions, fp32 running product) falls outside [lo,hi] read from the
+ * step-0 action row; obj = (sum q0 / #(q0>0) + 1 - min q1)/2; level 0 ("Low") -> violate,
+ * level 1 ("High") -> round(violate + obj, 5).   actions [B,T,8] -> R [B] fp32.
+ * Replaces: reward/calc at src/models/modelPN.py:15-72 (minus the print at :67). */
+int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, int level,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNPN_HIP_H */

@@ -1,0 +1,33 @@
+"""Shared parity rules for the GPU tests.
+
+Index parity: the path is chaotic in the picks (one flipped argmax changes every later decoder
+input of that problem), and the HIP kernels sum in a different order than MKL (|Δlogit| ~ 1e-5 on
+10*tanh(dot)).  So a problem whose every decision has a top-1/top-2 margin above TAU in the oracle
+must match the oracle index for index; problems with a thinner margin are *fragile* (a flip there is
+classified, not hidden): they are counted and reported, and the overall agreement must stay above
+the stated floor.
+"""
+import torch
+
+TAU = 5e-4          # decision margin above which indices must be bit-exact
+LOGIT_ATOL = 2e-4   # |C*tanh(dot)| differences (C = 10)
+R_ATOL = 1.0001e-5  # QoS score tolerance of BASELINE.json's north_star (scores are rounded to 5 decimals)
+
+
+def robust_problems(*margins):
+    """[B] bool: every decision of the problem has margin > TAU (inf margins for K == 1 count)."""
+    ok = None
+    for m in margins:
+        r = (torch.as_tensor(m) > TAU).all(dim=1)
+        ok = r if ok is None else ok & r
+    return ok
+
+
+def assert_index_parity(got, want, robust, what, min_agree=0.9):
+    got, want = torch.as_tensor(got).long().cpu(), torch.as_tensor(want).long().cpu()
+    same = (got == want).all(dim=1)
+    bad = robust & ~same
+    assert not bool(bad.any()), f"{what}: robust problems {bad.nonzero().flatten().tolist()} differ from the oracle"
+    agree = float(same.float().mean())
+    assert agree >= min_agree, f"{what}: only {agree:.3f} of problems index-exact"
+    return same

@@ -1,0 +1,197 @@
+"""-m gpu: every C-ABI entry point against the CPU oracle on the same seeded inputs.
+Tolerances: integer/index outputs bit-exact; fp32 outputs within the stated absolute bounds
+(different summation order than MKL: ~1e-6 relative per 256-long dot)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from oracle import ml as oml
+from oracle import pn as opn
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import gnnpn_sc_amd.ops as ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 50, 26), (256, 128, 24), (300, 1024, 256), (2816, 256, 128),
+                                   (4096, 1024, 256), (129, 65, 8), (64, 2507, 128)])
+def test_linear_matches_torch(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = F.linear(a, w, b)
+    out = ops.linear(a.to(dev), w.to(dev), b.to(dev)).cpu()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=2e-5), float((out - ref).abs().max())
+    # epilogue: BN affine + ReLU, and sigmoid
+    sc, sh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    ref2 = torch.relu(ref * sc + sh)
+    out2 = ops.linear(a.to(dev), w.to(dev), b.to(dev), sc.to(dev), sh.to(dev), ops.ACT_RELU).cpu()
+    assert torch.allclose(out2, ref2, rtol=1e-5, atol=3e-5)
+    out3 = ops.linear(a.to(dev), w.to(dev), None, None, None, ops.ACT_SIGMOID).cpu()
+    assert torch.allclose(out3, torch.sigmoid(F.linear(a, w)), rtol=1e-5, atol=1e-6)
+
+
+def test_linear_is_k_ordered_fma_chain(dev):
+    """The MFMA accumulation is a k-ordered fp32 fma chain: integer-valued operands are exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-8, 9, (70, 256), generator=g).float()
+    w = torch.randint(-8, 9, (90, 256), generator=g).float()
+    out = ops.linear(a.to(dev), w.to(dev)).cpu()
+    assert torch.equal(out, a @ w.t())
+    # A = I with asymmetric W catches a transposed C-write
+    eye = torch.eye(64)
+    w2 = torch.arange(64 * 64, dtype=torch.float32).view(64, 64)
+    assert torch.equal(ops.linear(eye.to(dev), w2.to(dev)).cpu(), w2.t())
+
+
+def test_embed_concat(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(100, 20, generator=g)
+    x = torch.cat([torch.randint(0, 100, (333, 1), generator=g).float(), torch.rand(333, 6, generator=g)], 1)
+    out = ops.embed_concat(x.to(dev), table.to(dev)).cpu()
+    assert torch.equal(out, torch.cat([table[x[:, 0].long()], x[:, 1:]], 1))
+    bad = x.clone()
+    bad[5, 0] = 100
+    assert torch.isnan(ops.embed_concat(bad.to(dev), table.to(dev)).cpu()[5, :20]).all()
+
+
+def _rand_graph(n, e, seed, loops=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if not loops:
+        ei = ei[:, ei[0] != ei[1]]
+    w = torch.rand(ei.shape[1], generator=g) + 0.05
+    return ei, w
+
+
+@pytest.mark.parametrize("n,e,C", [(5, 8, 2), (50, 400, 26), (301, 3000, 128), (1000, 20000, 256), (200, 0, 256),
+                                   (64, 5000, 24)])
+def test_gin_aggregate_bit_exact(dev, n, e, C):
+    """Sequential CSR-order sums with separate mul/add reproduce scatter_add bit for bit."""
+    ops = _ops()
+    from gnnpn_sc_amd import graph
+    ei, _ = _rand_graph(n, e, n + e)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(C))
+    eps = torch.tensor([0.137])
+    ref = oml.scatter_sum(x[ei[0]], ei[1], n) + (1 + eps) * x
+    csr = graph.csr_by_destination(ei, n).to(dev)
+    out = ops.csr_aggregate(csr.rowptr, csr.col, None, x.to(dev), self_coef=eps.to(dev)).cpu()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,e,C", [(50, 400, 24), (301, 3000, 256), (2507, 80000, 256)])
+def test_gcn_norm_and_aggregate(dev, n, e, C):
+    ops = _ops()
+    from gnnpn_sc_amd import graph
+    ei, w = _rand_graph(n, e, 11 * n, loops=True)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(C + 1))
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(2))
+    row, col, norm = oml.gcn_norm(ei, w, n)
+    ref = oml.scatter_sum(norm.view(-1, 1) * x[row], col, n) + bias
+    csr = graph.gcn_csr(ei, w, n).to(dev)
+    norm_dev = ops.gcn_norm(csr.rowptr, csr.col, csr.w)
+    # same multiset of normalised weights, bit for bit (CSR order = stable sort of the oracle's list)
+    order = torch.sort(col, stable=True).indices
+    assert torch.equal(norm_dev.cpu(), norm[order])
+    out = ops.csr_aggregate(csr.rowptr, csr.col, norm_dev, x.to(dev), bias=bias.to(dev)).cpu()
+    assert torch.equal(out, ref)
+
+
+def test_hand_graph_golden(dev):
+    """G6: 5-node hand-checkable graph; expected values from the (stand-in) GCNConv run."""
+    ops = _ops()
+    from gnnpn_sc_amd import graph
+    fx = golden("hand_graph.npz")
+    x, ei, w = torch.from_numpy(fx["x"]), torch.from_numpy(fx["edge_index"]), torch.from_numpy(fx["w"])
+    weight, bias = torch.from_numpy(fx["weight"]), torch.from_numpy(fx["bias"])
+    csr = graph.gcn_csr(ei, w, 5).to(dev)
+    norm = ops.gcn_norm(csr.rowptr, csr.col, csr.w)
+    xw = ops.linear(x.to(dev), weight.t().contiguous().to(dev))
+    out = ops.csr_aggregate(csr.rowptr, csr.col, norm, xw, bias=bias.to(dev)).cpu()
+    assert torch.allclose(out, torch.from_numpy(fx["gcn"]), rtol=0, atol=1e-6)
+    wf = graph.csr_by_destination(ei, 5).to(dev)
+    gin = ops.csr_aggregate(wf.rowptr, wf.col, None, x.to(dev), self_coef=torch.tensor([float(fx["gin_eps"])]).to(dev))
+    assert torch.equal(gin.cpu(), torch.from_numpy(fx["gin_pre"]))
+
+
+def test_segment_mean(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    sizes = [3, 1, 11, 0, 7, 48]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    x = torch.randn(sum(sizes), 128, generator=g)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    out = ops.segment_mean(ptr.to(dev), x.to(dev)).cpu()
+    assert torch.equal(out, oml.scatter_mean(x, batch, len(sizes)))
+
+
+@pytest.mark.parametrize("H,B,L", [(32, 5, 18), (256, 3, 40), (256, 9, 235)])
+def test_lstm_encode_vs_torch(dev, H, B, L):
+    ops = _ops()
+    sd = opn.make_state_dict(H, 5)
+    lstm = opn._lstm_module(sd, "encoder", H)
+    x = torch.randn(B, L, H, generator=torch.Generator().manual_seed(9)) * 0.5
+    with torch.no_grad():
+        ref_out, (ref_h, ref_c) = lstm(x)
+    w_ih, b_ih = sd["actor.encoder.weight_ih_l0"], sd["actor.encoder.bias_ih_l0"]
+    pre = ops.linear(x.view(B * L, H).to(dev), w_ih.to(dev), b_ih.to(dev)).view(B, L, 4 * H)
+    whh = ops.pack_lstm_weight(sd["actor.encoder.weight_hh_l0"]).to(dev)
+    enc, h_n, c_n = ops.lstm_encode([pre, pre], [whh, whh], [sd["actor.encoder.bias_hh_l0"].to(dev)] * 2)
+    for n in range(2):
+        assert float((enc[n].cpu() - ref_out).abs().max()) < 2e-5
+        assert float((h_n[n].cpu() - ref_h[0]).abs().max()) < 2e-5
+        assert float((c_n[n].cpu() - ref_c[0]).abs().max()) < 5e-5
+    assert torch.equal(enc[0], enc[1])      # two nets in one launch are independent and deterministic
+
+
+def test_qos_reward_golden(dev):
+    ops = _ops()
+    fx = golden("reward.npz")
+    a = torch.from_numpy(fx["actions"]).to(dev)
+    assert torch.equal(ops.qos_reward(a, "Low").cpu(), torch.from_numpy(fx["R_low"]))
+    assert float((ops.qos_reward(a, "High").cpu() - torch.from_numpy(fx["R_high"])).abs().max()) <= 1.0001e-5
+
+
+def test_select_candidates_vs_oracle(dev):
+    """Same selections as the oracle's rank-ordered loadDataPN on a dataset in the reference's JSON
+    format, including padding and absent categories."""
+    import json, os
+    from conftest import GOLDEN
+    from oracle import data as odata
+    from gnnpn_sc_amd import loadData as ld
+    ops = _ops()
+    fx = json.load(open(os.path.join(GOLDEN, "data_small.json")))
+    ds, K, T, S, P = fx["dataset"], fx["K"], fx["T"], fx["S"], fx["P"]
+    table, probs = ld.tables_from_dataset(ds)
+    rank = torch.tensor(fx["rank_each"])
+    # scores that realise the ranking: score = 1 - position/S (exact in fp32 for these sizes)
+    scores = torch.empty(P, S)
+    scores.scatter_(1, rank, (1.0 - torch.arange(S).float() / S).repeat(P, 1))
+    rows, ids = ops.select_candidates(scores.to(dev), torch.from_numpy(table.cat_ptr).to(dev),
+                                      torch.from_numpy(table.qos).to(dev),
+                                      torch.from_numpy(probs.local_bounds).to(dev),
+                                      torch.from_numpy(probs.present).to(dev),
+                                      torch.from_numpy(probs.global_bounds).to(dev), K)
+    want, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], fx["rank_each"], ds["minCostList"], K)
+    want = torch.tensor(want, dtype=torch.float32)[:, :, 1:]
+    assert torch.equal(rows.cpu(), want)
+    assert (ids.cpu()[(want[:, :, :4] == torch.tensor([0., 1., 1., 1.])).all(-1)] == -1).all()
+
+
+@pytest.mark.parametrize("B,S", [(3, 40), (4, 2507), (2, 16384)])
+def test_rank_rows(dev, B, S):
+    ops = _ops()
+    g = torch.Generator().manual_seed(S)
+    scores = torch.rand(B, S, generator=g)
+    scores[:, : S // 4] = scores[:, S // 2: S // 2 + S // 4]      # exact ties -> lowest id first
+    out = ops.rank_rows(scores.to(dev)).cpu().long()
+    assert torch.equal(out, oml.rank_services(scores))

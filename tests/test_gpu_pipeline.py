@@ -1,0 +1,157 @@
+"""-m gpu: the GNN mirror (Net) against the golden vectors of the reference's own Net glue, and the
+fused device pipeline (scores -> candidates -> two-level decode -> reward) against the oracle chain."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import data as odata
+from oracle import ml as oml
+from oracle import pn as opn
+from parity import R_ATOL, assert_index_parity, robust_problems
+
+pytestmark = pytest.mark.gpu
+SCORE_ATOL = 1e-5
+
+
+def make_net(fx, dev, vocab=100):
+    from gnnpn_sc_amd.modelML import Net
+    net = Net(int(fx["hidden"]), int(fx["S"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]), vocab=vocab)
+    net.load_state_dict(oml.make_state_dict(int(fx["hidden"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]),
+                                            int(fx["seed"]) + 2, vocab=vocab), strict=True)
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["tiny", "qws", "normal"])
+def test_net_forward_golden(dev, name):
+    fx = golden(f"ml_{name}.npz")
+    net = make_net(fx, dev)
+    B, S = int(fx["B"]), int(fx["S"])
+    t = lambda k: torch.from_numpy(fx[k]).to(dev)   # noqa: E731
+    # feed what a PyG batch holds: B replicated copies of the service graph (trainML.py:109-114)
+    data = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service").repeat(B, 1),
+                         torch.cat([t("edge_index_service") + b * S for b in range(B)], 1),
+                         t("edge_attr_service").repeat(B))
+    scores = net(data)
+    assert scores.shape == (B, S) and scores.dtype == torch.float32
+    err = float((scores.cpu() - torch.from_numpy(fx["scores"])).abs().max())
+    assert err < SCORE_ATOL, err
+    # ranking: identical wherever the golden scores are separated by more than the tolerance
+    from gnnpn_sc_amd import ops
+    rank = ops.rank_rows(scores).cpu().long()
+    want = torch.from_numpy(fx["ranking"])
+    gs = torch.from_numpy(fx["scores"])
+    sorted_scores = torch.gather(gs, 1, want)
+    gap_ok = torch.ones_like(want, dtype=torch.bool)
+    gap = (sorted_scores[:, :-1] - sorted_scores[:, 1:]) > 4 * SCORE_ATOL
+    gap_ok[:, 1:] &= gap
+    gap_ok[:, :-1] &= gap
+    assert torch.equal(rank[gap_ok], want[gap_ok])
+    # second forward reuses the cached CSR and is deterministic
+    assert torch.equal(net(data), scores)
+
+
+def test_net_rejects_training_and_noservices(dev):
+    from gnnpn_sc_amd.modelML import Net
+    with pytest.raises(NotImplementedError):
+        Net(16, 40, 8, 2, 2, isServices=False)
+    fx = golden("ml_tiny.npz")
+    net = make_net(fx, dev).train()
+    with pytest.raises(NotImplementedError):
+        net(oml.make_data(*[torch.from_numpy(fx[k]).to(dev) for k in
+                            ("x", "edge_index", "batch", "x_service", "edge_index_service", "edge_attr_service")]))
+
+
+def _oracle_chain(table, pb, sd_ml, sd_low, sd_high, n_gin, n_gcn, K):
+    data = oml.make_data(torch.from_numpy(pb.x), torch.from_numpy(pb.edge_index), torch.from_numpy(pb.batch),
+                         torch.from_numpy(table.x_service), torch.from_numpy(table.edge_index),
+                         torch.from_numpy(table.edge_attr))
+    scores = oml.net_forward(sd_ml, data, n_gin, n_gcn)
+    return scores
+
+
+@pytest.mark.parametrize("T,S,K,B,n_t,H", [(6, 60, 3, 8, 3, 32), (47, 940, 5, 24, 10, 256)])
+def test_pipeline_vs_oracle_chain(dev, T, S, K, B, n_t, H):
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
+    table = synth.make_service_table(T, S, seed=5, degree=8)
+    pb = synth.make_problem_batch(table, B, seed=6, tasks_per_problem=n_t, lo_range=(0.85, 0.96))
+    sd_ml = oml.make_state_dict(128, 20, 2, 2, seed=7)
+    sd_low, sd_high = opn.make_state_dict(H, 8), opn.make_state_dict(H, 9)
+    net = Net(128, S, 20, 2, 2)
+    net.load_state_dict(sd_ml)
+    low = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="Low")
+    high = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="High")
+    low.load_state_dict(sd_low)
+    high.load_state_dict(sd_high)
+    pipe = ML2PNPipeline(net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval(), K)
+    out = pipe.run(DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev))
+
+    # stage 1: scores
+    ref_scores = _oracle_chain(table, pb, sd_ml, sd_low, sd_high, 2, 2, K)
+    assert float((out["scores"].cpu() - ref_scores).abs().max()) < SCORE_ATOL
+    # stage 2: candidate reduction — exact given the device's own scores (stable ranking rule)
+    ds_like = {str(c + 1): table.qos[table.cat_ptr[c]:table.cat_ptr[c + 1]].tolist() for c in range(T)}
+    rank = oml.rank_services(out["scores"].cpu()).tolist()
+    nodes_per = pb.x.shape[0] // B
+    rows_want = []
+    for b in range(B):
+        nodes = []
+        for r in pb.x[b * nodes_per:(b + 1) * nodes_per]:
+            onehot = [0] * (T + 1)
+            onehot[int(r[0])] = 1
+            nodes.append(onehot + [float(v) for v in r[1:].astype(np.float64)])
+        rows_want.append(odata.reduce_candidates(rank[b], nodes, ds_like, K)[0])
+    rows_want = torch.tensor(rows_want, dtype=torch.float32)[:, :, 1:]
+    assert torch.equal(out["pn_inputs"].cpu(), rows_want)
+    # and it is the same reduction the oracle's own scores give, wherever scores are well separated
+    # stage 3: decode given identical inputs
+    ref = opn.two_level_greedy(sd_low, sd_high, rows_want, T, K)
+    robust = robust_problems(ref["margin_low"], ref["margin_high"])
+    s = assert_index_parity(out["idx_low"], ref["idx_low"], robust, "pipe/low", 0.8) & \
+        assert_index_parity(out["idx_high"], ref["idx_high"], robust, "pipe/high", 0.8)
+    assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
+    # sharding the batch does not change any result (what dist.py relies on)
+    svc = DeviceServices.from_table(table, dev)
+    full = DeviceBatch.from_problems(pb, dev)
+    parts = [pipe.run(svc, full.shard(r, 2)) for r in range(2)]
+    assert torch.equal(torch.cat([p["idx_high"] for p in parts]), out["idx_high"])
+    assert torch.equal(torch.cat([p["R"] for p in parts]), out["R"])
+
+
+def test_full_size_properties(dev):
+    """BASELINE configs[1] size (QWS shape, B=256): size-independent properties instead of an
+    oracle run — every pick lies in its step's window, picks of present categories are feasible
+    candidates, dummy rows only in absent categories, rewards are finite and rounded to 5 decimals,
+    the run is deterministic, and a batch permutation permutes the outputs."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
+    T, S, K, B = 47, 2507, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    pb = synth.make_problem_batch(table, B, seed=1, tasks_per_problem=10)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
+    out = pipe.run(svc, batch)
+    idx = out["idx_high"].cpu().long()
+    step = torch.arange(T).unsqueeze(0)
+    assert bool(((idx >= step * K) & (idx < (step + 1) * K)).all())
+    ids = out["candidate_ids"].cpu().view(B, T, K)
+    present = torch.from_numpy(pb.present).bool()
+    assert bool((ids[~present] == -1).all()) and bool((ids[present] >= 0).all())
+    cat_of = torch.repeat_interleave(torch.arange(T), torch.from_numpy(np.diff(table.cat_ptr)).long())
+    real = ids >= 0
+    assert torch.equal(cat_of[ids[real].long()], torch.arange(T).view(1, T, 1).expand(B, T, K)[real])
+    R = out["R"].cpu().double()
+    assert bool(torch.isfinite(R).all()) and float((R * 1e5 - (R * 1e5).round()).abs().max()) < 2e-2
+    out2 = pipe.run(svc, batch)
+    assert torch.equal(out2["idx_high"], out["idx_high"]) and torch.equal(out2["R"], out["R"])
+    # reversing the batch reverses the outputs
+    rev = DeviceBatch.from_problems(synth.ProblemBatch(
+        pb.x.reshape(B, -1, 7)[::-1].reshape(-1, 7).copy(), pb.edge_index, pb.batch, pb.local_bounds[::-1].copy(),
+        pb.present[::-1].copy(), pb.global_bounds[::-1].copy()), dev)
+    out3 = pipe.run(svc, rev)
+    assert torch.equal(out3["idx_high"].flip(0), out["idx_high"]) and torch.equal(out3["R"].flip(0), out["R"])

@@ -1,0 +1,117 @@
+"""-m gpu: the pointer-network mirror (CombinatorialRL / two_level_greedy) against the golden
+vectors produced by the imported reference (tests/golden/pn_*.npz) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import pn as opn
+from parity import LOGIT_ATOL, R_ATOL, assert_index_parity, robust_problems
+
+pytestmark = pytest.mark.gpu
+
+
+def build(fx_or_cfg, dev):
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    H, T, K = int(fx_or_cfg["hidden"]), int(fx_or_cfg["n_cat"]), int(fx_or_cfg["n_per"])
+    nets = []
+    for level, seed in (("Low", int(fx_or_cfg["seed_low"])), ("High", int(fx_or_cfg["seed_high"]))):
+        m = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed), strict=True)
+        nets.append(m.to(dev).eval())
+    return nets
+
+
+@pytest.mark.parametrize("name", ["small", "dummy", "qws", "normal"])
+def test_two_level_greedy_golden(dev, name):
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    fx = golden(f"pn_{name}.npz")
+    low, high = build(fx, dev)
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    out = two_level_greedy(low, high, x)
+    robust = robust_problems(fx["margin_low"], fx["margin_high"])
+    same_low = assert_index_parity(out["idx_low"], fx["idx_low"], robust, f"{name}/low", min_agree=0.7)
+    same = assert_index_parity(out["idx_high"], fx["idx_high"], robust, f"{name}/high", min_agree=0.7) & same_low
+    assert bool(robust.any()), "fixture has no robust problem"
+    # on problems whose picks agree the float outputs must agree within tolerance
+    s = same.numpy()
+    assert np.abs(out["win_low"].cpu().numpy()[s] - fx["win_low"][s]).max() < LOGIT_ATOL
+    win_high = (out["win_high_raw"] + out["win_low"]).cpu().numpy()
+    assert np.abs(win_high[s] - fx["win_high"][s]).max() < LOGIT_ATOL
+    assert np.abs(out["R"].cpu().numpy()[s] - fx["R"][s]).max() <= R_ATOL
+    assert np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
+    assert np.abs(out["action_probs"].cpu().numpy()[s] - fx["action_probs"][s]).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_reference_style_calls(dev, name):
+    """Drive the mirror exactly as trainPNHigh.py:138-139 drives the reference."""
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    fx = golden(f"pn_{name}.npz")
+    low, high = build(fx, dev)
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    T, K = int(fx["n_cat"]), int(fx["n_per"])
+    probs_l, aprob_l, actions_l, idx_l, latent = low(x, None, sample="greedy", training="SL")
+    R, aprob, actions, idx, latent_h = high(x, None, latent, sample="greedy")
+    fused = two_level_greedy(low, high, x)
+    assert torch.equal(torch.stack(idx_l, 1).int(), fused["idx_low"])
+    assert torch.equal(torch.stack(idx, 1).int(), fused["idx_high"])
+    assert torch.equal(R, fused["R"]) and R.dtype == torch.float32 and R.shape == (x.shape[0],)
+    assert idx[0].dtype == torch.int64 and len(idx) == T and actions[0].shape == (x.shape[0], 8)
+    assert len(latent) == T and len(probs_l) == T
+    # the reference's full-length latent (list of [B,L]) works as input too, and gives the same picks
+    as_list = [latent[k] for k in range(T)]
+    R2, _, _, idx2, _ = high(x, None, as_list, sample="greedy")
+    assert torch.equal(torch.stack(idx2, 1), torch.stack(idx, 1)) and torch.equal(R2, R)
+    # full-length view of step 1: -inf exactly at the step-0 picks (modelPN.py:172), values as golden
+    lat1 = latent[1].cpu()
+    same0 = (fused["idx_low"][:, 0].cpu().numpy() == fx["idx_low"][:, 0])
+    want = torch.from_numpy(fx["latent_step1"])
+    assert torch.equal(torch.isinf(lat1)[same0], torch.isinf(want)[same0])
+    fin = ~torch.isinf(want)
+    assert float((lat1[fin] - want[fin]).abs().max()) < 5e-4
+    p0 = probs_l[0].cpu()
+    assert p0.shape == (x.shape[0], T * K) and torch.allclose(p0.sum(1), torch.ones(x.shape[0]), atol=1e-5)
+    assert float(p0[:, K:].abs().max()) == 0.0
+    low_R = low(x, None, sample="greedy", training="RL")[0].cpu().numpy()
+    s = (fused["idx_low"].cpu().numpy() == fx["idx_low"]).all(1)
+    assert np.array_equal(low_R[s], fx["R_low"][s])
+
+
+def test_unsupported_modes_fail_loudly(dev):
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    with pytest.raises(NotImplementedError):
+        CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6)
+    with pytest.raises(NotImplementedError):
+        CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Dot", 3, 6)
+    with pytest.raises(NotImplementedError):
+        CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Bahdanau", 3, 6)
+    m = CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)
+    with pytest.raises(NotImplementedError):
+        m(torch.rand(2, 18, 8, device=dev), None)           # default sample="sample"
+    with pytest.raises(AssertionError):
+        m(torch.rand(2, 17, 8, device=dev), None, sample="greedy")   # seq_len assert (modelPN.py:182)
+
+
+def test_cpu_tensors_are_rejected(dev):
+    """There is no CPU fallback: host tensors raise instead of silently running elsewhere."""
+    from gnnpn_sc_amd import ops
+    with pytest.raises(ops.GnnpnError):
+        ops.linear(torch.rand(4, 8), torch.rand(3, 8))
+
+
+def test_fresh_oracle_batch(dev):
+    """A batch that is not a stored fixture: oracle run live on the CPU vs the HIP path."""
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": 12, "n_per": 4, "seed_low": 101, "seed_high": 102}
+    low, high = build(cfg, dev)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(16, 48, 8, generator=g)
+    x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
+    x[:, 4:, 4:] = 0
+    ref = opn.two_level_greedy(opn.make_state_dict(256, 101), opn.make_state_dict(256, 102), x, 12, 4)
+    out = two_level_greedy(low, high, x.to(dev))
+    robust = robust_problems(ref["margin_low"], ref["margin_high"])
+    s = assert_index_parity(out["idx_high"], ref["idx_high"], robust, "fresh/high", 0.8) & \
+        assert_index_parity(out["idx_low"], ref["idx_low"], robust, "fresh/low", 0.8)
+    assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
