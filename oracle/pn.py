@@ -183,14 +183,22 @@ def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=Tru
         "idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
         "actions": torch.stack(actions, 1), "action_probs": torch.stack(aprob, 1),
         "win_low": win_low, "win_high": win_high,
-        "margin_low": decision_margin(win_low), "margin_high": decision_margin(win_high),
+        "margin_low": decision_margin(win_low, inputs), "margin_high": decision_margin(win_high, inputs),
         "latent": latent,
     }
 
 
-def decision_margin(win):
-    """top-1 minus top-2 of each [.., K] window (how far a decision is from flipping)."""
-    if win.shape[-1] == 1:
-        return torch.full(win.shape[:-1], float("inf"))
-    top2 = win.topk(2, dim=-1).values
-    return top2[..., 0] - top2[..., 1]
+def decision_margin(win, inputs):
+    """How far each decision is from flipping to a DIFFERENT candidate: top-1 logit minus the best
+    logit among window rows whose input row differs from the top-1's row (+inf when there is none).
+    Rows that are identical (dummy rows of an absent category, loadData.py:148, or the cyclic
+    padding of :137-138) are the same selection: whichever copy wins, the action row and the next
+    decoder input (modelPN.py:235) are identical, so a flip among them changes nothing downstream.
+    win [B,T,K], inputs [B,T*K,F] -> [B,T]."""
+    B, T, K = win.shape
+    rows = inputs.view(B, T, K, -1)
+    top = win.argmax(dim=2, keepdim=True)                                   # first max
+    top_row = torch.gather(rows, 2, top.unsqueeze(-1).expand(B, T, 1, rows.shape[-1]))
+    other = (rows != top_row).any(dim=-1)                                   # [B,T,K]
+    rival = torch.where(other, win, torch.full_like(win, NEG_INF)).max(dim=2).values
+    return torch.gather(win, 2, top).squeeze(2) - rival

@@ -23,9 +23,19 @@ def robust_problems(*margins):
     return ok
 
 
-def assert_index_parity(got, want, robust, what, min_agree=0.9):
+def assert_index_parity(got, want, robust, what, min_agree=0.9, rows=None):
+    """got / want: picked positions [B,T].  With ``rows`` (the PN input [B,L,F]) two picks count as
+    the same selection when their input rows are identical (duplicate candidates: dummy rows /
+    cyclic padding) — see oracle.pn.decision_margin."""
     got, want = torch.as_tensor(got).long().cpu(), torch.as_tensor(want).long().cpu()
-    same = (got == want).all(dim=1)
+    if rows is None:
+        same = (got == want).all(dim=1)
+    else:
+        rows = torch.as_tensor(rows).cpu()
+        F = rows.shape[-1]
+        a = torch.gather(rows, 1, got.unsqueeze(-1).expand(-1, -1, F))
+        b = torch.gather(rows, 1, want.unsqueeze(-1).expand(-1, -1, F))
+        same = (a == b).all(dim=-1).all(dim=1)
     bad = robust & ~same
     assert not bool(bad.any()), f"{what}: robust problems {bad.nonzero().flatten().tolist()} differ from the oracle"
     agree = float(same.float().mean())

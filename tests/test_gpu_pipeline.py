@@ -110,9 +110,15 @@ def test_pipeline_vs_oracle_chain(dev, T, S, K, B, n_t, H):
     # stage 3: decode given identical inputs
     ref = opn.two_level_greedy(sd_low, sd_high, rows_want, T, K)
     robust = robust_problems(ref["margin_low"], ref["margin_high"])
-    s = assert_index_parity(out["idx_low"], ref["idx_low"], robust, "pipe/low", 0.8) & \
-        assert_index_parity(out["idx_high"], ref["idx_high"], robust, "pipe/high", 0.8)
+    s = assert_index_parity(out["idx_low"], ref["idx_low"], robust, "pipe/low", 0.8, rows_want) & \
+        assert_index_parity(out["idx_high"], ref["idx_high"], robust, "pipe/high", 0.8, rows_want)
+    assert bool(robust.any())
     assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
+    # "selected service indices" (north star): the chosen service ids agree with the oracle's
+    ids = out["candidate_ids"].cpu().long()
+    sel_got = torch.gather(ids, 1, out["idx_high"].cpu().long())
+    sel_ref = torch.gather(ids, 1, ref["idx_high"])
+    assert torch.equal(sel_got[s], sel_ref[s])
     # sharding the batch does not change any result (what dist.py relies on)
     svc = DeviceServices.from_table(table, dev)
     full = DeviceBatch.from_problems(pb, dev)

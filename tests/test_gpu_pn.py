@@ -30,8 +30,8 @@ def test_two_level_greedy_golden(dev, name):
     x = torch.from_numpy(fx["inputs"]).to(dev)
     out = two_level_greedy(low, high, x)
     robust = robust_problems(fx["margin_low"], fx["margin_high"])
-    same_low = assert_index_parity(out["idx_low"], fx["idx_low"], robust, f"{name}/low", min_agree=0.7)
-    same = assert_index_parity(out["idx_high"], fx["idx_high"], robust, f"{name}/high", min_agree=0.7) & same_low
+    same_low = assert_index_parity(out["idx_low"], fx["idx_low"], robust, f"{name}/low", 0.7, fx["inputs"])
+    same = assert_index_parity(out["idx_high"], fx["idx_high"], robust, f"{name}/high", 0.7, fx["inputs"]) & same_low
     assert bool(robust.any()), "fixture has no robust problem"
     # on problems whose picks agree the float outputs must agree within tolerance
     s = same.numpy()
@@ -112,6 +112,6 @@ def test_fresh_oracle_batch(dev):
     ref = opn.two_level_greedy(opn.make_state_dict(256, 101), opn.make_state_dict(256, 102), x, 12, 4)
     out = two_level_greedy(low, high, x.to(dev))
     robust = robust_problems(ref["margin_low"], ref["margin_high"])
-    s = assert_index_parity(out["idx_high"], ref["idx_high"], robust, "fresh/high", 0.8) & \
-        assert_index_parity(out["idx_low"], ref["idx_low"], robust, "fresh/low", 0.8)
+    s = assert_index_parity(out["idx_high"], ref["idx_high"], robust, "fresh/high", 0.8, x) & \
+        assert_index_parity(out["idx_low"], ref["idx_low"], robust, "fresh/low", 0.8, x)
     assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
