@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""CLI of the ML+2PN mode, mirroring the reference's ``python main.py <dataset> ML+2PN [epoch]``
+(reference main.py:216-231): score the artefacts under ./solutions with ``ML2PN.check``.
+
+    python main.py QWS ML+2PN            # epoch from environment.ini ([QWS-ML+2PN] -> -1)
+    python main.py Normal ML+2PN 3       # argv[3] overrides the epoch (reference main.py:219-220)
+    python main.py QWS ML+2PN -1 --infer # first PRODUCE the artefacts on the GPU (random-init or
+                                         # ./solutions/pretrained/<ds>-{ML.pt,PNLow.model,PNHigh.model}
+                                         # weights), then score them
+
+Every other approach of the reference (training, WOA, GA/DQN baselines) is out of scope and
+answers with the reference's own message.
+"""
+import configparser
+import os
+import sys
+
+
+def _models(cfg, ds, n_services, n_cat):
+    import torch
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    ml, pn = cfg[f"{ds}-ML"], cfg[f"{ds}-PNHigh"]
+    K, H = int(pn["serNumber"]), int(pn["hidden_size"])
+    torch.manual_seed(0)
+    net = Net(int(ml["hiddenChannels"]), n_services, int(ml["embeddingChannels"]), int(ml["numLayersGIN"]),
+              int(ml["numLayersGCN"]), vocab=max(100, n_cat + 1))
+    mk = lambda lvl: CombinatorialRL(0, H, n_cat * K, int(pn["n_glimpses"]), float(pn["tanh_exploration"]),  # noqa: E731
+                                     int(pn["use_tanh"]), reward, "Dot", K, n_cat, level=lvl)
+    low, high = mk("Low"), mk("High")
+    pre = "./solutions/pretrained/"
+    if os.path.exists(pre + f"{ds}-ML.pt"):
+        net.load_state_dict(torch.load(pre + f"{ds}-ML.pt", map_location="cpu"))
+    for m, name in ((low, f"{ds}-PNLow.model"), (high, f"{ds}-PNHigh.model")):
+        if os.path.exists(pre + name):      # checkpoint format of trainPNLow.py:112-117 / trainPNHigh.py:118-123
+            m.load_state_dict(torch.load(pre + name, map_location="cpu")["model"])
+    return net, low, high, K
+
+
+def main(argv):
+    if len(argv) < 3:
+        print("Please check the parameters!")
+        return 1
+    dataset, approach = argv[1], argv[2]
+    ds = {"QWS": "QWS", "qws": "QWS", "Normal": "Normal"}.get(dataset)
+    if ds is None or approach != "ML+2PN":
+        print("Please check the parameters!")                       # reference main.py:231
+        return 1
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = configparser.RawConfigParser()
+    cfg.optionxform = str
+    cfg.read([os.path.join(here, "environment.ini"), "environment.ini"])
+    sec = cfg[f"{ds}-ML+2PN"]
+    flags = [a for a in argv[3:] if a.startswith("--")]
+    pos = [a for a in argv[3:] if not a.startswith("--")]
+    epoch = int(pos[0]) if pos else int(sec["epoch"])
+    n_cat = int(sec["serviceCategory"])
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    from gnnpn_sc_amd import ML2PN
+    if "--infer" in flags:
+        import json
+        with open(f"./data/{ds}/serviceFeature.data") as f:
+            sf = json.load(f)
+        n_services = sum(len(v) for v in sf.values())
+        net, low, high, K = _models(cfg, ds, n_services, len(sf))
+        ML2PN.infer(ds, net, low, high, K, epoch)
+        n_cat = len(sf)
+    ML2PN.check(ds, n_cat, epoch)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

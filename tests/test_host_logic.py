@@ -1,0 +1,185 @@
+"""-m "not gpu": host-side mirrors (loadData, loadDataPN, ML2PN.check, main.py CLI), layout helpers,
+state_dict compatibility, sharding + the gloo world_size-2 all-gather."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import ml as oml
+from oracle import pn as opn
+
+
+@pytest.fixture()
+def fx():
+    with open(os.path.join(GOLDEN, "data_small.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture()
+def workdir(fx, tmp_path, monkeypatch):
+    import gnnpn_sc_amd.synth as synth
+    synth.write_dataset(str(tmp_path), "QWS", fx["dataset"])
+    (tmp_path / "solutions" / "pretrained").mkdir(parents=True)
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def test_loadData_matches_reference(fx, workdir):
+    from gnnpn_sc_amd.loadData import loadData
+    nodes, services, ei, eis, eas, labels, inv = loadData("QWS")
+    g = fx["loadData"]
+    assert nodes == g["nodefeatures"] and services == g["serviceFeatureList"]
+    assert eis == g["edge_indices_service"] and eas == g["edge_attrs_service"]
+    assert ei == fx["dataset"]["edge_indices"] and labels == fx["dataset"]["labels"]
+    assert inv.shape == (fx["S"],)
+
+
+def test_loadDataPN_matches_reference(fx, workdir):
+    from gnnpn_sc_amd.loadData import loadDataPN
+    P, K, T = fx["P"], fx["K"], fx["T"]
+    (workdir / "solutions" / "pretrained" / "QWS-ML.txt").write_text(json.dumps([fx["rank_shared"]] * P))
+    rows, labels = loadDataPN(epoch=-1, dataset="QWS", serviceNumber=K)
+    assert rows == fx["rows_shared"] and labels == fx["dataset"]["minCostList"]
+    # epoch >= 0 reads the other artefact path (loadData.py:84-86)
+    (workdir / "solutions" / "ML" / "QWS").mkdir(parents=True)
+    (workdir / "solutions" / "ML" / "QWS" / "testServices-epoch2.txt").write_text(json.dumps(fx["rank_each"]))
+    rows_e, _ = loadDataPN(epoch=2, dataset="QWS", serviceNumber=K)
+    for p in range(P):
+        for c in range(T):
+            got = sorted({tuple(r) for r in rows_e[p][c * K:(c + 1) * K]})
+            assert got == [tuple(r) for r in fx["rows_each_sets"][p][c]]
+
+
+def test_check_and_cli_match_reference(fx, workdir):
+    from gnnpn_sc_amd import ML2PN
+    P, T = fx["P"], fx["T"]
+    (workdir / "solutions" / "pretrained" / "QWS-ML.txt").write_text(json.dumps([fx["rank_shared"]] * P))
+    (workdir / "solutions" / "pretrained" / "QWS-PNHigh.txt").write_text(json.dumps(fx["check"]["actions"]))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = ML2PN.check("QWS", T, -1)
+    assert abs(res - fx["check"]["score"]) < 1e-12
+    assert buf.getvalue() == fx["check"]["printed"]            # same printed line as the reference
+    # CLI: section [QWS-ML+2PN] says serviceCategory = 47; this dataset has T = 6 -> use a local ini
+    (workdir / "environment.ini").write_text("[QWS-ML+2PN]\nserviceCategory = 6\nepoch = -1\n"
+                                             "[Normal-ML+2PN]\nserviceCategory = 6\nepoch = -1\n")
+    import main as cli
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["main.py", "qws", "ML+2PN"]) == 0
+    assert buf.getvalue() == fx["check"]["printed"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["main.py", "QWS", "WOA"]) == 1
+    assert buf.getvalue().strip() == "Please check the parameters!"       # reference main.py:231
+
+
+def test_calc_penalties():
+    from gnnpn_sc_amd.ML2PN import calc
+    qos = [[0.2, 0.4], [0.5, 0.3], [0.9, 0.9], [1.0, 1.0]]
+    base = 0.5 * (0.3 + 1 - 0.3)
+    assert abs(calc(qos, [[0.5, 1.0], [0.5, 1.0]]) - base) < 1e-12
+    assert abs(calc(qos, [[0.9, 1.0], [0.5, 1.0]]) - (base + 1)) < 1e-12      # 0.81 < 0.9
+    assert abs(calc(qos, [[0.9, 1.0], [0.1, 0.5]]) - (base + 2)) < 1e-12      # and 1.0 > 0.5
+
+
+def test_state_dict_layout_is_the_reference_layout():
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    net = Net(128, 300, 20, 2, 4)
+    sd = oml.make_state_dict(128, 20, 2, 4, 0)
+    assert set(net.state_dict()) == set(sd)
+    assert all(net.state_dict()[k].shape == sd[k].shape for k in sd)
+    assert net.state_dict()["serviceConvs.0.weight"].shape == (24, 256)        # in x out (PyG 1.7)
+    pn = CombinatorialRL(0, 256, 235, 0, 10, 1, reward, "Dot", 5, 47)
+    want = opn.make_state_dict(256, 0)
+    assert set(pn.state_dict()) == set(want)
+    assert "actor.alpha" not in pn.state_dict()                                # plain tensor in the reference
+    ck = {"epoch": 3, "model": want, "optimizer": {}}                          # trainPNLow.py:112-117
+    pn.load_state_dict(ck["model"])
+
+
+def test_csr_layout_preserves_edge_order():
+    from gnnpn_sc_amd import graph
+    ei = torch.tensor([[3, 1, 2, 1, 0, 3], [0, 0, 1, 0, 2, 2]])
+    w = torch.arange(6).float()
+    csr = graph.csr_by_destination(ei, 4, w)
+    assert csr.rowptr.tolist() == [0, 3, 4, 6, 6]
+    assert csr.col.tolist() == [3, 1, 1, 2, 0, 3] and csr.w.tolist() == [0., 1., 3., 2., 4., 5.]
+    g = graph.gcn_csr(torch.tensor([[0, 1, 1], [1, 1, 0]]), torch.tensor([0.5, 7.0, 0.25]), 3)
+    # self loop of node 1 keeps weight 7; nodes 0 and 2 get weight-1 loops; loops come last in a row
+    assert g.rowptr.tolist() == [0, 2, 4, 5]
+    assert g.col.tolist() == [1, 0, 0, 1, 2] and g.w.tolist() == [0.25, 1.0, 0.5, 7.0, 1.0]
+    with pytest.raises(ValueError):
+        graph.segment_ptr(torch.tensor([0, 1, 0]), 2)
+
+
+def test_pack_lstm_weight_layout():
+    from gnnpn_sc_amd import ops
+    H = 8
+    w = torch.arange(4 * H * H, dtype=torch.float32).view(4 * H, H)
+    p = ops.pack_lstm_weight(w)
+    assert p.shape == (H // 4, 4, H, 4)
+    assert float(p[1, 2, 5, 3]) == float(w[2 * H + 5, 1 * 4 + 3])
+
+
+def test_synth_is_seeded_and_well_formed():
+    import gnnpn_sc_amd.synth as synth
+    a, b = synth.make_dataset(6, 40, 8, seed=3, tasks_per_problem=3), synth.make_dataset(6, 40, 8, seed=3, tasks_per_problem=3)
+    assert a == b
+    assert len(a["nodefeatures"][0][0]) == 6 + 1 + 6 and sum(a["labels"][0]) == 3
+    t = synth.make_service_table(47, 2507, 0, degree=32)
+    assert t.cat_ptr[-1] == 2507 and (np.diff(t.cat_ptr) >= 53).all()
+    ei = t.edge_index
+    assert (ei[0, 0::2] == ei[1, 1::2]).all() and (ei[1, 0::2] == ei[0, 1::2]).all()   # symmetric pairs
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gnnpn_sc_amd import dist
+    dist.init_process_group("gloo")
+    B, T = 7, 5
+    full = torch.arange(B * T, dtype=torch.int32).view(B, T)
+    sizes = [dist.shard_range(B, r, world)[1] - dist.shard_range(B, r, world)[0] for r in range(world)]
+    lo, hi = dist.shard_range(B, rank, world)
+    ragged = dist.all_gather_indices(full[lo:hi], sizes)
+    even = dist.all_gather_indices(full[rank * 3:(rank + 1) * 3])
+    t = dist.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
+    dist.barrier(world)
+    q.put((rank, torch.equal(ragged, full), torch.equal(even, full[:6]), t))
+    dist.destroy(world)
+
+
+def test_all_gather_of_indices_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, True, 2.0), (1, True, True, 2.0)]
+
+
+def test_batch_shard_is_a_partition():
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd.pipeline import DeviceBatch
+    table = synth.make_service_table(6, 40, 0, degree=4)
+    pb = synth.make_problem_batch(table, 7, tasks_per_problem=3)
+    full = DeviceBatch.from_problems(pb, torch.device("cpu"))
+    parts = [full.shard(r, 3) for r in range(3)]
+    assert sum(p.n_problems for p in parts) == 7
+    assert torch.equal(torch.cat([p.x for p in parts]), full.x)
+    assert torch.equal(torch.cat([p.present for p in parts]), full.present)
+    for p in parts:
+        assert int(p.seg_ptr[0]) == 0 and int(p.seg_ptr[-1]) == p.x.shape[0]
+        assert int(p.wf_csr.rowptr[-1]) == p.wf_csr.col.numel()
+        assert p.wf_csr.col.numel() == 0 or (int(p.wf_csr.col.min()) >= 0 and int(p.wf_csr.col.max()) < p.x.shape[0])

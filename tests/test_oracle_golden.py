@@ -1,0 +1,116 @@
+"""-m "not gpu": the oracle (oracle/) against the golden vectors generated from the imported
+reference (tests/golden/make_golden.py).  This is what pins the checker."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+from oracle import data as odata
+from oracle import ml as oml
+from oracle import pn as opn
+
+
+@pytest.mark.parametrize("name", ["small", "dummy", "qws", "normal"])
+def test_pn_oracle_reproduces_reference(name):
+    fx = golden(f"pn_{name}.npz")
+    torch.set_num_threads(1)
+    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    out = opn.two_level_greedy(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])),
+                               torch.from_numpy(fx["inputs"]), T, K)
+    assert np.array_equal(out["idx_low"].numpy(), fx["idx_low"])
+    assert np.array_equal(out["idx_high"].numpy(), fx["idx_high"])
+    assert np.array_equal(out["actions"].numpy(), fx["actions"])
+    assert np.allclose(out["R"].numpy(), fx["R"], rtol=0, atol=1e-6)
+    assert np.allclose(out["win_low"].numpy(), fx["win_low"], rtol=0, atol=2e-5)
+    assert np.allclose(out["win_high"].numpy(), fx["win_high"], rtol=0, atol=2e-5)
+    lat1 = out["latent"][1].numpy()
+    assert np.array_equal(np.isinf(lat1), np.isinf(fx["latent_step1"]))
+
+
+def test_lstm_cell_explicit_matches_nn_lstm():
+    """Documents the cell arithmetic the kernels implement (gate order i,f,g,o)."""
+    sd = opn.make_state_dict(32, 3)
+    lstm = opn._lstm_module(sd, "decoder", 32)
+    g = torch.Generator().manual_seed(0)
+    x, h, c = (torch.randn(5, 32, generator=g) for _ in range(3))
+    with torch.no_grad():
+        _, (h_ref, c_ref) = lstm(x.unsqueeze(1), (h.unsqueeze(0), c.unsqueeze(0)))
+    h2, c2 = opn.lstm_cell_explicit(x, h, c, *(sd[f"actor.decoder.{k}"] for k in
+                                               ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")))
+    assert torch.allclose(h2, h_ref[0], atol=1e-6) and torch.allclose(c2, c_ref[0], atol=1e-6)
+
+
+def test_reward_known_answers():
+    fx = golden("reward.npz")
+    actions = [torch.from_numpy(fx["actions"][:, t]) for t in range(fx["actions"].shape[1])]
+    assert np.array_equal(opn.reward(actions, "Low").numpy(), fx["R_low"])
+    assert np.array_equal(opn.reward(actions, "High").numpy(), fx["R_high"])
+    assert fx["R_low"].tolist() == [0, 1, 2, 0, 0, 0]           # violated / dummy / boundary cases
+
+
+def test_decision_margin_ignores_duplicate_rows():
+    win = torch.tensor([[[1.0, 0.9999, 0.2]]])
+    rows = torch.tensor([[[1., 2.], [1., 2.], [3., 4.]]])       # rows 0 and 1 identical
+    assert abs(float(opn.decision_margin(win, rows)) - 0.8) < 1e-6
+    rows2 = torch.tensor([[[1., 2.], [1., 3.], [3., 4.]]])
+    assert abs(float(opn.decision_margin(win, rows2)) - 1e-4) < 1e-6
+
+
+def _fx_data():
+    with open(os.path.join(GOLDEN, "data_small.json")) as f:
+        return json.load(f)
+
+
+def test_data_oracle_reproduces_reference():
+    fx = _fx_data()
+    ds, K, T, P = fx["dataset"], fx["K"], fx["T"], fx["P"]
+    assert odata.node_rows(ds["nodefeatures"]) == fx["loadData"]["nodefeatures"]
+    assert odata.service_rows(ds["serviceFeature"]) == fx["loadData"]["serviceFeatureList"]
+    ei, w = odata.service_graph(ds["labels"])
+    assert ei == fx["loadData"]["edge_indices_service"] and w == fx["loadData"]["edge_attrs_service"]
+    rows, labels = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], [fx["rank_shared"]] * P,
+                                      ds["minCostList"], K)
+    assert rows == fx["rows_shared"] and labels == ds["minCostList"]
+    rows_e, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], fx["rank_each"], ds["minCostList"], K)
+    for p in range(P):
+        for c in range(T):
+            got = sorted({tuple(r) for r in rows_e[p][c * K:(c + 1) * K]})
+            assert got == [tuple(r) for r in fx["rows_each_sets"][p][c]]
+    k1, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], [fx["rank_shared"]] * P, ds["minCostList"], 1)
+    assert abs(odata.check(k1, ds["minCostList"], fx["check"]["actions"], T) - fx["check"]["score"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["tiny", "qws", "normal"])
+def test_ml_oracle_reproduces_reference_glue(name):
+    fx = golden(f"ml_{name}.npz")
+    torch.set_num_threads(1)
+    sd = oml.make_state_dict(int(fx["hidden"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]), int(fx["seed"]) + 2)
+    t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
+    data = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service"), t("edge_index_service"),
+                         t("edge_attr_service"))
+    scores = oml.net_forward(sd, data, int(fx["n_gin"]), int(fx["n_gcn"]))
+    assert float((scores - t("scores")).abs().max()) <= 1e-6
+    assert torch.equal(oml.rank_services(t("scores")), t("ranking"))
+
+
+def test_hand_graph():
+    fx = golden("hand_graph.npz")
+    x, ei, w = torch.from_numpy(fx["x"]), torch.from_numpy(fx["edge_index"]), torch.from_numpy(fx["w"])
+    out = oml.gcn_conv(x, ei, w, torch.from_numpy(fx["weight"]), torch.from_numpy(fx["bias"]))
+    assert torch.equal(out, torch.from_numpy(fx["gcn"]))
+    # hand check of one entry: node 3 has in-edges {4->3 (w .125), self loop (w 1)}; deg = 1.125
+    row, col, norm = oml.gcn_norm(ei, w, 5)
+    sel = (col == 3)
+    assert sorted(row[sel].tolist()) == [3, 4]
+    deg3, deg4 = 0.125 + 1.0, 0.75 + 3.0
+    assert abs(float(norm[sel & (row == 4)]) - 0.125 / (deg3 ** 0.5 * deg4 ** 0.5)) < 1e-7
+    # existing self loops keep their weight (node 4: 3.0, node 2: 0.0 -> weight-0 loop)
+    assert float(norm[(row == 2) & (col == 2)]) == 0.0
+
+
+def test_rank_is_stable_lowest_index_first():
+    s = torch.tensor([[0.5, 0.9, 0.5, 0.9, 0.1]])
+    assert oml.rank_services(s).tolist() == [[1, 3, 0, 2, 4]]
