@@ -9,17 +9,7 @@
 // W_hh (1 MiB at H=256) is re-streamed from L2 every step; the step is bound by that stream.
 #include "common.h"
 #include "recurrent.h"
-
-#define GNNPN_MAX_NETS 4
-
-struct LstmNets {
-    const float* pregates[GNNPN_MAX_NETS];
-    const float* whh[GNNPN_MAX_NETS];
-    const float* bhh[GNNPN_MAX_NETS];
-    float* enc_out[GNNPN_MAX_NETS];
-    float* h_n[GNNPN_MAX_NETS];
-    float* c_n[GNNPN_MAX_NETS];
-};
+#include "lstm_shared.h"
 
 template <int H, int BT>
 __global__ __launch_bounds__(H) void lstm_encode_kernel(LstmNets nets, int32_t B, int32_t L) {
@@ -96,7 +86,8 @@ static int launch_encode(const LstmNets& nets, int n_nets, int32_t B, int32_t L,
 
 extern "C" int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float* const* whh_packed,
                                      const float* const* bhh, float* const* enc_out, float* const* h_n,
-                                     float* const* c_n, int32_t B, int32_t L, int32_t H, void* stream) {
+                                     float* const* c_n, int32_t B, int32_t L, int32_t H, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
     GNNPN_REQUIRE(pregates && whh_packed && bhh && enc_out && h_n && c_n, "lstm_encode: null pointer array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
@@ -115,8 +106,15 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, c
     }
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (H == 256) launch_encode<256>(nets, n_nets, B, L, s);
-    else launch_encode<32>(nets, n_nets, B, L, s);
+    const int impl = gnnpn_option_lstm_impl();   // 0 auto, 1 per-workgroup streaming, 2 cooperative
+    if (H == 256 && impl != 1 && (workspace != nullptr || impl == 2)) {
+        const int rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, workspace, workspace_bytes, s);
+        if (rc != GNNPN_OK) return rc;
+    } else if (H == 256) {
+        launch_encode<256>(nets, n_nets, B, L, s);
+    } else {
+        launch_encode<32>(nets, n_nets, B, L, s);
+    }
     GNNPN_CHECK_LAUNCH("lstm_encode_f32");
     return GNNPN_OK;
 }

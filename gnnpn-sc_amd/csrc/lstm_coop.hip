@@ -1,0 +1,218 @@
+// Pointer-network LSTM encoder recurrence, cooperative form (v2).
+//
+// v1 (lstm.hip) gives each workgroup whole problems and re-streams the 1 MiB W_hh from L2 every
+// step (~11 us/step measured).  Here the recurrent weights never move: a GROUP of G = 8
+// workgroups (one per CU) owns a tile of 16 problems; member m keeps the W_hh rows of hidden
+// units [32m, 32m+32) (128 gate columns) in REGISTERS as fp32 MFMA B-fragments (128 VGPRs/lane)
+// for the whole launch.  Per step a member
+//   1. gathers the tile's full h_{t-1} [16 x 256] from the group's exchange buffer into LDS,
+//   2. runs 128 v_mfma_f32_16x16x4_f32 per wave (exact fp32, k-ordered fma chain: bit-identical
+//      to v1's per-thread fmaf chain),
+//   3. adds bias + pre-gates, applies the cell update in registers (c never leaves them),
+//   4. writes its h_t slice to enc_out and PUBLISHES it to the 7 peers.
+// Hand-off = 8-byte {tag = step+1, value} granules written with ONE sc1 (write-through, agent
+// scope) store each and swept by sc1 loads until every tag matches: the data is the flag, no
+// fences, no separate flag round trip, placement independent (CDNA4 guide, Guideline 16 / R2).
+// Buffers are double-buffered by step parity; a member can run at most one step ahead of any
+// peer, so a slot is never overwritten before every peer has read it.  Every spin is bounded:
+// on timeout the workgroup raises the launch's error word and leaves, so the grid always drains.
+// Groups are placed on one XCD (blockIdx % 8 equal) for speed only.
+#include "common.h"
+#include "recurrent.h"
+#include "lstm_shared.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+namespace {
+constexpr int H = 256;
+constexpr int G = 8;              // workgroups per group
+constexpr int ROWS = 16;          // problems per tile (MFMA M)
+constexpr int UNITS = H / G;      // hidden units per member
+constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
+constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
+}  // namespace
+
+__device__ __forceinline__ u64 granule_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dwordx2 sc1
+}
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
+}
+
+// Sweep this wave's quarter (rows 4w..4w+3, all 256 units) of one parity buffer until every
+// granule carries `tag`; values go to LDS.  Returns false on timeout.
+__device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, float* hs, int wave, int lane,
+                                              bool keep) {
+    const u64* src = buf + wave * 4 * H;
+    unsigned v[16];
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u64 x = granule_load(src + j * 64 + lane);
+            v[j] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == tag;
+        }
+        if (__all(ok)) break;
+        if (spins > SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = j * 64 + lane;            // 0..1023 within the quarter
+            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
+                                                                  unsigned* __restrict__ err, int32_t B, int32_t L,
+                                                                  int n_nets, int groups_per_net) {
+    __shared__ float hs[ROWS * LDH];
+    __shared__ int abort_flag;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, c = lane & 15;
+    // XCD-aware placement (speed only): blocks with equal blockIdx%8 share an XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gpx = (gridDim.x >> 3) / G;                 // groups per XCD
+    const int group = xcd * gpx + slot / G, member = slot % G;
+    const int net = group / groups_per_net, gi = group % groups_per_net;
+    if (net >= n_nets) return;                            // spare group: takes part in no exchange
+    if (threadIdx.x == 0) abort_flag = 0;
+
+    const float* __restrict__ pre = nets.pregates[net];
+    const float* __restrict__ Wp = nets.whh[net];
+    float* __restrict__ enc = nets.enc_out[net];
+    u64* xg = xchg + (size_t)group * (2 * ROWS * H);
+
+    // this lane's two gate columns: tile 0 = [i | f], tile 1 = [g | o], 8 units per wave
+    const int unit = member * UNITS + wave * 8 + (c & 7);
+    int wrow[2];
+    wrow[0] = (0 + (c >> 3)) * H + unit;
+    wrow[1] = (2 + (c >> 3)) * H + unit;
+    float wB[2][64], bh[2];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+        const int gate = wrow[tl] / H, u = wrow[tl] % H;
+        bh[tl] = nets.bhh[net][wrow[tl]];
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk)   // packed layout: W[g*H+u][4kk+kq] = Wp[((kk*4+g)*H+u)*4+kq]
+            wB[tl][kk] = Wp[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+    }
+
+    const int n_tiles = (B + ROWS - 1) / ROWS;
+    unsigned step = 0;                                     // running step counter: tag = step+1, parity = step&1
+    bool first_tile = true;
+    for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
+        const int b0 = tile * ROWS;
+        float cst[4] = {0.f, 0.f, 0.f, 0.f};
+        float hlast[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < L; ++t, ++step) {
+            // pre-gates of this step (consumed after the MFMAs: latency hidden)
+            float pg[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = b0 + kq * 4 + r;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+                    pg[tl][r] = b < B ? pre[((int64_t)b * L + t) * (4 * H) + wrow[tl]] : 0.0f;
+            }
+            // h_{t-1}: zeros at t == 0, else the peers' published slices.  At a tile switch the
+            // sweep still runs (values dropped): it proves every peer is done with the buffer
+            // this member is about to overwrite.
+            bool ok = true;
+            if (t == 0) {
+                for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
+                if (!first_tile) ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
+            } else {
+                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true);
+            }
+            if (!ok) abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) break;
+
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+                float a[64];
+#pragma unroll
+                for (int kk = 0; kk < 64; ++kk) a[kk] = hs[c * LDH + 4 * kk + kq];
+#pragma unroll
+                for (int kk = 0; kk < 64; ++kk) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[0][kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[1][kk], acc1, 0, 0, 0);
+                }
+            }
+            __syncthreads();   // everyone is done reading hs before the next step's sweep rewrites it
+
+            u64* out_buf = xg + (step & 1) * (ROWS * H);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // gates = (h.W_hh^T + b_hh) + (x.W_ih^T + b_ih); lanes c<8 hold (i,g), c>=8 hold (f,o)
+                const float g0 = __fadd_rn(__fadd_rn(acc0[r], bh[0]), pg[0][r]);
+                const float g1 = __fadd_rn(__fadd_rn(acc1[r], bh[1]), pg[1][r]);
+                const float a0 = sigmoid_f32(g0);
+                const float a1 = (c < 8) ? tanhf(g1) : sigmoid_f32(g1);
+                const float p0 = __shfl_xor(a0, 8, 64), p1 = __shfl_xor(a1, 8, 64);
+                const float ig = (c < 8) ? a0 : p0, gg = (c < 8) ? a1 : p1;
+                const float fg = (c < 8) ? p0 : a0, og = (c < 8) ? p1 : a1;
+                cst[r] = __fadd_rn(__fmul_rn(fg, cst[r]), __fmul_rn(ig, gg));
+                hlast[r] = __fmul_rn(og, tanhf(cst[r]));
+                if (c < 8) {
+                    const int row = kq * 4 + r;
+                    granule_store(out_buf + row * H + unit, step + 1, hlast[r]);
+                    if (b0 + row < B) enc[((int64_t)(b0 + row) * L + t) * H + unit] = hlast[r];
+                }
+            }
+        }
+        if (abort_flag) break;
+        if (c < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = b0 + kq * 4 + r;
+                if (b < B) {
+                    nets.h_n[net][(int64_t)b * H + unit] = hlast[r];
+                    nets.c_n[net][(int64_t)b * H + unit] = cst[r];
+                }
+            }
+        }
+        first_tile = false;
+    }
+    if (abort_flag && threadIdx.x == 0) atomicOr(err, 1u);
+}
+
+// workspace: [0,256) status words (word 0 = error), then the exchange buffers
+extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
+    return 256 + (int64_t)64 * 2 * ROWS * H * sizeof(u64);   // up to 64 groups
+}
+
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
+                             int64_t workspace_bytes, hipStream_t s) {
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: cannot query the device");
+    const int n_tiles = (B + ROWS - 1) / ROWS;
+    // groups per XCD: every workgroup must be resident at once (one per CU), grid = 8 * G * gpx
+    int gpx = n_cu / (8 * G);
+    if (gpx > 8) gpx = 8;
+    while (gpx > 1 && (gpx - 1) * 8 >= n_nets * n_tiles) --gpx;
+    if (gpx < 1) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, cooperative form needs >= 64", n_cu);
+    const int groups = gpx * 8;
+    if (groups < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups, n_nets);
+    const int groups_per_net = groups / n_nets;
+    const int64_t need = 256 + (int64_t)groups * 2 * ROWS * H * sizeof(u64);
+    if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
+        GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
+    // zero the status word and every tag before each launch (tags start at 1)
+    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
+    hipLaunchKernelGGL(lstm_encode_coop_kernel, dim3(groups * G), dim3(256), 0, s, nets,
+                       reinterpret_cast<u64*>(static_cast<char*>(workspace) + 256),
+                       reinterpret_cast<unsigned*>(workspace), B, L, n_nets, groups_per_net);
+    return GNNPN_OK;
+}

@@ -1,0 +1,19 @@
+// Argument block shared by the two encoder implementations (lstm.hip, lstm_coop.hip).
+#pragma once
+#include "common.h"
+
+#define GNNPN_MAX_NETS 4
+
+struct LstmNets {
+    const float* pregates[GNNPN_MAX_NETS];
+    const float* whh[GNNPN_MAX_NETS];
+    const float* bhh[GNNPN_MAX_NETS];
+    float* enc_out[GNNPN_MAX_NETS];
+    float* h_n[GNNPN_MAX_NETS];
+    float* c_n[GNNPN_MAX_NETS];
+};
+
+
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
+                             int64_t workspace_bytes, hipStream_t s);
+int gnnpn_option_lstm_impl();

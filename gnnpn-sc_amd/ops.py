@@ -116,6 +116,35 @@ def pack_lstm_weight(w):
     return w.reshape(4, H, H // 4, 4).permute(2, 0, 1, 3).contiguous()
 
 
+_workspaces = {}
+
+
+def set_option(name, value):
+    """Run-time A/B switches of the library (gnnpn_set_option), e.g. ("lstm_impl", 1)."""
+    check(_lib.load().gnnpn_set_option(name.encode(), int(value)), "gnnpn_set_option")
+
+
+def encode_workspace(device):
+    """Per-device workspace of the cooperative encoder (status word + hand-off buffers)."""
+    key = (device.type, device.index)
+    if key not in _workspaces:
+        n = int(_lib.load().gnnpn_lstm_encode_workspace_bytes())
+        _workspaces[key] = torch.zeros(n, dtype=torch.uint8, device=device)
+    return _workspaces[key]
+
+
+def check_status(device):
+    """Synchronise and raise if a bounded inter-workgroup wait of the cooperative kernels timed
+    out (their outputs would be invalid).  Called by tests / bench after a run, never inside it."""
+    ws = _workspaces.get((device.type, device.index))
+    if ws is None:
+        return
+    torch.cuda.synchronize(device)
+    word = int(ws[:4].view(torch.int32).item())
+    if word != 0:
+        raise GnnpnError(f"cooperative kernel reported status {word:#x}: an inter-workgroup hand-off timed out")
+
+
 def lstm_encode(pregates, whh_packed, bhh):
     """Run the encoder recurrence of len(pregates) nets in ONE launch.
     pregates[n] [B,L,4H] -> (enc_out[n] [B,L,H], h_n[n] [B,H], c_n[n] [B,H])."""
@@ -126,10 +155,12 @@ def lstm_encode(pregates, whh_packed, bhh):
     enc = [torch.empty((B, L, H), dtype=F32, device=dev) for _ in range(n)]
     h_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
     c_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
+    ws = encode_workspace(dev) if H == 256 else None
     check(_lib.load().gnnpn_lstm_encode_f32(
         n, ptr_array(pregates, F32, "pregates"), ptr_array(whh_packed, F32, "whh"), ptr_array(bhh, F32, "bhh"),
         ptr_array(enc, F32, "enc_out"), ptr_array(h_n, F32, "h_n"), ptr_array(c_n, F32, "c_n"), B, L, H,
-        stream_ptr()), "gnnpn_lstm_encode_f32")
+        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
+        "gnnpn_lstm_encode_f32")
     return enc, h_n, c_n
 
 

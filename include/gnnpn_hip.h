@@ -124,10 +124,22 @@ int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, in
  *   enc_out[n]   [B, L, H];  h_n[n], c_n[n]  [B, H]
  * H must be 256 or 32 (the configurations of environment.ini:55 and of the unit fixtures).
  * Pointer arrays are HOST arrays of device pointers.
+ * Two implementations with bit-identical results: cooperative (H = 256 and a workspace given:
+ * groups of 8 workgroups keep W_hh in registers and exchange h every step) and streaming.
  * Replaces: nn.LSTM encoder at src/models/modelPN.py:157,191. */
 int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float* const* whh_packed,
                           const float* const* bhh, float* const* enc_out, float* const* h_n,
-                          float* const* c_n, int32_t B, int32_t L, int32_t H, void* stream);
+                          float* const* c_n, int32_t B, int32_t L, int32_t H, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
+/* Size of the device workspace the cooperative encoder needs (status words + hand-off buffers).
+ * With workspace == NULL gnnpn_lstm_encode_f32 uses the per-workgroup streaming form instead.
+ * After the stream has been synchronised, word 0 of the workspace (uint32) is non-zero iff a
+ * bounded inter-workgroup wait timed out (outputs are then invalid). */
+int64_t gnnpn_lstm_encode_workspace_bytes(void);
+
+/* Run-time switches for A/B measurements: "lstm_impl" = 0 auto, 1 streaming, 2 cooperative. */
+int gnnpn_set_option(const char* name, int value);
 
 /* Greedy pointer decode of ONE net: T steps of {decoder LSTM cell; dot-attention logits over the
  * step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent window (High net) ; softmax;

@@ -153,6 +153,31 @@ def test_lstm_encode_vs_torch(dev, H, B, L):
     assert torch.equal(enc[0], enc[1])      # two nets in one launch are independent and deterministic
 
 
+@pytest.mark.parametrize("B,L,nets", [(16, 12, 1), (37, 30, 2), (256, 235, 2), (300, 20, 3), (1040, 9, 2)])
+def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
+    """The cooperative form (weights in registers, per-step granule hand-off between 8 CUs) and the
+    per-workgroup streaming form are the same k-ordered fp32 fma chains: bit-identical outputs.
+    Sizes cover partial tiles, several tiles per group (tile switch path) and 3 nets."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + L)
+    H = 256
+    pre = [(torch.randn(B, L, 4 * H, generator=g) * 0.7).to(dev) for _ in range(nets)]
+    whh = [ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
+    bhh = [((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
+    try:
+        ops.set_option("lstm_impl", 1)
+        ref = ops.lstm_encode(pre, whh, bhh)
+        ops.set_option("lstm_impl", 2)
+        out = ops.lstm_encode(pre, whh, bhh)
+        out2 = ops.lstm_encode(pre, whh, bhh)       # back-to-back launches reuse the hand-off buffers
+    finally:
+        ops.set_option("lstm_impl", 0)
+    ops.check_status(dev)
+    for n in range(nets):
+        for a, b, c in zip(ref, out, out2):
+            assert torch.equal(a[n], b[n]) and torch.equal(a[n], c[n])
+
+
 def test_qos_reward_golden(dev):
     ops = _ops()
     fx = golden("reward.npz")
