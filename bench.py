@@ -60,8 +60,9 @@ def algorithmic_cost(name, w, B):
     L = T * K
     if name == "lstm_encode":       # both nets in one launch: recurrent matmul flops
         return dict(bound="mfma", work=2 * B * L * 2 * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
-    if name == "pointer_decode":    # one net: window rows of enc_out + embedded pick + state + outputs
-        byt = B * (L * H * 4 + T * (H * 4 + 2 * H * 4) + T * (8 * 4 + K * 4 + 8 + 32))
+    if name == "pointer_decode":    # BOTH nets in one launch; per net: every enc_out row once (L*H*4), the
+        # picked embedded row + state per step, outputs   (SURVEY §8d "PN decode, one problem, one net")
+        byt = 2 * B * (L * H * 4 + T * (H * 4 + 2 * H * 4) + T * (8 * 4 + K * 4 + 8 + 32))
         return dict(bound="hbm", work=byt, unit="GB/s", peak=PEAK_HBM_GBS)
     if name == "pregates_gemm":     # [B*L,256] x [256,1024] per net
         return dict(bound="mfma", work=2 * B * L * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)

@@ -31,12 +31,21 @@ _SIGNATURES = {
     "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
-    "gnnpn_pointer_decode_f32": (c_int, [_P] * 11 + [c_float, c_int] + [_P] * 5 + [c_int32] * 4 + [_P]),
+    "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, _P,
+                                         c_int64, _P]),
+    "gnnpn_pointer_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
+
+class DecodeNet(ctypes.Structure):
+    """gnnpn_decode_net_t of include/gnnpn_hip.h."""
+    _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih_packed", "whh_packed", "bih",
+                                  "bhh", "latent_win", "idx", "win_logits", "pick_prob", "actions", "queries")] + \
+               [("latent_from", c_int32), ("reserved", c_int32)]
+
 
 _lib = None
 

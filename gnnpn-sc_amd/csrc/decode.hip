@@ -10,7 +10,9 @@
 //   C*tanh, + latent (High net), softmax over the window, first-max argmax (torch.max on CPU
 //   returns the first maximal index), gather of the next decoder input and of the action row.
 #include "common.h"
+#include <string.h>
 #include "recurrent.h"
+#include "decode_shared.h"
 
 template <int H, int BT>
 __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_kernel(
@@ -158,29 +160,55 @@ static void launch_decode(const float* embedded, const float* enc_out, const flo
 #undef GNNPN_LAUNCH_DEC
 }
 
-extern "C" int gnnpn_pointer_decode_f32(const float* embedded, const float* enc_out, const float* h0,
-                                        const float* c0, const float* start, const float* wih_packed,
-                                        const float* whh_packed, const float* bih, const float* bhh,
-                                        const float* latent_win, const float* inputs, float tanh_c, int use_tanh,
-                                        int32_t* idx, float* win_logits, float* pick_prob, float* actions,
-                                        float* queries, int32_t B, int32_t T, int32_t n_per, int32_t H,
-                                        void* stream) {
-    GNNPN_REQUIRE(embedded && enc_out && h0 && c0 && start && wih_packed && whh_packed && bih && bhh && inputs,
-                  "pointer_decode: null input");
-    GNNPN_REQUIRE(idx && win_logits && pick_prob && actions, "pointer_decode: null output");
+extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const float* inputs,
+                                        float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+    GNNPN_REQUIRE(nets && inputs, "pointer_decode: null input");
+    GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_DECODE_NETS, "pointer_decode: n_nets must be 1..%d",
+                  GNNPN_MAX_DECODE_NETS);
     GNNPN_REQUIRE(B >= 0 && T > 0, "pointer_decode: bad shape");
     GNNPN_REQUIRE(n_per >= 1 && n_per <= 64, "pointer_decode: n_per must be in [1,64], got %d", n_per);
-    GNNPN_REQUIRE(gnnpn_aligned(wih_packed, 16) && gnnpn_aligned(whh_packed, 16) && gnnpn_aligned(enc_out, 16),
-                  "pointer_decode: weights / enc_out must be 16-byte aligned");
     if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: hidden size %d not built (256, 32)", H);
+    DecodeArgs args{};
+    for (int n = 0; n < n_nets; ++n) {
+        const gnnpn_decode_net_t& d = nets[n];
+        GNNPN_REQUIRE(d.embedded && d.enc_out && d.h0 && d.c0 && d.start && d.wih_packed && d.whh_packed && d.bih &&
+                          d.bhh, "pointer_decode: null input of net %d", n);
+        GNNPN_REQUIRE(d.idx && d.win_logits && d.pick_prob && d.actions, "pointer_decode: null output of net %d", n);
+        GNNPN_REQUIRE(d.latent_from < n && d.latent_from >= -1, "pointer_decode: latent_from of net %d must name an "
+                      "earlier net of the call", n);
+        GNNPN_REQUIRE(!(d.latent_win && d.latent_from >= 0), "pointer_decode: net %d has two latent sources", n);
+        GNNPN_REQUIRE(gnnpn_aligned(d.wih_packed, 16) && gnnpn_aligned(d.whh_packed, 16) &&
+                          gnnpn_aligned(d.enc_out, 16) && gnnpn_aligned(d.embedded, 16),
+                      "pointer_decode: weights / enc_out / embedded must be 16-byte aligned");
+        static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "layout");
+        memcpy(&args.net[n], &d, sizeof(DecodeNet));
+    }
+    args.inputs = inputs;
+    args.tanh_c = tanh_c;
+    args.use_tanh = use_tanh;
+    args.B = B;
+    args.T = T;
+    args.K = n_per;
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (H == 256)
-        launch_decode<256>(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, latent_win, inputs,
-                           tanh_c, use_tanh, idx, win_logits, pick_prob, actions, queries, B, T, n_per, s);
-    else
-        launch_decode<32>(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, latent_win, inputs,
-                          tanh_c, use_tanh, idx, win_logits, pick_prob, actions, queries, B, T, n_per, s);
+    const int impl = gnnpn_option_decode_impl();   // 0 auto, 1 streaming, 2 cooperative
+    if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl == 2)) {
+        const int rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+        if (rc != GNNPN_OK) return rc;
+        GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
+        return GNNPN_OK;
+    }
+    for (int n = 0; n < n_nets; ++n) {   // streaming form: one net after the other (Low before High)
+        const DecodeNet& d = args.net[n];
+        const float* latent = d.latent_from >= 0 ? args.net[d.latent_from].win_logits : d.latent_win;
+        if (H == 256)
+            launch_decode<256>(d.embedded, d.enc_out, d.h0, d.c0, d.start, d.wih, d.whh, d.bih, d.bhh, latent, inputs,
+                               tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per, s);
+        else
+            launch_decode<32>(d.embedded, d.enc_out, d.h0, d.c0, d.start, d.wih, d.whh, d.bih, d.bhh, latent, inputs,
+                              tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per, s);
+    }
     GNNPN_CHECK_LAUNCH("pointer_decode_f32");
     return GNNPN_OK;
 }

@@ -1,0 +1,40 @@
+// Argument blocks shared by the two decoder implementations (decode.hip, decode_coop.hip).
+#pragma once
+#include "common.h"
+
+// device-side view of gnnpn_decode_net_t (same field order; see include/gnnpn_hip.h)
+struct DecodeNet {
+    const float* embedded;
+    const float* enc_out;
+    const float* h0;
+    const float* c0;
+    const float* start;
+    const float* wih;
+    const float* whh;
+    const float* bih;
+    const float* bhh;
+    const float* latent_win;
+    int32_t* idx;
+    float* win_logits;
+    float* pick_prob;
+    float* actions;
+    float* queries;
+    int32_t latent_from;
+    int32_t reserved;
+};
+static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "DecodeNet must mirror gnnpn_decode_net_t");
+
+#define GNNPN_MAX_DECODE_NETS 2
+
+struct DecodeArgs {
+    DecodeNet net[GNNPN_MAX_DECODE_NETS];
+    const float* inputs;
+    float tanh_c;
+    int use_tanh;
+    int32_t B, T, K;
+};
+
+bool gnnpn_decode_coop_supported(int32_t H, int32_t n_per);
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace, int64_t workspace_bytes,
+                             hipStream_t s);
+int gnnpn_option_decode_impl();

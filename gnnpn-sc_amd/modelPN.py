@@ -123,11 +123,16 @@ class PointerNet(nn.Module):
         H = self.hidden_size
         return embedded.view(B, L, H), pregates.view(B, L, 4 * H)
 
-    def decode(self, inputs, embedded, enc_out, h_n, c_n, latent_win, want_queries=False):
+    def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1):
+        """One entry of the ``nets`` list of ops.pointer_decode."""
         w = self.packed()
-        return ops.pointer_decode(embedded, enc_out, h_n, c_n, w["start"], w["dec_wih"], w["dec_whh"], w["dec_bih"],
-                                  w["dec_bhh"], inputs, self.serCategory, self.serNumber, latent_win, self.C,
-                                  self.use_tanh, want_queries)
+        return {"embedded": embedded, "enc_out": enc_out, "h0": h_n, "c0": c_n, "start": w["start"],
+                "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"], "bhh": w["dec_bhh"],
+                "latent_win": latent_win, "latent_from": latent_from}
+
+    def decode(self, inputs, embedded, enc_out, h_n, c_n, latent_win, want_queries=False):
+        return ops.pointer_decode([self.decode_args(embedded, enc_out, h_n, c_n, latent_win)], inputs,
+                                  self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
 
     @torch.no_grad()
     def run(self, inputs, latent=None, want_queries=False):
@@ -237,8 +242,8 @@ class CombinatorialRL(nn.Module):
 @torch.no_grad()
 def two_level_greedy(low, high, inputs):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
-    ONE launch (they are independent), Low decode, High decode biased by Low's window logits,
-    QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
+    ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
+    logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
     action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
     win_high_raw + win_low (modelPN.py:216)."""
     inputs = inputs.contiguous()
@@ -248,8 +253,9 @@ def two_level_greedy(low, high, inputs):
     wl, wh = la.packed(), ha.packed()
     enc, h_n, c_n = ops.lstm_encode([pre_l, pre_h], [wl["enc_whh"], wh["enc_whh"]], [wl["enc_bhh"], wh["enc_bhh"]])
     del pre_l, pre_h
-    dl = la.decode(inputs, emb_l, enc[0], h_n[0], c_n[0], None)
-    dh = ha.decode(inputs, emb_h, enc[1], h_n[1], c_n[1], dl["win_logits"])
+    dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0]),
+                                 ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0)],
+                                inputs, la.serCategory, la.serNumber, la.C, la.use_tanh)
     R = ops.qos_reward(dh["actions"], high.level)
     return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
             "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -136,13 +136,14 @@ def encode_workspace(device):
 def check_status(device):
     """Synchronise and raise if a bounded inter-workgroup wait of the cooperative kernels timed
     out (their outputs would be invalid).  Called by tests / bench after a run, never inside it."""
-    ws = _workspaces.get((device.type, device.index))
-    if ws is None:
-        return
     torch.cuda.synchronize(device)
-    word = int(ws[:4].view(torch.int32).item())
-    if word != 0:
-        raise GnnpnError(f"cooperative kernel reported status {word:#x}: an inter-workgroup hand-off timed out")
+    for key, ws in _workspaces.items():
+        if key[:2] != (device.type, device.index):
+            continue
+        word = int(ws[:4].view(torch.int32).item())
+        if word != 0:
+            raise GnnpnError(f"cooperative kernel reported status {word:#x}: an inter-workgroup hand-off "
+                             "timed out (outputs invalid)")
 
 
 def lstm_encode(pregates, whh_packed, bhh):
@@ -164,28 +165,56 @@ def lstm_encode(pregates, whh_packed, bhh):
     return enc, h_n, c_n
 
 
-def pointer_decode(embedded, enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, inputs, n_cat, n_per,
-                   latent_win=None, tanh_c=10.0, use_tanh=True, want_queries=False):
-    """Greedy decode of one net -> dict(idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T],
-    actions [B,T,8], queries [B,T,H] | None)."""
-    B, L, H = enc_out.shape
+def decode_workspace(device, B, T, n_per):
+    """Per-device workspace of the cooperative decoder, grown on demand."""
+    key = (device.type, device.index, "decode")
+    need = int(_lib.load().gnnpn_pointer_decode_workspace_bytes(B, T, n_per))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False):
+    """Greedy decode of 1 or 2 pointer networks in ONE call (gnnpn_pointer_decode_f32).
+
+    nets: list of dicts with keys embedded, enc_out, h0, c0, start, wih, whh, bih, bhh and optionally
+    latent_win ([B,T,K] tensor computed earlier) or latent_from (index of an earlier net of this call).
+    Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
+    queries [B,T,H] | None."""
+    B, L, H = nets[0]["enc_out"].shape
     if L != n_cat * n_per:
         raise GnnpnError(f"pointer_decode: seq_len {L} != {n_cat}*{n_per}")   # modelPN.py:182
-    dev = enc_out.device
-    idx = torch.empty((B, n_cat), dtype=I32, device=dev)
-    win = torch.empty((B, n_cat, n_per), dtype=F32, device=dev)
-    prob = torch.empty((B, n_cat), dtype=F32, device=dev)
-    actions = torch.empty((B, n_cat, 8), dtype=F32, device=dev)
-    queries = torch.empty((B, n_cat, H), dtype=F32, device=dev) if want_queries else None
+    dev = nets[0]["enc_out"].device
+    arr = (_lib.DecodeNet * len(nets))()
+    outs = []
+    for i, d in enumerate(nets):
+        out = {"idx": torch.empty((B, n_cat), dtype=I32, device=dev),
+               "win_logits": torch.empty((B, n_cat, n_per), dtype=F32, device=dev),
+               "pick_prob": torch.empty((B, n_cat), dtype=F32, device=dev),
+               "actions": torch.empty((B, n_cat, 8), dtype=F32, device=dev),
+               "queries": torch.empty((B, n_cat, H), dtype=F32, device=dev) if want_queries else None}
+        outs.append(out)
+        a = arr[i]
+        for name, key in (("embedded", "embedded"), ("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"),
+                          ("start", "start"), ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"),
+                          ("bhh", "bhh")):
+            setattr(a, name, dev_ptr(d[key], F32, f"nets[{i}].{key}").value)
+        lw = d.get("latent_win")
+        a.latent_win = None if lw is None else dev_ptr(lw, F32, f"nets[{i}].latent_win").value
+        a.latent_from = int(d.get("latent_from", -1))
+        a.idx = dev_ptr(out["idx"], I32, "idx").value
+        a.win_logits = dev_ptr(out["win_logits"], F32, "win").value
+        a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value
+        a.actions = dev_ptr(out["actions"], F32, "actions").value
+        a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
+    ws = decode_workspace(dev, B, n_cat, n_per) if (H == 256 and n_per <= 16) else None
     check(_lib.load().gnnpn_pointer_decode_f32(
-        dev_ptr(embedded, F32, "embedded"), dev_ptr(enc_out, F32, "enc_out"), dev_ptr(h0, F32, "h0"),
-        dev_ptr(c0, F32, "c0"), dev_ptr(start, F32, "start"), dev_ptr(wih_packed, F32, "wih"),
-        dev_ptr(whh_packed, F32, "whh"), dev_ptr(bih, F32, "bih"), dev_ptr(bhh, F32, "bhh"),
-        dev_ptr(latent_win, F32, "latent_win", True), dev_ptr(inputs, F32, "inputs"), float(tanh_c),
-        int(bool(use_tanh)), dev_ptr(idx, I32, "idx"), dev_ptr(win, F32, "win"), dev_ptr(prob, F32, "prob"),
-        dev_ptr(actions, F32, "actions"), dev_ptr(queries, F32, "queries", True), B, n_cat, n_per, H,
-        stream_ptr()), "gnnpn_pointer_decode_f32")
-    return {"idx": idx, "win_logits": win, "pick_prob": prob, "actions": actions, "queries": queries}
+        len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
+        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
+        "gnnpn_pointer_decode_f32")
+    return outs
 
 
 def attention_logits(enc_out, queries, step, idx, tanh_c=10.0, use_tanh=True):

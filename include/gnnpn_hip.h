@@ -138,28 +138,56 @@ int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float*
  * bounded inter-workgroup wait timed out (outputs are then invalid). */
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
-/* Run-time switches for A/B measurements: "lstm_impl" = 0 auto, 1 streaming, 2 cooperative. */
+/* Run-time switches for A/B measurements: "lstm_impl" / "decode_impl" = 0 auto, 1 streaming,
+ * 2 cooperative. */
 int gnnpn_set_option(const char* name, int value);
 
-/* Greedy pointer decode of ONE net: T steps of {decoder LSTM cell; dot-attention logits over the
- * step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent window (High net) ; softmax;
- * first-max argmax; next input = embedded row of the pick}.
+/* Greedy pointer decode of up to two pointer networks in one call: T steps of {decoder LSTM cell;
+ * dot-attention logits over the step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent
+ * window (High net); softmax; first-max argmax; next input = embedded row of the pick}.
+ * Per net (gnnpn_decode_net_t, all device pointers):
  *   embedded [B,L,H]  enc_out [B,L,H]  h0,c0 [B,H]  start [H]
  *   wih_packed / whh_packed / bih / bhh : decoder LSTM (packed as for the encoder)
- *   latent_win  [B,T,n_per] or NULL : the Low net's in-window logits, added before the argmax
- *   inputs   [B,L,8] : rows gathered into `actions`
- * outputs: idx [B,T] int32; win_logits [B,T,n_per] (C*tanh(dot), before latent);
- *          pick_prob [B,T] softmax prob of the pick; actions [B,T,8]; queries [B,T,H] or NULL.
+ *   latent_win  [B,T,n_per] or NULL : window logits of a Low net computed EARLIER, added before the
+ *               argmax;   latent_from : index (< own index) of a net of THIS call whose window
+ *               logits are used instead (the two-level scheme of trainPNHigh.py:138-139), or -1
+ *   outputs: idx [B,T] int32; win_logits [B,T,n_per] (C*tanh(dot), before the latent is added);
+ *            pick_prob [B,T] softmax prob of the pick; actions [B,T,8]; queries [B,T,H] or NULL.
+ * inputs [B,L,8] : rows gathered into `actions`.   nets: HOST array of n_nets (1 or 2) structs.
+ * Two implementations: cooperative (H = 256, n_per <= 16, workspace given: 8-CU groups keep both
+ * weight matrices in registers; both nets in one launch, the High net one step behind the Low net)
+ * and per-workgroup streaming (nets decoded one after the other).  They differ only in the order
+ * the 256 products of an attention dot are summed.
  * Replaces: PointerNet.forward's decode loop src/models/modelPN.py:193-241 incl. Attention 'Dot'
  * (:111-114,119-120), the window mask loop (:220-222), softmax/max (:224-226), the gathers at
  * :235 and CombinatorialRL.forward :293-299. */
-int gnnpn_pointer_decode_f32(const float* embedded, const float* enc_out, const float* h0,
-                             const float* c0, const float* start, const float* wih_packed,
-                             const float* whh_packed, const float* bih, const float* bhh,
-                             const float* latent_win, const float* inputs, float tanh_c,
-                             int use_tanh, int32_t* idx, float* win_logits, float* pick_prob,
-                             float* actions, float* queries, int32_t B, int32_t T, int32_t n_per,
-                             int32_t H, void* stream);
+typedef struct {
+    const float* embedded;
+    const float* enc_out;
+    const float* h0;
+    const float* c0;
+    const float* start;
+    const float* wih_packed;
+    const float* whh_packed;
+    const float* bih;
+    const float* bhh;
+    const float* latent_win;
+    int32_t* idx;
+    float* win_logits;
+    float* pick_prob;
+    float* actions;
+    float* queries;
+    int32_t latent_from;
+    int32_t reserved;
+} gnnpn_decode_net_t;
+
+int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const float* inputs,
+                             float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Workspace the cooperative decoder needs for this shape (status words, hand-off buffers, the
+ * Low->High latent granules).  Word 0 after synchronisation: as for the encoder. */
+int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per);
 
 /* Full-length attention logits of ONE decode step, for callers that need the reference's
  * return values verbatim (the reference returns every step's whole [B,L] logits tensor,

@@ -115,3 +115,42 @@ def test_fresh_oracle_batch(dev):
     s = assert_index_parity(out["idx_high"], ref["idx_high"], robust, "fresh/high", 0.8, x) & \
         assert_index_parity(out["idx_low"], ref["idx_low"], robust, "fresh/low", 0.8, x)
     assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
+
+
+@pytest.mark.parametrize("B,T,K", [(16, 6, 3), (40, 47, 5), (256, 47, 5), (300, 12, 10), (23, 9, 16)])
+def test_decode_cooperative_vs_streaming(dev, B, T, K):
+    """Cooperative decoder (both nets in one launch, weights in registers, per-step hand-off) vs the
+    per-workgroup streaming decoder on the same encoder outputs.  The LSTM cells are the same fma
+    chains; only the 256-term attention dots are summed in a different order, so window logits agree
+    to ~1e-5 and picks agree wherever the streaming decision margin exceeds that."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": T, "n_per": K, "seed_low": 5 + B, "seed_high": 6 + B}
+    low, high = build(cfg, dev)
+    g = torch.Generator().manual_seed(B * T)
+    x = torch.rand(B, T * K, 8, generator=g)
+    x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
+    x[:, K:, 4:] = 0
+    x = x.to(dev)
+    try:
+        ops.set_option("decode_impl", 1)
+        ref = two_level_greedy(low, high, x)
+        ops.set_option("decode_impl", 2)
+        out = two_level_greedy(low, high, x)
+        out2 = two_level_greedy(low, high, x)
+    finally:
+        ops.set_option("decode_impl", 0)
+    ops.check_status(dev)
+    for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions", "action_probs"):
+        assert torch.equal(out[k], out2[k]), k                    # deterministic across launches
+    win_ref = torch.stack([ref["win_low"], ref["win_high_raw"] + ref["win_low"]]).cpu()
+    m = opn.decision_margin(win_ref[0], x.cpu()), opn.decision_margin(win_ref[1], x.cpu())
+    robust = (m[0] > 1e-3).all(1) & (m[1] > 1e-3).all(1)
+    same = assert_index_parity(out["idx_low"], ref["idx_low"], robust, "coop/low", 0.8, x.cpu()) & \
+        assert_index_parity(out["idx_high"], ref["idx_high"], robust, "coop/high", 0.8, x.cpu())
+    assert bool(robust.any())
+    s = same.to(dev)
+    assert float((out["win_low"][s] - ref["win_low"][s]).abs().max()) < 1e-4
+    assert float((out["win_high_raw"][s] - ref["win_high_raw"][s]).abs().max()) < 1e-4
+    assert float((out["R"][s] - ref["R"][s]).abs().max()) <= R_ATOL
+    assert float((out["action_probs"][s] - ref["action_probs"][s]).abs().max()) < 1e-4
