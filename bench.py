@@ -194,7 +194,7 @@ def main():
     if not args.no_kernel_timers:
         timers.wrap(ops, "lstm_encode", "lstm_encode")
         timers.wrap(ops, "pointer_decode", "pointer_decode")
-        timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: wt.shape == (1024, 256))
+        timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
         timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
 
     def step():

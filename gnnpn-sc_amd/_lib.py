@@ -28,7 +28,7 @@ _SIGNATURES = {
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "gnnpn_rank_rows": (c_int, [_P, c_int64, _P, c_int32, c_int32, _P]),
-    "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int64, _P]),
+    "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, _P,
@@ -43,8 +43,14 @@ EXPORTS = tuple(_SIGNATURES)
 class DecodeNet(ctypes.Structure):
     """gnnpn_decode_net_t of include/gnnpn_hip.h."""
     _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih_packed", "whh_packed", "bih",
-                                  "bhh", "latent_win", "idx", "win_logits", "pick_prob", "actions", "queries")] + \
+                                  "bhh", "latent_win", "emb_w", "emb_b", "idx", "win_logits", "pick_prob", "actions",
+                                  "queries")] + \
                [("latent_from", c_int32), ("reserved", c_int32)]
+
+
+class EncodeNet(ctypes.Structure):
+    """gnnpn_encode_net_t of include/gnnpn_hip.h."""
+    _fields_ = [(n, _P) for n in ("pregates", "inputs", "w_in", "b_in", "whh_packed", "bhh", "enc_out", "h_n", "c_n")]
 
 
 _lib = None

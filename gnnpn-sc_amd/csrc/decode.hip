@@ -172,14 +172,15 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     DecodeArgs args{};
     for (int n = 0; n < n_nets; ++n) {
         const gnnpn_decode_net_t& d = nets[n];
-        GNNPN_REQUIRE(d.embedded && d.enc_out && d.h0 && d.c0 && d.start && d.wih_packed && d.whh_packed && d.bih &&
-                          d.bhh, "pointer_decode: null input of net %d", n);
+        GNNPN_REQUIRE(d.enc_out && d.h0 && d.c0 && d.start && d.wih_packed && d.whh_packed && d.bih && d.bhh,
+                      "pointer_decode: null input of net %d", n);
+        GNNPN_REQUIRE(d.embedded || (d.emb_w && d.emb_b), "pointer_decode: net %d needs embedded or (emb_w, emb_b)", n);
         GNNPN_REQUIRE(d.idx && d.win_logits && d.pick_prob && d.actions, "pointer_decode: null output of net %d", n);
         GNNPN_REQUIRE(d.latent_from < n && d.latent_from >= -1, "pointer_decode: latent_from of net %d must name an "
                       "earlier net of the call", n);
         GNNPN_REQUIRE(!(d.latent_win && d.latent_from >= 0), "pointer_decode: net %d has two latent sources", n);
         GNNPN_REQUIRE(gnnpn_aligned(d.wih_packed, 16) && gnnpn_aligned(d.whh_packed, 16) &&
-                          gnnpn_aligned(d.enc_out, 16) && gnnpn_aligned(d.embedded, 16),
+                          gnnpn_aligned(d.enc_out, 16) && (!d.embedded || gnnpn_aligned(d.embedded, 16)),
                       "pointer_decode: weights / enc_out / embedded must be 16-byte aligned");
         static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "layout");
         memcpy(&args.net[n], &d, sizeof(DecodeNet));
@@ -201,6 +202,7 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     }
     for (int n = 0; n < n_nets; ++n) {   // streaming form: one net after the other (Low before High)
         const DecodeNet& d = args.net[n];
+        if (!d.embedded) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the streaming form needs the embedded tensor");
         const float* latent = d.latent_from >= 0 ? args.net[d.latent_from].win_logits : d.latent_win;
         if (H == 256)
             launch_decode<256>(d.embedded, d.enc_out, d.h0, d.c0, d.start, d.wih, d.whh, d.bih, d.bhh, latent, inputs,

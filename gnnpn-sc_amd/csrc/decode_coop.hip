@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     __shared__ float part[ROWS][KMAX][G];
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
+    __shared__ float xin[ROWS][8];
     __shared__ int abort_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,6 +110,14 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
         }
     }
 
+    // in-kernel embedding2 of the picked row (net.embedded == nullptr): column tid of emb_w
+    float ew[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, eb = 0.f;
+    if (!net.embedded) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ew[i] = net.emb_w[tid * 8 + i];
+        eb = net.emb_b[tid];
+    }
+
     const int n_tiles = (B + ROWS - 1) / ROWS;
     unsigned step = 0;   // publish counter: tag = step+1, parity = step&1
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
         for (int k = 0; k <= T; ++k) {
             float4 xg[4];
+            float xraw = 0.0f;
             if (k > 0) {
                 // ---- hand-off of publish #(step-1): h_{k-1}, partial dots, Low's window logits
                 const unsigned tag = step;
@@ -216,11 +226,16 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 }
                 if (k == T) break;
                 // x_k = embedded[idx_{k-1}] : in flight under the W_hh.h MFMAs
+                if (net.embedded) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = tid + 256 * j, row = f >> 6, q4 = f & 63, b = b0 + row;
-                    xg[j] = b < B ? *reinterpret_cast<const float4*>(net.embedded + ((int64_t)b * L + sel[row]) * H + q4 * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = tid + 256 * j, row = f >> 6, q4 = f & 63, b = b0 + row;
+                        xg[j] = b < B ? *reinterpret_cast<const float4*>(net.embedded + ((int64_t)b * L + sel[row]) * H + q4 * 4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else if (tid < ROWS * 8) {   // only the raw 8-feature row of the pick is fetched
+                    const int row = tid >> 3, b = b0 + row;
+                    xraw = b < B ? a.inputs[((int64_t)b * L + sel[row]) * 8 + (tid & 7)] : 0.0f;
                 }
             }
 
@@ -249,11 +264,25 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 }
             }
             if (k > 0) {
+                if (net.embedded) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = tid + 256 * j, row = f >> 6, q4 = f & 63;
-                    float* d = &xs[row * LDH + q4 * 4];
-                    d[0] = xg[j].x; d[1] = xg[j].y; d[2] = xg[j].z; d[3] = xg[j].w;
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = tid + 256 * j, row = f >> 6, q4 = f & 63;
+                        float* d = &xs[row * LDH + q4 * 4];
+                        d[0] = xg[j].x; d[1] = xg[j].y; d[2] = xg[j].z; d[3] = xg[j].w;
+                    }
+                } else {
+                    if (tid < ROWS * 8) xin[tid >> 3][tid & 7] = xraw;
+                    __syncthreads();
+                    // x[row][tid] = (sum_i inputs[row][i] * emb_w[tid][i], i ascending, from 0) + emb_b[tid]:
+                    // the k-ordered chain + bias of gnnpn_linear_f32 -> the same bits as the stored row
+#pragma unroll
+                    for (int row = 0; row < ROWS; ++row) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc = fmaf(xin[row][i], ew[i], acc);
+                        xs[row * LDH + tid] = __fadd_rn(acc, eb);
+                    }
                 }
                 __syncthreads();
             }

@@ -14,6 +14,8 @@ struct DecodeNet {
     const float* bih;
     const float* bhh;
     const float* latent_win;
+    const float* emb_w;
+    const float* emb_b;
     int32_t* idx;
     float* win_logits;
     float* pick_prob;

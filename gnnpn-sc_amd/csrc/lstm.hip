@@ -84,30 +84,39 @@ static int launch_encode(const LstmNets& nets, int n_nets, int32_t B, int32_t L,
     return 0;
 }
 
-extern "C" int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float* const* whh_packed,
-                                     const float* const* bhh, float* const* enc_out, float* const* h_n,
-                                     float* const* c_n, int32_t B, int32_t L, int32_t H, void* workspace,
-                                     int64_t workspace_bytes, void* stream) {
+extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, int32_t B, int32_t L, int32_t H,
+                                     int32_t F, void* workspace, int64_t workspace_bytes, void* stream) {
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
-    GNNPN_REQUIRE(pregates && whh_packed && bhh && enc_out && h_n && c_n, "lstm_encode: null pointer array");
+    GNNPN_REQUIRE(in, "lstm_encode: null net array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
     if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: hidden size %d not built (256, 32)", H);
     LstmNets nets{};
+    bool any_fold = false;
     for (int n = 0; n < n_nets; ++n) {
-        GNNPN_REQUIRE(pregates[n] && whh_packed[n] && bhh[n] && enc_out[n] && h_n[n] && c_n[n],
-                      "lstm_encode: null operand for net %d", n);
-        GNNPN_REQUIRE(gnnpn_aligned(whh_packed[n], 16), "lstm_encode: packed weights must be 16-byte aligned");
-        nets.pregates[n] = pregates[n];
-        nets.whh[n] = whh_packed[n];
-        nets.bhh[n] = bhh[n];
-        nets.enc_out[n] = enc_out[n];
-        nets.h_n[n] = h_n[n];
-        nets.c_n[n] = c_n[n];
+        const gnnpn_encode_net_t& e = in[n];
+        GNNPN_REQUIRE(e.whh_packed && e.bhh && e.enc_out && e.h_n && e.c_n, "lstm_encode: null operand for net %d", n);
+        GNNPN_REQUIRE(e.pregates || (e.inputs && e.w_in && e.b_in),
+                      "lstm_encode: net %d needs pregates or (inputs, w_in, b_in)", n);
+        GNNPN_REQUIRE(gnnpn_aligned(e.whh_packed, 16), "lstm_encode: packed weights must be 16-byte aligned");
+        any_fold |= (e.pregates == nullptr);
+        nets.pregates[n] = e.pregates;
+        nets.inputs[n] = e.inputs;
+        nets.w_in[n] = e.w_in;
+        nets.b_in[n] = e.b_in;
+        nets.whh[n] = e.whh_packed;
+        nets.bhh[n] = e.bhh;
+        nets.enc_out[n] = e.enc_out;
+        nets.h_n[n] = e.h_n;
+        nets.c_n[n] = e.c_n;
     }
+    if (any_fold) GNNPN_REQUIRE(F == 8, "lstm_encode: in-kernel input projection is built for F = 8, got %d", F);
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
     const int impl = gnnpn_option_lstm_impl();   // 0 auto, 1 per-workgroup streaming, 2 cooperative
-    if (H == 256 && impl != 1 && (workspace != nullptr || impl == 2)) {
+    const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl == 2);
+    if (!coop && any_fold)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the streaming form needs precomputed pregates");
+    if (coop) {
         const int rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, workspace, workspace_bytes, s);
         if (rc != GNNPN_OK) return rc;
     } else if (H == 256) {

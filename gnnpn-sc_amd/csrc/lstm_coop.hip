@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
     if (threadIdx.x == 0) abort_flag = 0;
 
     const float* __restrict__ pre = nets.pregates[net];
+    const float* __restrict__ xin = nets.inputs[net];     // used when pre == nullptr (F = 8)
     const float* __restrict__ Wp = nets.whh[net];
     float* __restrict__ enc = nets.enc_out[net];
     u64* xg = xchg + (size_t)group * (2 * ROWS * H);
@@ -95,11 +96,16 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
     int wrow[2];
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
-    float wB[2][64], bh[2];
+    float wB[2][64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = nets.bhh[net][wrow[tl]];
+        if (!pre) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
+            wX[tl][0] = nets.w_in[net][wrow[tl] * 8 + kq];
+            wX[tl][1] = nets.w_in[net][wrow[tl] * 8 + 4 + kq];
+            bx[tl] = nets.b_in[net][wrow[tl]];
+        }
 #pragma unroll
         for (int kk = 0; kk < 64; ++kk)   // packed layout: W[g*H+u][4kk+kq] = Wp[((kk*4+g)*H+u)*4+kq]
             wB[tl][kk] = Wp[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
@@ -113,14 +119,22 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
         float cst[4] = {0.f, 0.f, 0.f, 0.f};
         float hlast[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < L; ++t, ++step) {
-            // pre-gates of this step (consumed after the MFMAs: latency hidden)
+            // input side of this step (consumed after the MFMAs: latency hidden): either the
+            // stored pre-gates or the raw 8-feature rows as MFMA A-fragments (row c, k = 4*kk2 + kq)
             float pg[2][4];
+            float ax[2] = {0.f, 0.f};
+            if (pre) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = b0 + kq * 4 + r;
+                for (int r = 0; r < 4; ++r) {
+                    const int b = b0 + kq * 4 + r;
 #pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-                    pg[tl][r] = b < B ? pre[((int64_t)b * L + t) * (4 * H) + wrow[tl]] : 0.0f;
+                    for (int tl = 0; tl < 2; ++tl)
+                        pg[tl][r] = b < B ? pre[((int64_t)b * L + t) * (4 * H) + wrow[tl]] : 0.0f;
+                }
+            } else if (b0 + c < B) {
+                const float* row = xin + ((int64_t)(b0 + c) * L + t) * 8;
+                ax[0] = row[kq];
+                ax[1] = row[4 + kq];
             }
             // h_{t-1}: zeros at t == 0, else the peers' published slices.  At a tile switch the
             // sweep still runs (values dropped): it proves every peer is done with the buffer
@@ -145,6 +159,18 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
                 for (int kk = 0; kk < 64; ++kk) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[0][kk], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[1][kk], acc1, 0, 0, 0);
+                }
+            }
+            if (!pre) {   // x_t . w_in^T as its own k-ordered chain, then + b_in (as gnnpn_linear_f32 would)
+                f32x4 px0 = {0.f, 0.f, 0.f, 0.f}, px1 = {0.f, 0.f, 0.f, 0.f};
+                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[0][0], px0, 0, 0, 0);
+                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[1][0], px1, 0, 0, 0);
+                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[0][1], px0, 0, 0, 0);
+                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[1][1], px1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pg[0][r] = __fadd_rn(px0[r], bx[0]);
+                    pg[1][r] = __fadd_rn(px1[r], bx[1]);
                 }
             }
             __syncthreads();   // everyone is done reading hs before the next step's sweep rewrites it

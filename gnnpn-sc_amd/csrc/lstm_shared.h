@@ -5,7 +5,10 @@
 #define GNNPN_MAX_NETS 4
 
 struct LstmNets {
-    const float* pregates[GNNPN_MAX_NETS];
+    const float* pregates[GNNPN_MAX_NETS];   // or nullptr: input projection in-kernel from the three below
+    const float* inputs[GNNPN_MAX_NETS];
+    const float* w_in[GNNPN_MAX_NETS];
+    const float* b_in[GNNPN_MAX_NETS];
     const float* whh[GNNPN_MAX_NETS];
     const float* bhh[GNNPN_MAX_NETS];
     float* enc_out[GNNPN_MAX_NETS];

@@ -18,6 +18,13 @@ from torch import nn
 
 from . import ops
 
+# Fold embedding2 (modelPN.py:190) and the encoder LSTM's input projection into ONE [4H, 8] matrix
+# evaluated inside the recurrent kernel (W_ih.(W_e x + b_e) + b_ih = (W_ih W_e) x + (W_ih b_e + b_ih)):
+# an exact algebraic identity that removes the [B*L,256]x[256,1024] GEMM and the 246 MB pre-gate
+# round trip per net.  It rounds differently from the reference's two-stage evaluation (by about the
+# reference's own rounding error); set False for the literal two-stage order.
+FOLD_INPUT_PROJECTION = True
+
 qosandcons = 8   # modelPN.py:10
 qosNum = 4       # modelPN.py:11
 consNum = 2      # modelPN.py:12
@@ -111,38 +118,47 @@ class PointerNet(nn.Module):
                 "dec_whh": ops.pack_lstm_weight(f(self.decoder.weight_hh_l0)), "dec_bhh": f(self.decoder.bias_hh_l0),
                 "start": f(self.decoder_start_input),
             }
+            # folded input projection, formed in fp64 on the host and rounded once
+            w_ih, w_e = self.encoder.weight_ih_l0.detach().double().cpu(), self.embedding2.weight.detach().double().cpu()
+            b = w_ih @ self.embedding2.bias.detach().double().cpu() + self.encoder.bias_ih_l0.detach().double().cpu()
+            dev = self.embedding2.weight.device
+            self._packed["enc_wfold"] = (w_ih @ w_e).float().contiguous().to(dev)
+            self._packed["enc_bfold"] = b.float().contiguous().to(dev)
         return self._packed
 
-    def embed(self, inputs):
-        """embedding2 (:190) and the encoder's input projection x_t.W_ih^T + b_ih (inside :191)."""
+    def encode_args(self, inputs, fold=None):
+        """One entry of the ``nets`` list of ops.lstm_encode (+ the embedded tensor when the literal
+        two-stage order is asked for: embedding2 (:190), then x_t.W_ih^T + b_ih (inside :191))."""
         B, L, F = inputs.shape
         assert L == self.seq_len                                                        # :182
         w = self.packed()
+        fold = FOLD_INPUT_PROJECTION if fold is None else fold
+        if fold:
+            return {"inputs": inputs, "w_in": w["enc_wfold"], "b_in": w["enc_bfold"], "whh": w["enc_whh"],
+                    "bhh": w["enc_bhh"]}, None
         embedded = ops.linear(inputs.reshape(B * L, F), w["emb_w"], w["emb_b"])
         pregates = ops.linear(embedded, w["enc_wih"], w["enc_bih"])
         H = self.hidden_size
-        return embedded.view(B, L, H), pregates.view(B, L, 4 * H)
+        return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
+            embedded.view(B, L, H)
 
     def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1):
-        """One entry of the ``nets`` list of ops.pointer_decode."""
+        """One entry of the ``nets`` list of ops.pointer_decode (embedded=None: picks are embedded
+        in-kernel from the raw rows)."""
         w = self.packed()
-        return {"embedded": embedded, "enc_out": enc_out, "h0": h_n, "c0": c_n, "start": w["start"],
-                "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"], "bhh": w["dec_bhh"],
-                "latent_win": latent_win, "latent_from": latent_from}
-
-    def decode(self, inputs, embedded, enc_out, h_n, c_n, latent_win, want_queries=False):
-        return ops.pointer_decode([self.decode_args(embedded, enc_out, h_n, c_n, latent_win)], inputs,
-                                  self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
+        return {"embedded": embedded, "emb_w": w["emb_w"], "emb_b": w["emb_b"], "enc_out": enc_out, "h0": h_n,
+                "c0": c_n, "start": w["start"], "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"],
+                "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from}
 
     @torch.no_grad()
-    def run(self, inputs, latent=None, want_queries=False):
+    def run(self, inputs, latent=None, want_queries=False, fold=None):
         """Encode + greedy decode; returns the decode dict of ops.pointer_decode plus enc_out."""
         inputs = inputs.contiguous()
-        embedded, pregates = self.embed(inputs)
-        w = self.packed()
-        enc, h_n, c_n = ops.lstm_encode([pregates], [w["enc_whh"]], [w["enc_bhh"]])
-        out = self.decode(inputs, embedded, enc[0], h_n[0], c_n[0],
-                          _window_tensor(latent, self.serCategory, self.serNumber), want_queries)
+        enc_args, embedded = self.encode_args(inputs, fold)
+        enc, h_n, c_n = ops.lstm_encode([enc_args])
+        out = ops.pointer_decode(
+            [self.decode_args(embedded, enc[0], h_n[0], c_n[0], _window_tensor(latent, self.serCategory, self.serNumber))],
+            inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
         out["enc_out"] = enc[0]
         return out
 
@@ -240,7 +256,7 @@ class CombinatorialRL(nn.Module):
 
 
 @torch.no_grad()
-def two_level_greedy(low, high, inputs):
+def two_level_greedy(low, high, inputs, fold=None):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
@@ -248,11 +264,10 @@ def two_level_greedy(low, high, inputs):
     win_high_raw + win_low (modelPN.py:216)."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
-    emb_l, pre_l = la.embed(inputs)
-    emb_h, pre_h = ha.embed(inputs)
-    wl, wh = la.packed(), ha.packed()
-    enc, h_n, c_n = ops.lstm_encode([pre_l, pre_h], [wl["enc_whh"], wh["enc_whh"]], [wl["enc_bhh"], wh["enc_bhh"]])
-    del pre_l, pre_h
+    enc_l, emb_l = la.encode_args(inputs, fold)
+    enc_h, emb_h = ha.encode_args(inputs, fold)
+    enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h])
+    del enc_l, enc_h
     dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0]),
                                  ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0)],
                                 inputs, la.serCategory, la.serNumber, la.C, la.use_tanh)

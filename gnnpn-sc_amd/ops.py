@@ -117,11 +117,13 @@ def pack_lstm_weight(w):
 
 
 _workspaces = {}
+_options = {}
 
 
 def set_option(name, value):
     """Run-time A/B switches of the library (gnnpn_set_option), e.g. ("lstm_impl", 1)."""
     check(_lib.load().gnnpn_set_option(name.encode(), int(value)), "gnnpn_set_option")
+    _options[name] = int(value)
 
 
 def encode_workspace(device):
@@ -146,22 +148,51 @@ def check_status(device):
                              "timed out (outputs invalid)")
 
 
-def lstm_encode(pregates, whh_packed, bhh):
-    """Run the encoder recurrence of len(pregates) nets in ONE launch.
-    pregates[n] [B,L,4H] -> (enc_out[n] [B,L,H], h_n[n] [B,H], c_n[n] [B,H])."""
-    n = len(pregates)
-    B, L, H4 = pregates[0].shape
-    H = H4 // 4
-    dev = pregates[0].device
-    enc = [torch.empty((B, L, H), dtype=F32, device=dev) for _ in range(n)]
-    h_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
-    c_n = [torch.empty((B, H), dtype=F32, device=dev) for _ in range(n)]
-    ws = encode_workspace(dev) if H == 256 else None
-    check(_lib.load().gnnpn_lstm_encode_f32(
-        n, ptr_array(pregates, F32, "pregates"), ptr_array(whh_packed, F32, "whh"), ptr_array(bhh, F32, "bhh"),
-        ptr_array(enc, F32, "enc_out"), ptr_array(h_n, F32, "h_n"), ptr_array(c_n, F32, "c_n"), B, L, H,
-        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
-        "gnnpn_lstm_encode_f32")
+def coop_supported(H, n_per=1, option=None):
+    """Shapes the cooperative recurrent kernels are built for (else: per-workgroup streaming);
+    ``option`` names the A/B switch that can force the streaming form."""
+    return H == 256 and n_per <= 16 and _options.get(option, 0) != 1
+
+
+def lstm_encode(nets):
+    """Run the encoder recurrence of len(nets) nets in ONE launch (gnnpn_lstm_encode_f32).
+
+    nets: list of dicts with whh (packed), bhh and EITHER pregates [B,L,4H] OR inputs [B,L,8] +
+    w_in [4H,8] + b_in [4H] (input projection evaluated inside the cooperative kernel; for shapes
+    without a cooperative kernel the projection is materialised first with gnnpn_linear_f32 —
+    the same k-ordered fma chain + bias, so the same bits).
+    -> (enc_out list [B,L,H], h_n list [B,H], c_n list [B,H])."""
+    n = len(nets)
+    H = nets[0]["bhh"].numel() // 4
+    first = nets[0]["pregates"] if nets[0].get("pregates") is not None else nets[0]["inputs"]
+    B, L = first.shape[0], first.shape[1]
+    dev = first.device
+    coop = coop_supported(H, option="lstm_impl")
+    arr = (_lib.EncodeNet * n)()
+    enc, h_n, c_n, keep = [], [], [], []
+    for i, d in enumerate(nets):
+        pre = d.get("pregates")
+        if pre is None and not coop:
+            x = d["inputs"]
+            pre = linear(x.reshape(B * L, x.shape[2]), d["w_in"], d["b_in"]).view(B, L, 4 * H)
+            keep.append(pre)
+        e = torch.empty((B, L, H), dtype=F32, device=dev)
+        hn = torch.empty((B, H), dtype=F32, device=dev)
+        cn = torch.empty((B, H), dtype=F32, device=dev)
+        enc.append(e), h_n.append(hn), c_n.append(cn)
+        a = arr[i]
+        a.pregates = None if pre is None else dev_ptr(pre, F32, f"nets[{i}].pregates").value
+        if pre is None:
+            a.inputs = dev_ptr(d["inputs"], F32, f"nets[{i}].inputs").value
+            a.w_in = dev_ptr(d["w_in"], F32, f"nets[{i}].w_in").value
+            a.b_in = dev_ptr(d["b_in"], F32, f"nets[{i}].b_in").value
+        a.whh_packed = dev_ptr(d["whh"], F32, f"nets[{i}].whh").value
+        a.bhh = dev_ptr(d["bhh"], F32, f"nets[{i}].bhh").value
+        a.enc_out, a.h_n, a.c_n = (dev_ptr(t, F32, "out").value for t in (e, hn, cn))
+    ws = encode_workspace(dev) if coop else None
+    check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, dev_ptr(ws, torch.uint8, "workspace", True),
+                                            0 if ws is None else ws.numel(), stream_ptr()),
+          "gnnpn_lstm_encode_f32")
     return enc, h_n, c_n
 
 
@@ -179,8 +210,9 @@ def decode_workspace(device, B, T, n_per):
 def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False):
     """Greedy decode of 1 or 2 pointer networks in ONE call (gnnpn_pointer_decode_f32).
 
-    nets: list of dicts with keys embedded, enc_out, h0, c0, start, wih, whh, bih, bhh and optionally
-    latent_win ([B,T,K] tensor computed earlier) or latent_from (index of an earlier net of this call).
+    nets: list of dicts with keys enc_out, h0, c0, start, wih, whh, bih, bhh, EITHER embedded [B,L,H]
+    OR emb_w [H,8] + emb_b [H] (picked rows embedded in-kernel), and optionally latent_win ([B,T,K]
+    tensor computed earlier) or latent_from (index of an earlier net of this call).
     Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
     queries [B,T,H] | None."""
     B, L, H = nets[0]["enc_out"].shape
@@ -197,10 +229,17 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
                "queries": torch.empty((B, n_cat, H), dtype=F32, device=dev) if want_queries else None}
         outs.append(out)
         a = arr[i]
-        for name, key in (("embedded", "embedded"), ("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"),
-                          ("start", "start"), ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"),
-                          ("bhh", "bhh")):
+        for name, key in (("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"), ("start", "start"),
+                          ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"), ("bhh", "bhh")):
             setattr(a, name, dev_ptr(d[key], F32, f"nets[{i}].{key}").value)
+        emb = d.get("embedded")
+        if emb is None and not coop_supported(H, n_per, "decode_impl"):   # no in-kernel embedding there
+            emb = linear(inputs.reshape(B * L, inputs.shape[2]), d["emb_w"], d["emb_b"]).view(B, L, H)
+            outs[-1]["_embedded"] = emb
+        a.embedded = None if emb is None else dev_ptr(emb, F32, f"nets[{i}].embedded").value
+        if emb is None:
+            a.emb_w = dev_ptr(d["emb_w"], F32, f"nets[{i}].emb_w").value
+            a.emb_b = dev_ptr(d["emb_b"], F32, f"nets[{i}].emb_b").value
         lw = d.get("latent_win")
         a.latent_win = None if lw is None else dev_ptr(lw, F32, f"nets[{i}].latent_win").value
         a.latent_from = int(d.get("latent_from", -1))
@@ -209,7 +248,7 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value
         a.actions = dev_ptr(out["actions"], F32, "actions").value
         a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
-    ws = decode_workspace(dev, B, n_cat, n_per) if (H == 256 and n_per <= 16) else None
+    ws = decode_workspace(dev, B, n_cat, n_per) if coop_supported(H, n_per, "decode_impl") else None
     check(_lib.load().gnnpn_pointer_decode_f32(
         len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
         dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),

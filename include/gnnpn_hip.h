@@ -117,20 +117,34 @@ int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, in
 
 /* ---------------------------------------------------------------------------------------------
  * Pointer-network LSTM encoder recurrence for `n_nets` independent nets in one launch
- * (Low and High encoders are independent given the inputs).
- *   pregates[n]  [B, L, 4H] fp32 = x_t . W_ih^T + b_ih (gate order i,f,g,o)
- *   whh_packed[n][k/4][gate][j][4] fp32  = W_hh[gate*H + j][k..k+3]   (gnnpn packing, see .py)
- *   bhh[n]       [4H]
- *   enc_out[n]   [B, L, H];  h_n[n], c_n[n]  [B, H]
- * H must be 256 or 32 (the configurations of environment.ini:55 and of the unit fixtures).
- * Pointer arrays are HOST arrays of device pointers.
+ * (Low and High encoders are independent given the inputs).  Per net (gnnpn_encode_net_t):
+ *   input side, ONE of
+ *     pregates [B, L, 4H] fp32 = x_t . W_ih^T + b_ih (gate order i,f,g,o) computed beforehand, or
+ *     inputs [B, L, F] raw rows + w_in [4H, F] + b_in [4H]: the input projection is evaluated inside
+ *     the kernel as inputs_t . w_in^T + b_in (F must be 8).  With w_in = W_ih . W_emb and
+ *     b_in = W_ih . b_emb + b_ih this folds embedding2 (modelPN.py:190) and the LSTM's input
+ *     projection into one [4H, 8] matrix — an exact algebraic identity, rounded differently
+ *     (DESIGN.md §5); only the cooperative form evaluates it in-kernel.
+ *   whh_packed [H/4][gate][j][4] fp32  = W_hh[gate*H + j][k..k+3]   (ops.pack_lstm_weight)
+ *   bhh [4H];   outputs enc_out [B, L, H], h_n / c_n [B, H]
+ * H must be 256 or 32 (environment.ini:55 and the unit fixtures).  `nets` is a HOST array.
  * Two implementations with bit-identical results: cooperative (H = 256 and a workspace given:
  * groups of 8 workgroups keep W_hh in registers and exchange h every step) and streaming.
  * Replaces: nn.LSTM encoder at src/models/modelPN.py:157,191. */
-int gnnpn_lstm_encode_f32(int n_nets, const float* const* pregates, const float* const* whh_packed,
-                          const float* const* bhh, float* const* enc_out, float* const* h_n,
-                          float* const* c_n, int32_t B, int32_t L, int32_t H, void* workspace,
-                          int64_t workspace_bytes, void* stream);
+typedef struct {
+    const float* pregates;
+    const float* inputs;
+    const float* w_in;
+    const float* b_in;
+    const float* whh_packed;
+    const float* bhh;
+    float* enc_out;
+    float* h_n;
+    float* c_n;
+} gnnpn_encode_net_t;
+
+int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B, int32_t L, int32_t H,
+                          int32_t F, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Size of the device workspace the cooperative encoder needs (status words + hand-off buffers).
  * With workspace == NULL gnnpn_lstm_encode_f32 uses the per-workgroup streaming form instead.
@@ -146,7 +160,10 @@ int gnnpn_set_option(const char* name, int value);
  * dot-attention logits over the step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent
  * window (High net); softmax; first-max argmax; next input = embedded row of the pick}.
  * Per net (gnnpn_decode_net_t, all device pointers):
- *   embedded [B,L,H]  enc_out [B,L,H]  h0,c0 [B,H]  start [H]
+ *   embedded [B,L,H] (decoder inputs = rows of it), or NULL with emb_w [H,8] / emb_b [H]: the picked
+ *            row is then computed in-kernel as inputs[pick] . emb_w^T + emb_b (same k-ordered fma
+ *            chain + bias as gnnpn_linear_f32, so bit-identical to the stored row; cooperative form)
+ *   enc_out [B,L,H]  h0,c0 [B,H]  start [H]
  *   wih_packed / whh_packed / bih / bhh : decoder LSTM (packed as for the encoder)
  *   latent_win  [B,T,n_per] or NULL : window logits of a Low net computed EARLIER, added before the
  *               argmax;   latent_from : index (< own index) of a net of THIS call whose window
@@ -172,6 +189,8 @@ typedef struct {
     const float* bih;
     const float* bhh;
     const float* latent_win;
+    const float* emb_w;
+    const float* emb_b;
     int32_t* idx;
     float* win_logits;
     float* pick_prob;

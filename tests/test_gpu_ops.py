@@ -145,7 +145,8 @@ def test_lstm_encode_vs_torch(dev, H, B, L):
     w_ih, b_ih = sd["actor.encoder.weight_ih_l0"], sd["actor.encoder.bias_ih_l0"]
     pre = ops.linear(x.view(B * L, H).to(dev), w_ih.to(dev), b_ih.to(dev)).view(B, L, 4 * H)
     whh = ops.pack_lstm_weight(sd["actor.encoder.weight_hh_l0"]).to(dev)
-    enc, h_n, c_n = ops.lstm_encode([pre, pre], [whh, whh], [sd["actor.encoder.bias_hh_l0"].to(dev)] * 2)
+    net = {"pregates": pre, "whh": whh, "bhh": sd["actor.encoder.bias_hh_l0"].to(dev)}
+    enc, h_n, c_n = ops.lstm_encode([net, dict(net)])
     for n in range(2):
         assert float((enc[n].cpu() - ref_out).abs().max()) < 2e-5
         assert float((h_n[n].cpu() - ref_h[0]).abs().max()) < 2e-5
@@ -164,18 +165,38 @@ def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
     pre = [(torch.randn(B, L, 4 * H, generator=g) * 0.7).to(dev) for _ in range(nets)]
     whh = [ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
     bhh = [((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
+    args = [{"pregates": pre[n], "whh": whh[n], "bhh": bhh[n]} for n in range(nets)]
     try:
         ops.set_option("lstm_impl", 1)
-        ref = ops.lstm_encode(pre, whh, bhh)
+        ref = ops.lstm_encode(args)
         ops.set_option("lstm_impl", 2)
-        out = ops.lstm_encode(pre, whh, bhh)
-        out2 = ops.lstm_encode(pre, whh, bhh)       # back-to-back launches reuse the hand-off buffers
+        out = ops.lstm_encode(args)
+        out2 = ops.lstm_encode(args)       # back-to-back launches reuse the hand-off buffers
     finally:
         ops.set_option("lstm_impl", 0)
     ops.check_status(dev)
     for n in range(nets):
         for a, b, c in zip(ref, out, out2):
             assert torch.equal(a[n], b[n]) and torch.equal(a[n], c[n])
+
+
+def test_in_kernel_input_projection_equals_materialised(dev):
+    """inputs . w_in^T + b_in evaluated inside the cooperative encoder is the same k-ordered fma chain
+    + bias that gnnpn_linear_f32 materialises: bit-identical encoder outputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    B, L, H = 50, 33, 256
+    x = torch.rand(B, L, 8, generator=g).to(dev)
+    w_in = ((torch.rand(4 * H, 8, generator=g) * 2 - 1) * 0.3).to(dev)
+    b_in = ((torch.rand(4 * H, generator=g) * 2 - 1) * 0.3).to(dev)
+    whh = ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev)
+    bhh = ((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev)
+    pre = ops.linear(x.view(B * L, 8), w_in, b_in).view(B, L, 4 * H)
+    a = ops.lstm_encode([{"pregates": pre, "whh": whh, "bhh": bhh}])
+    b = ops.lstm_encode([{"inputs": x, "w_in": w_in, "b_in": b_in, "whh": whh, "bhh": bhh}])
+    ops.check_status(dev)
+    for u, v in zip(a, b):
+        assert torch.equal(u[0], v[0])
 
 
 def test_qos_reward_golden(dev):

@@ -154,3 +154,23 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     assert float((out["win_high_raw"][s] - ref["win_high_raw"][s]).abs().max()) < 1e-4
     assert float((out["R"][s] - ref["R"][s]).abs().max()) <= R_ATOL
     assert float((out["action_probs"][s] - ref["action_probs"][s]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["qws", "normal"])
+def test_folded_vs_two_stage_input_projection(dev, name):
+    """FOLD_INPUT_PROJECTION (W_ih.W_e as one [4H,8] matrix, evaluated in-kernel) against the literal
+    two-stage order of the reference (embedding2, then W_ih): same picks on robust problems, logits
+    within the usual tolerance, and both within tolerance of the golden vectors."""
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    fx = golden(f"pn_{name}.npz")
+    low, high = build(fx, dev)
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    a = two_level_greedy(low, high, x, fold=True)
+    b = two_level_greedy(low, high, x, fold=False)
+    robust = robust_problems(fx["margin_low"], fx["margin_high"])
+    for out, tag in ((a, "fold"), (b, "two-stage")):
+        s = assert_index_parity(out["idx_high"], fx["idx_high"], robust, f"{name}/{tag}", 0.7, fx["inputs"]).numpy() & \
+            assert_index_parity(out["idx_low"], fx["idx_low"], robust, f"{name}/{tag}", 0.7, fx["inputs"]).numpy()
+        assert np.abs(out["win_low"].cpu().numpy()[s] - fx["win_low"][s]).max() < LOGIT_ATOL
+    same = ((a["idx_low"] == b["idx_low"]).all(1) & (a["idx_high"] == b["idx_high"]).all(1))
+    assert float((a["win_low"][same] - b["win_low"][same]).abs().max()) < LOGIT_ATOL
