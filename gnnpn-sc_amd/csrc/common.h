@@ -62,6 +62,47 @@ __device__ __forceinline__ unsigned float_order_key(float f) {
 // library, IEEE division; no fast-math.
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- activations of the LSTM cells ---------------------------------------------------------------
+// The recurrent kernels run one wave per SIMD, so every VALU instruction of the cell update is on
+// the per-step critical path (the device-library expf/tanhf sequences cost ~1 us of a 5.6 us step).
+// These forms use the hardware v_exp_f32 / v_rcp_f32 (1 ulp each) with the argument product carried
+// in two parts and one Newton step on the reciprocal: |error| <= ~1.5e-7 absolute, i.e. the rounding
+// of the result itself (tests/test_gpu_ops.py::test_cell_activations measures it against torch CPU).
+// ALL recurrent kernels (streaming and cooperative, encoder and decoder) use exactly these, which
+// is what keeps the implementations bit-identical to each other.
+__device__ __forceinline__ float cell_exp(float x) {        // e^x for x in [-87, 87]
+    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596303e-08f;
+    const float t = __fmul_rn(x, L2E_HI);
+    float r = fmaf(x, L2E_HI, -t);                           // exact low part of the product
+    r = fmaf(x, L2E_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);               // v_exp_f32
+    return fmaf(e, __fmul_rn(r, 0.693147182f), e);           // e * 2^r
+}
+__device__ __forceinline__ float cell_rcp(float d) {        // 1/d, d finite and >= 1
+    const float r = __builtin_amdgcn_rcpf(d);                // v_rcp_f32
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+// One activation, branch-free in `is_tanh` (per-lane selectable): the sigmoid and the tanh share the
+// exp/reciprocal core, the tanh-only parts (odd polynomial below |x| = 0.25, 1 - 2r, sign) are a few
+// extra VALU instructions selected by v_cndmask — no divergent branch when half a wave wants tanh
+// and the other half sigmoid (the [g | o] MFMA tile of the cooperative kernels).
+__device__ __forceinline__ float cell_act(float x, bool is_tanh) {
+    const float ax = fminf(fabsf(x), 43.0f);
+    const float u = is_tanh ? __fmul_rn(2.0f, ax) : fminf(fmaxf(-x, -87.0f), 87.0f);
+    const float r = cell_rcp(__fadd_rn(1.0f, cell_exp(u)));   // sigmoid(x), or 1/(e^{2|x|}+1)
+    // tanh: |x| >= 0.25: 1 - 2/(e^{2|x|}+1);  below: odd Taylor polynomial (truncation < 3e-9 relative)
+    const float big = __fsub_rn(1.0f, __fmul_rn(2.0f, r));
+    const float x2 = __fmul_rn(ax, ax);
+    float p = fmaf(x2, 2.18694885e-02f, -5.39682540e-02f);   // 62/2835, -17/315
+    p = fmaf(x2, p, 1.33333333e-01f);                        // 2/15
+    p = fmaf(x2, p, -3.33333333e-01f);                       // -1/3
+    const float small = fmaf(__fmul_rn(ax, x2), p, ax);
+    const float th = copysignf(ax < 0.25f ? small : big, x);
+    return is_tanh ? th : r;
+}
+__device__ __forceinline__ float cell_sigmoid(float x) { return cell_act(x, false); }
+__device__ __forceinline__ float cell_tanh(float x) { return cell_act(x, true); }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == GNNPN_ACT_RELU) return v < 0.0f ? 0.0f : v;   // NaN stays NaN, as torch.relu
     if (act == GNNPN_ACT_SIGMOID) return sigmoid_f32(v);

@@ -1,0 +1,70 @@
+// Helpers shared by the cooperative recurrent kernels (lstm_coop.hip, decode_coop.hip).
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+// ---- granule hand-off (CDNA4 guide, Guideline 16 / R2): 8-byte {tag, value}, ONE sc1 store / load
+__device__ __forceinline__ u64 granule_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dwordx2 sc1
+}
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
+}
+
+// value of lane (l ^ 8) within each row of 16 lanes, as a DPP row rotate (no LDS round trip)
+__device__ __forceinline__ float swap8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+}
+
+// Diagnostic stamps (diagnostic option only; never in a measured run)
+__device__ __forceinline__ u64 phase_stamp() {
+    u64 t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// Two k-ordered fp32 MFMA chains (one per 16-column tile) over K = 256 against A-fragments read from
+// an LDS tile `src` (row c, stride LDH, element 4*kk + kq).  The A-fragments are fetched 16 k-steps
+// ahead of the MFMAs that use them: left to itself hipcc issues each ds_read right before the MFMAs
+// that need it and waits ~70 cycles per 4 MFMAs (measured 6.3k instead of 4.1k cycles per step).
+template <int LDH>
+__device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq, const float (&w0)[64],
+                                                const float (&w1)[64], f32x4& acc0, f32x4& acc1) {
+    const float* base = src + c * LDH + kq;
+    float a[2][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[0][i] = base[4 * i];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        if (ch < 3) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[(ch + 1) & 1][i] = base[4 * (16 * (ch + 1) + i)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w0[16 * ch + i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w1[16 * ch + i], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LSTM cell update for the [i | f] / [g | o] tile pair: lanes c < 8 hold (i, g), lanes c >= 8 hold
+// (f, o) of the same hidden unit; one DPP swap per value, then both halves update (c, h) alike.
+// Same arithmetic as lstm_cell_update (recurrent.h): cy = f*c + i*g ; hy = o*tanh(cy), products and
+// sum rounded separately.
+__device__ __forceinline__ void cell_update_pair(float g0, float g1, bool lo_half, float& cst, float& h) {
+    const float a0 = cell_act(g0, false);            // sigmoid(i) | sigmoid(f)
+    const float a1 = cell_act(g1, lo_half);          // tanh(g)    | sigmoid(o)
+    const float p0 = swap8(a0), p1 = swap8(a1);
+    const float ig = lo_half ? a0 : p0, gg = lo_half ? a1 : p1;
+    const float fg = lo_half ? p0 : a0, og = lo_half ? p1 : a1;
+    cst = __fadd_rn(__fmul_rn(fg, cst), __fmul_rn(ig, gg));
+    h = __fmul_rn(og, cell_act(cst, true));
+}

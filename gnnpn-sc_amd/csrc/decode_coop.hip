@@ -21,9 +21,7 @@
 #include "common.h"
 #include "recurrent.h"
 #include "decode_shared.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
+#include "coop_common.h"
 
 namespace {
 constexpr int H = 256;
@@ -34,33 +32,6 @@ constexpr int LDH = 258;
 constexpr int KMAX = 16;          // candidates per category the cooperative form is built for
 constexpr unsigned SPIN_LIMIT = 400000;
 }  // namespace
-
-__device__ __forceinline__ u64 g_load(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void g_store(u64* p, unsigned tag, float v) {
-    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// poll `n` (<= 64*NP) granules p[idx(q)] until all carry `tag`; lane q-th value -> v[]
-template <int NP, typename IdxFn>
-__device__ __forceinline__ bool sweep_small(const u64* p, unsigned tag, int n, int lane, IdxFn idx, unsigned (&v)[NP]) {
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int q = lane + 64 * j;
-            if (q < n) {
-                const u64 x = g_load(p + idx(q));
-                v[j] = (unsigned)x;
-                ok &= (unsigned)(x >> 32) == tag;
-            }
-        }
-        if (__all(ok)) return true;
-        if (spins > SPIN_LIMIT) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 
 __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
@@ -140,71 +111,106 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
             float4 xg[4];
             float xraw = 0.0f;
             if (k > 0) {
-                // ---- hand-off of publish #(step-1): h_{k-1}, partial dots, Low's window logits
+                // ---- hand-off of publish #(step-1): h_{k-1}, partial dots, Low's window logits — ONE
+                // combined sweep (all loads issued, then all tags checked): one round trip, not three
                 const unsigned tag = step;
                 const int par = (step - 1) & 1;
-                bool ok;
+                const bool has_lat = latent_in_launch || net.latent_win;
                 {
-                    const u64* src = xh_g + par * (ROWS * H) + wave * 4 * H;
-                    unsigned v[16];
-                    ok = sweep_small<16>(src, tag, 1024, lane, [](int q) { return q; }, v);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int i = j * 64 + lane;
-                        hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
-                    }
-                }
-                if (ok) {
-                    const u64* src = xp_g + par * (G * ROWS * K);
-                    const int n = G * 4 * K;   // this wave's rows 4w..4w+3 from all members
-                    unsigned v[8];
-                    auto at = [&](int q) { const int m = q / (4 * K), rem = q - m * 4 * K;
-                                           return (m * ROWS + wave * 4 + rem / K) * K + rem % K; };
-                    ok = sweep_small<8>(src, tag, n, lane, at, v);
+                    const u64* src_h = xh_g + par * (ROWS * H) + wave * 4 * H;
+                    const u64* src_p = xp_g + par * (G * ROWS * K);
+                    const u64* src_l = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
+                    const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all members
+                    const int n_l = 4 * K;
+                    int p_at[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int q = lane + 64 * j;
-                        if (q < n) {
+                        const int m = q / (4 * K), rem = q - m * 4 * K;
+                        p_at[j] = (m * ROWS + wave * 4 + rem / K) * K + rem % K;
+                    }
+                    unsigned vh[16], vp[8], vl = 0;
+                    bool ok = false;
+                    for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
+                        bool good = true;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const u64 x = granule_load(src_h + j * 64 + lane);
+                            vh[j] = (unsigned)x;
+                            good &= (unsigned)(x >> 32) == tag;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (lane + 64 * j < n_p) {
+                                const u64 x = granule_load(src_p + p_at[j]);
+                                vp[j] = (unsigned)x;
+                                good &= (unsigned)(x >> 32) == tag;
+                            }
+                        }
+                        if (latent_in_launch && lane < n_l) {
+                            const u64 x = granule_load(src_l + lane);
+                            vl = (unsigned)x;
+                            good &= (unsigned)(x >> 32) == 1u;
+                        }
+                        if (__all(good)) {
+                            ok = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ok) abort_flag = 1;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int i = j * 64 + lane;
+                        hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = lane + 64 * j;
+                        if (q < n_p) {
                             const int m = q / (4 * K), rem = q - m * 4 * K;
-                            part[wave * 4 + rem / K][rem % K][m] = __uint_as_float(v[j]);
+                            part[wave * 4 + rem / K][rem % K][m] = __uint_as_float(vp[j]);
                         }
                     }
-                }
-                if (ok && (latent_in_launch || net.latent_win)) {
-                    const int n = 4 * K;
-                    if (latent_in_launch) {
-                        const u64* src = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
-                        unsigned v[1];
-                        ok = sweep_small<1>(src, 1u, n, lane, [](int q) { return q; }, v);
-                        if (lane < n) lat[wave * 4 + lane / K][lane % K] = __uint_as_float(v[0]);
-                    } else if (lane < n) {
-                        const int b = b0 + wave * 4 + lane / K;
-                        lat[wave * 4 + lane / K][lane % K] =
-                            b < B ? net.latent_win[((int64_t)b * T + (k - 1)) * K + lane % K] : 0.0f;
+                    if (lane < n_l) {
+                        float lv = 0.0f;
+                        if (latent_in_launch) {
+                            lv = __uint_as_float(vl);
+                        } else if (net.latent_win) {
+                            const int b = b0 + wave * 4 + lane / K;
+                            lv = b < B ? net.latent_win[((int64_t)b * T + (k - 1)) * K + lane % K] : 0.0f;
+                        }
+                        lat[wave * 4 + lane / K][lane % K] = lv;
                     }
                 }
-                if (!ok) abort_flag = 1;
                 __syncthreads();
                 if (abort_flag) break;
 
-                // ---- logits, C*tanh, latent bias, softmax, first-max argmax: one thread per row
+                // ---- logits: one thread per (row, candidate): sum of the 8 partial dots in member
+                // order, C*tanh (device-library tanhf: these values decide the pick), + latent
+                if (tid < ROWS * K) {
+                    const int row = tid / K, r = tid - row * K, b = b0 + row;
+                    float dot = part[row][r][0];
+#pragma unroll
+                    for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part[row][r][m]);
+                    float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;
+                    if (member == 0) {
+                        if (b < B) net.win_logits[((int64_t)b * T + (k - 1)) * K + r] = v;
+                        if (publishes_latent)
+                            granule_store(xl + (((size_t)tile * T + (k - 1)) * ROWS + row) * K + r, 1u, v);
+                    }
+                    if (has_lat) v = __fadd_rn(v, lat[row][r]);
+                    lat[row][r] = v;                    // biased logit
+                }
+                __syncthreads();
+                // ---- softmax denominator + first-max argmax: one thread per row
                 if (tid < ROWS) {
                     const int row = tid, b = b0 + row;
-                    const bool has_lat = latent_in_launch || net.latent_win;
-                    const int64_t wbase = ((int64_t)b * T + (k - 1)) * K;
-                    float best = 0.0f;
-                    int best_r = -1;
-                    for (int r = 0; r < K; ++r) {
-                        float dot = part[row][r][0];
-#pragma unroll
-                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part[row][r][m]);
-                        float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;
-                        if (member == 0 && b < B) net.win_logits[wbase + r] = v;
-                        if (publishes_latent && member == 0)
-                            g_store(xl + (((size_t)tile * T + (k - 1)) * ROWS + row) * K + r, 1u, v);
-                        if (has_lat) v = __fadd_rn(v, lat[row][r]);
-                        lat[row][r] = v;   // keep the biased logit for the softmax denominator
-                        if (best_r < 0 || v > best) {
+                    float best = lat[row][0];
+                    int best_r = 0;
+                    for (int r = 1; r < K; ++r) {
+                        const float v = lat[row][r];
+                        if (v > best) {                 // strict '>' keeps the first maximum
                             best = v;
                             best_r = r;
                         }
@@ -253,16 +259,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
             // ---- decoder LSTM cell: two independent fma chains per gate column
             f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax1 = ah0;
-            {
-                float av[64];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) av[kk] = hs[c * LDH + 4 * kk + kq];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) {
-                    ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], wBh[0][kk], ah0, 0, 0, 0);
-                    ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], wBh[1][kk], ah1, 0, 0, 0);
-                }
-            }
+            mfma_chain_pair<LDH>(hs, c, kq, wBh[0], wBh[1], ah0, ah1);
             if (k > 0) {
                 if (net.embedded) {
 #pragma unroll
@@ -286,31 +283,16 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 }
                 __syncthreads();
             }
-            {
-                float av[64];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) av[kk] = xs[c * LDH + 4 * kk + kq];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) {
-                    ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], wBx[0][kk], ax0, 0, 0, 0);
-                    ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], wBx[1][kk], ax1, 0, 0, 0);
-                }
-            }
+            mfma_chain_pair<LDH>(xs, c, kq, wBx[0], wBx[1], ax0, ax1);
             u64* out_h = xh_g + (step & 1) * (ROWS * H);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float g0 = __fadd_rn(__fadd_rn(ah0[r], bh[0]), __fadd_rn(ax0[r], bi[0]));
                 const float g1 = __fadd_rn(__fadd_rn(ah1[r], bh[1]), __fadd_rn(ax1[r], bi[1]));
-                const float a0 = sigmoid_f32(g0);
-                const float a1 = (c < 8) ? tanhf(g1) : sigmoid_f32(g1);
-                const float p0 = __shfl_xor(a0, 8, 64), p1 = __shfl_xor(a1, 8, 64);
-                const float ig = (c < 8) ? a0 : p0, gg = (c < 8) ? a1 : p1;
-                const float fg = (c < 8) ? p0 : a0, og = (c < 8) ? p1 : a1;
-                cst[r] = __fadd_rn(__fmul_rn(fg, cst[r]), __fmul_rn(ig, gg));
-                hl[r] = __fmul_rn(og, tanhf(cst[r]));
+                cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);
                 if (c < 8) {
                     const int row = kq * 4 + r;
-                    g_store(out_h + row * H + unit, step + 1, hl[r]);
+                    granule_store(out_h + row * H + unit, step + 1, hl[r]);
                     hsl[row][wave * 8 + (c & 7)] = hl[r];
                     if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
                 }
@@ -326,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     p = fmaf(ev[j].z, hsl[prow][4 * j + 2], p);
                     p = fmaf(ev[j].w, hsl[prow][4 * j + 3], p);
                 }
-                g_store(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p);
+                granule_store(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p);
             }
             ++step;
         }

@@ -20,9 +20,7 @@
 #include "common.h"
 #include "recurrent.h"
 #include "lstm_shared.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
+#include "coop_common.h"
 
 namespace {
 constexpr int H = 256;
@@ -33,18 +31,10 @@ constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 }  // namespace
 
-__device__ __forceinline__ u64 granule_load(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dwordx2 sc1
-}
-__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
-    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
-}
-
 // Sweep this wave's quarter (rows 4w..4w+3, all 256 units) of one parity buffer until every
 // granule carries `tag`; values go to LDS.  Returns false on timeout.
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, float* hs, int wave, int lane,
-                                              bool keep) {
+                                              bool keep, bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
     unsigned v[16];
     for (unsigned spins = 0;; ++spins) {
@@ -55,7 +45,7 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
             v[j] = (unsigned)x;
             ok &= (unsigned)(x >> 32) == tag;
         }
-        if (__all(ok)) break;
+        if (__all(ok) || nowait) break;
         if (spins > SPIN_LIMIT) return false;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -71,8 +61,9 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
 
 __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
-                                                                  int n_nets, int groups_per_net) {
+                                                                  int n_nets, int groups_per_net, int ablate) {
     __shared__ float hs[ROWS * LDH];
+    __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
     __shared__ int abort_flag;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,23 +109,36 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
         const int b0 = tile * ROWS;
         float cst[4] = {0.f, 0.f, 0.f, 0.f};
         float hlast[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < L; ++t, ++step) {
-            // input side of this step (consumed after the MFMAs: latency hidden): either the
-            // stored pre-gates or the raw 8-feature rows as MFMA A-fragments (row c, k = 4*kk2 + kq)
-            float pg[2][4];
-            float ax[2] = {0.f, 0.f};
+        // Input side, software-pipelined by one step: the loads of step t+1 are issued AFTER step t's
+        // hand-off wait (vector-memory operations retire in issue order, so an HBM-latency load issued
+        // before the sweep would be waited for by the sweep) and are consumed a whole step later.
+        float pg[2][4], pg_next[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float ax[2] = {0.f, 0.f}, ax_next[2] = {0.f, 0.f};
+        auto load_input = [&](int t, float (&pgv)[2][4], float (&axv)[2]) {
             if (pre) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = b0 + kq * 4 + r;
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl)
-                        pg[tl][r] = b < B ? pre[((int64_t)b * L + t) * (4 * H) + wrow[tl]] : 0.0f;
+                        pgv[tl][r] = b < B ? pre[((int64_t)b * L + t) * (4 * H) + wrow[tl]] : 0.0f;
                 }
-            } else if (b0 + c < B) {
+            } else if (b0 + c < B) {   // raw 8-feature row as MFMA A-fragments (row c, k = 4*kk2 + kq)
                 const float* row = xin + ((int64_t)(b0 + c) * L + t) * 8;
-                ax[0] = row[kq];
-                ax[1] = row[4 + kq];
+                axv[0] = row[kq];
+                axv[1] = row[4 + kq];
+            }
+        };
+        load_input(0, pg_next, ax_next);
+        for (int t = 0; t < L; ++t, ++step) {
+            const bool stamps = ablate & 32;
+            u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+            if (stamps) s0 = phase_stamp();
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                ax[tl] = ax_next[tl];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pg[tl][r] = pg_next[tl][r];
             }
             // h_{t-1}: zeros at t == 0, else the peers' published slices.  At a tile switch the
             // sweep still runs (values dropped): it proves every peer is done with the buffer
@@ -143,23 +147,30 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
             if (t == 0) {
                 for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
                 if (!first_tile) ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
-            } else {
-                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true);
+            } else if (!(ablate & 8)) {
+                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
+            if (stamps) s1 = phase_stamp();
             __syncthreads();
             if (abort_flag) break;
+            if (stamps) s2 = phase_stamp();
+            if (t + 1 < L) load_input(t + 1, pg_next, ax_next);
+            // enc_out of the PREVIOUS step leaves now: after the hand-off wait (stores retire in issue
+            // order with the sweep's loads, so storing before the sweep would lengthen it), as whole
+            // 128-B lines (one per problem row) out of the LDS staging tile.
+            if (t > 0 && threadIdx.x < ROWS * 8) {
+                const int row = threadIdx.x >> 3, q = threadIdx.x & 7;
+                if (b0 + row < B)
+                    *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (t - 1)) * H + member * UNITS + 4 * q) =
+                        *reinterpret_cast<const float4*>(&hst[row][4 * q]);
+            }
 
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0) {
-                float a[64];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) a[kk] = hs[c * LDH + 4 * kk + kq];
-#pragma unroll
-                for (int kk = 0; kk < 64; ++kk) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[0][kk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wB[1][kk], acc1, 0, 0, 0);
-                }
+            if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDH>(hs, c, kq, wB[0], wB[1], acc0, acc1);
+            if (stamps) {
+                asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));   // the MFMA chains have retired
+                s3 = phase_stamp();
             }
             if (!pre) {   // x_t . w_in^T as its own k-ordered chain, then + b_in (as gnnpn_linear_f32 would)
                 f32x4 px0 = {0.f, 0.f, 0.f, 0.f}, px1 = {0.f, 0.f, 0.f, 0.f};
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
                 }
             }
             __syncthreads();   // everyone is done reading hs before the next step's sweep rewrites it
+            if (stamps) s4 = phase_stamp();
 
             u64* out_buf = xg + (step & 1) * (ROWS * H);
 #pragma unroll
@@ -181,21 +193,35 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
                 // gates = (h.W_hh^T + b_hh) + (x.W_ih^T + b_ih); lanes c<8 hold (i,g), c>=8 hold (f,o)
                 const float g0 = __fadd_rn(__fadd_rn(acc0[r], bh[0]), pg[0][r]);
                 const float g1 = __fadd_rn(__fadd_rn(acc1[r], bh[1]), pg[1][r]);
-                const float a0 = sigmoid_f32(g0);
-                const float a1 = (c < 8) ? tanhf(g1) : sigmoid_f32(g1);
-                const float p0 = __shfl_xor(a0, 8, 64), p1 = __shfl_xor(a1, 8, 64);
-                const float ig = (c < 8) ? a0 : p0, gg = (c < 8) ? a1 : p1;
-                const float fg = (c < 8) ? p0 : a0, og = (c < 8) ? p1 : a1;
-                cst[r] = __fadd_rn(__fmul_rn(fg, cst[r]), __fmul_rn(ig, gg));
-                hlast[r] = __fmul_rn(og, tanhf(cst[r]));
+                cell_update_pair(g0, g1, c < 8, cst[r], hlast[r]);
                 if (c < 8) {
                     const int row = kq * 4 + r;
-                    granule_store(out_buf + row * H + unit, step + 1, hlast[r]);
-                    if (b0 + row < B) enc[((int64_t)(b0 + row) * L + t) * H + unit] = hlast[r];
+                    if (!(ablate & 16)) granule_store(out_buf + row * H + unit, step + 1, hlast[r]);
+                    hst[row][wave * 8 + (c & 7)] = hlast[r];
+                }
+            }
+            if (stamps) {
+                asm volatile("" ::"v"(hlast[3]));
+                s5 = phase_stamp();
+                if (blockIdx.x == 0 && threadIdx.x == 0 && t > 0) {   // sums live in the status area (words 8..)
+                    u64* prof = reinterpret_cast<u64*>(err) + 4;
+                    prof[0] += s1 - s0;   // input copy + hand-off sweep + LDS fill
+                    prof[1] += s2 - s1;   // barrier
+                    prof[2] += s3 - s2;   // input prefetch issue + enc_out flush + A-fragment reads + 128 MFMAs
+                    prof[3] += s4 - s3;   // input projection + barrier
+                    prof[4] += s5 - s4;   // cell update + publish
+                    prof[5] += 1;
                 }
             }
         }
         if (abort_flag) break;
+        __syncthreads();                                   // last step's slice is complete in hst
+        if (threadIdx.x < ROWS * 8) {
+            const int row = threadIdx.x >> 3, q = threadIdx.x & 7;
+            if (b0 + row < B)
+                *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (L - 1)) * H + member * UNITS + 4 * q) =
+                    *reinterpret_cast<const float4*>(&hst[row][4 * q]);
+        }
         if (c < 8) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -239,6 +265,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
     hipLaunchKernelGGL(lstm_encode_coop_kernel, dim3(groups * G), dim3(256), 0, s, nets,
                        reinterpret_cast<u64*>(static_cast<char*>(workspace) + 256),
-                       reinterpret_cast<unsigned*>(workspace), B, L, n_nets, groups_per_net);
+                       reinterpret_cast<unsigned*>(workspace), B, L, n_nets, groups_per_net,
+                       gnnpn_option_lstm_ablate());
     return GNNPN_OK;
 }

@@ -5,9 +5,9 @@
 // one LSTM cell update from the four gate pre-activations (torch: cy = f*c + i*g ; hy = o*tanh(cy),
 // products and sum rounded separately)
 __device__ __forceinline__ void lstm_cell_update(float gi, float gf, float gg, float go, float& c, float& h) {
-    const float i = sigmoid_f32(gi), f = sigmoid_f32(gf), g = tanhf(gg), o = sigmoid_f32(go);
+    const float i = cell_sigmoid(gi), f = cell_sigmoid(gf), g = cell_tanh(gg), o = cell_sigmoid(go);
     c = __fadd_rn(__fmul_rn(f, c), __fmul_rn(i, g));
-    h = __fmul_rn(o, tanhf(c));
+    h = __fmul_rn(o, cell_tanh(c));
 }
 
 // acc[p][g] += sum_k W[g*H+j][k] * v[p][k], k ascending, one fmaf chain per (p,g)

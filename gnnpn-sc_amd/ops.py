@@ -277,3 +277,12 @@ def qos_reward(actions, level):
     check(_lib.load().gnnpn_qos_reward_f32(dev_ptr(actions, F32, "actions"), dev_ptr(R, F32, "R"), B, T,
                                            0 if level == "Low" else 1, stream_ptr()), "gnnpn_qos_reward_f32")
     return R
+
+
+def debug_cell_activations(x):
+    """(sigmoid, tanh) as the LSTM-cell kernels evaluate them (test hook)."""
+    sig, th = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().gnnpn_debug_cell_activations(dev_ptr(x, F32, "x"), dev_ptr(sig, F32, "sig"),
+                                                   dev_ptr(th, F32, "th"), x.numel(), stream_ptr()),
+          "gnnpn_debug_cell_activations")
+    return sig, th

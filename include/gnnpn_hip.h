@@ -227,6 +227,10 @@ int gnnpn_attention_logits_f32(const float* enc_out, const float* queries, int64
 int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, int level,
                          void* stream);
 
+/* Test hook: the sigmoid / tanh the LSTM cells use (hardware exp2/rcp based, |error| ~1e-7),
+ * evaluated on an array so that tests can measure them against the CPU's libm-grade functions. */
+int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,26 @@ def test_in_kernel_input_projection_equals_materialised(dev):
         assert torch.equal(u[0], v[0])
 
 
+def test_cell_activations(dev):
+    """The hardware-exp2/rcp sigmoid and tanh of the LSTM cells against torch CPU in fp64:
+    absolute error at the level of the result's own fp32 rounding, sane at the extremes."""
+    ops = _ops()
+    x = torch.cat([torch.linspace(-30, 30, 400001), torch.linspace(-0.3, 0.3, 200001),
+                   torch.tensor([0.0, -0.0, 1e-30, -1e-30, 88.0, -88.0, 200.0, -200.0, 1e30, -1e30,
+                                 float("inf"), float("-inf")])]).float()
+    sig, th = (t.cpu().double() for t in ops.debug_cell_activations(x.to(dev)))
+    xd = x.double()
+    err_s = (sig - torch.sigmoid(xd)).abs().max().item()
+    err_t = (th - torch.tanh(xd)).abs().max().item()
+    assert err_s < 1.5e-7 and err_t < 1.5e-7, (err_s, err_t)
+    small = xd.abs() < 0.25
+    rel = ((th - torch.tanh(xd)).abs() / torch.tanh(xd).abs().clamp(min=1e-30))[small & (xd != 0)].max().item()
+    assert rel < 3e-7, rel                                   # small arguments keep RELATIVE accuracy
+    assert torch.isfinite(sig).all() and torch.isfinite(th).all()
+    assert sig[-1] < 1e-37 and sig[-2] == 1.0 and th[-1] == -1.0 and th[-2] == 1.0
+    assert th[400001 + 200001] == 0.0 and (sig >= 0).all() and (sig <= 1).all() and (th.abs() <= 1).all()
+
+
 def test_qos_reward_golden(dev):
     ops = _ops()
     fx = golden("reward.npz")
