@@ -44,7 +44,7 @@ EXPORTS = tuple(_SIGNATURES)
 class DecodeNet(ctypes.Structure):
     """gnnpn_decode_net_t of include/gnnpn_hip.h."""
     _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih_packed", "whh_packed", "bih",
-                                  "bhh", "latent_win", "emb_w", "emb_b", "idx", "win_logits", "pick_prob", "actions",
+                                  "bhh", "latent_win", "emb_w", "emb_b", "xw_fold", "xb_fold", "start_fold", "idx", "win_logits", "pick_prob", "actions",
                                   "queries")] + \
                [("latent_from", c_int32), ("reserved", c_int32)]
 

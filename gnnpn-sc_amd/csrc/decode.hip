@@ -174,7 +174,10 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         const gnnpn_decode_net_t& d = nets[n];
         GNNPN_REQUIRE(d.enc_out && d.h0 && d.c0 && d.start && d.wih_packed && d.whh_packed && d.bih && d.bhh,
                       "pointer_decode: null input of net %d", n);
-        GNNPN_REQUIRE(d.embedded || (d.emb_w && d.emb_b), "pointer_decode: net %d needs embedded or (emb_w, emb_b)", n);
+        GNNPN_REQUIRE(d.embedded || (d.emb_w && d.emb_b) || d.xw_fold,
+                      "pointer_decode: net %d needs embedded, (emb_w, emb_b) or the folded input side", n);
+        GNNPN_REQUIRE((d.xw_fold != nullptr) == (d.xb_fold != nullptr) && (d.xw_fold != nullptr) == (d.start_fold != nullptr),
+                      "pointer_decode: net %d: xw_fold, xb_fold and start_fold go together", n);
         GNNPN_REQUIRE(d.idx && d.win_logits && d.pick_prob && d.actions, "pointer_decode: null output of net %d", n);
         GNNPN_REQUIRE(d.latent_from < n && d.latent_from >= -1, "pointer_decode: latent_from of net %d must name an "
                       "earlier net of the call", n);

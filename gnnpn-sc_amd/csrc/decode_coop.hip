@@ -12,6 +12,11 @@
 //                 -> publish the h_k slice; partial dots of the step-k window rows against the OWN
 //                    h_k slice (dot = sum of 8 partials of 32, in member order) -> publish them.
 //
+// With the folded input side (net.xw_fold != NULL) the decoder input x_k = embedding2(inputs[pick])
+// never exists: W_ih.(W_e r + b_e) + b_ih = (W_ih W_e) r + (W_ih b_e + b_ih) is evaluated from the raw
+// 8-feature row r with 4 MFMAs per step instead of 128 (same identity as the encoder's folded input
+// projection; step 0 uses the precomputed W_ih.start + b_ih).
+//
 // The attention therefore needs no second hand-off: the partial dots ride the same exchange as h.
 // Every member computes every row's argmax (identical arithmetic on identical data), so all agree
 // without exchanging indices; member 0 writes the outputs.  The Low net never waits for the High
@@ -22,6 +27,7 @@
 #include "recurrent.h"
 #include "decode_shared.h"
 #include "coop_common.h"
+#include "lstm_shared.h"
 
 namespace {
 constexpr int H = 256;
@@ -33,17 +39,28 @@ constexpr int KMAX = 16;          // candidates per category the cooperative for
 constexpr unsigned SPIN_LIMIT = 400000;
 }  // namespace
 
+// max / sum over each row of 16 lanes by DPP rotations (every lane ends with the row's result)
+__device__ __forceinline__ int ror16(int v, int n) {
+    switch (n) {
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);
+        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);
+    }
+}
+
+template <bool FOLDX>
 __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, int n_nets,
-                                                                     int groups_per_net) {
+                                                                     int groups_per_net, int ablate) {
     __shared__ float hs[ROWS * LDH];
-    __shared__ float xs[ROWS * LDH];
-    __shared__ float hsl[ROWS][UNITS + 1];
+    __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
+    __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ float part[ROWS][KMAX][G];
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
-    __shared__ float xin[ROWS][8];
+    __shared__ float xin[FOLDX ? 1 : ROWS][8];
     __shared__ int abort_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,6 +75,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;
+    const bool has_lat = latent_in_launch || net.latent_win;
     bool publishes_latent = false;
     for (int n = 0; n < n_nets; ++n) publishes_latent |= (a.net[n].latent_from == net_id);
 
@@ -68,22 +86,29 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     int wrow[2];
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
-    float wBh[2][64], wBx[2][64], bh[2], bi[2];
+    float wBh[2][64], wBx[FOLDX ? 1 : 2][FOLDX ? 1 : 64], bh[2], bi[2], wXf[2][2], sg[2];
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = net.bhh[wrow[tl]];
-        bi[tl] = net.bih[wrow[tl]];
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) {
-            wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
-            wBx[tl][kk] = net.wih[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+        for (int kk = 0; kk < 64; ++kk) wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+        if constexpr (FOLDX) {   // B-fragments of (W_ih W_e) [4H,8], its bias, and the step-0 gates W_ih.start + b_ih
+            wXf[tl][0] = net.xw_fold[wrow[tl] * 8 + kq];
+            wXf[tl][1] = net.xw_fold[wrow[tl] * 8 + 4 + kq];
+            bi[tl] = net.xb_fold[wrow[tl]];
+            sg[tl] = net.start_fold[wrow[tl]];
+        } else {
+            bi[tl] = net.bih[wrow[tl]];
+            wXf[tl][0] = wXf[tl][1] = sg[tl] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 64; ++kk)
+                wBx[tl][kk] = net.wih[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
         }
     }
-
-    // in-kernel embedding2 of the picked row (net.embedded == nullptr): column tid of emb_w
+    // unfolded path, in-kernel embedding2 of the picked row (net.embedded == nullptr): column tid of emb_w
     float ew[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, eb = 0.f;
-    if (!net.embedded) {
+    if (!FOLDX && !net.embedded) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) ew[i] = net.emb_w[tid * 8 + i];
         eb = net.emb_b[tid];
@@ -103,19 +128,21 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
         __syncthreads();   // previous tile is completely done with the LDS arrays
         for (int j = 0; j < ROWS; ++j) {
             hs[j * LDH + tid] = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
-            xs[j * LDH + tid] = net.start[tid];
+            if (!FOLDX) xs[j * LDH + tid] = net.start[tid];
         }
         __syncthreads();
 
         for (int k = 0; k <= T; ++k) {
             float4 xg[4];
-            float xraw = 0.0f;
+            float xraw = 0.0f, axf[2] = {0.f, 0.f};
+            const bool stamps = ablate & 32;
+            u64 st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (stamps) st[0] = phase_stamp();
             if (k > 0) {
                 // ---- hand-off of publish #(step-1): h_{k-1}, partial dots, Low's window logits — ONE
                 // combined sweep (all loads issued, then all tags checked): one round trip, not three
                 const unsigned tag = step;
                 const int par = (step - 1) & 1;
-                const bool has_lat = latent_in_launch || net.latent_win;
                 {
                     const u64* src_h = xh_g + par * (ROWS * H) + wave * 4 * H;
                     const u64* src_p = xp_g + par * (G * ROWS * K);
@@ -183,44 +210,53 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                         lat[wave * 4 + lane / K][lane % K] = lv;
                     }
                 }
+                if (stamps) st[1] = phase_stamp();
                 __syncthreads();
                 if (abort_flag) break;
 
-                // ---- logits: one thread per (row, candidate): sum of the 8 partial dots in member
-                // order, C*tanh (device-library tanhf: these values decide the pick), + latent
-                if (tid < ROWS * K) {
-                    const int row = tid / K, r = tid - row * K, b = b0 + row;
-                    float dot = part[row][r][0];
+                // ---- logits, softmax and first-max argmax inside the wave: wave w owns rows 4w..4w+3,
+                // 16 lanes per row, lane = candidate (K <= 16).  Row-wide max / sum by DPP rotations.
+                {
+                    const int row = wave * 4 + kq, b = b0 + row, r = c;
+                    const bool live = r < K;
+                    float dot = 0.0f;
+                    if (live) {
+                        dot = part[row][r][0];
 #pragma unroll
-                    for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part[row][r][m]);
+                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part[row][r][m]);   // member order
+                    }
+                    // C*tanh with the device-library tanhf: these values decide the pick
                     float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;
-                    if (member == 0) {
+                    if (live && member == 0) {
                         if (b < B) net.win_logits[((int64_t)b * T + (k - 1)) * K + r] = v;
                         if (publishes_latent)
                             granule_store(xl + (((size_t)tile * T + (k - 1)) * ROWS + row) * K + r, 1u, v);
                     }
-                    if (has_lat) v = __fadd_rn(v, lat[row][r]);
-                    lat[row][r] = v;                    // biased logit
-                }
-                __syncthreads();
-                // ---- softmax denominator + first-max argmax: one thread per row
-                if (tid < ROWS) {
-                    const int row = tid, b = b0 + row;
-                    float best = lat[row][0];
-                    int best_r = 0;
-                    for (int r = 1; r < K; ++r) {
-                        const float v = lat[row][r];
-                        if (v > best) {                 // strict '>' keeps the first maximum
-                            best = v;
-                            best_r = r;
-                        }
+                    if (has_lat && live) v = __fadd_rn(v, lat[row][r]);
+                    // key: larger logit wins, ties -> lower candidate index (torch.max returns the first)
+                    const unsigned hi = live ? float_order_key(v) : 0u;
+                    unsigned long long key = ((unsigned long long)hi << 32) | (unsigned)(15 - r);
+#pragma unroll
+                    for (int n = 1; n <= 8; n <<= 1) {
+                        const unsigned olo = (unsigned)ror16((int)(unsigned)key, n);
+                        const unsigned ohi = (unsigned)ror16((int)(unsigned)(key >> 32), n);
+                        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+                        key = o > key ? o : key;
                     }
-                    float denom = 0.0f;
-                    for (int r = 0; r < K; ++r) denom = __fadd_rn(denom, expf(__fsub_rn(lat[row][r], best)));
-                    sel[row] = (k - 1) * K + best_r;
-                    if (member == 0 && b < B) {
-                        net.pick_prob[(int64_t)b * T + (k - 1)] = 1.0f / denom;
-                        net.idx[(int64_t)b * T + (k - 1)] = (k - 1) * K + best_r;
+                    const int best_r = 15 - (int)(key & 0xffffffffu);
+                    // best logit value = the winner's v: fetch it by one more rotation-reduce (max of v)
+                    float best = live ? v : -INFINITY;
+#pragma unroll
+                    for (int n = 1; n <= 8; n <<= 1) best = fmaxf(best, __int_as_float(ror16(__float_as_int(best), n)));
+                    float e = live ? expf(__fsub_rn(v, best)) : 0.0f;
+#pragma unroll
+                    for (int n = 8; n >= 1; n >>= 1) e = __fadd_rn(e, __int_as_float(ror16(__float_as_int(e), n)));
+                    if (r == 0) {
+                        sel[row] = (k - 1) * K + best_r;
+                        if (member == 0 && b < B) {
+                            net.pick_prob[(int64_t)b * T + (k - 1)] = 1.0f / e;
+                            net.idx[(int64_t)b * T + (k - 1)] = (k - 1) * K + best_r;
+                        }
                     }
                 }
                 __syncthreads();
@@ -231,8 +267,15 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                             a.inputs[((int64_t)b * L + sel[row]) * 8 + (tid & 7)];
                 }
                 if (k == T) break;
-                // x_k = embedded[idx_{k-1}] : in flight under the W_hh.h MFMAs
-                if (net.embedded) {
+                if (stamps) st[2] = phase_stamp();
+                // decoder input of step k, in flight under the W_hh.h MFMAs
+                if constexpr (FOLDX) {            // raw 8-feature row of the pick as MFMA A-fragments (row c)
+                    if (b0 + c < B) {
+                        const float* rowp = a.inputs + ((int64_t)(b0 + c) * L + sel[c]) * 8;
+                        axf[0] = rowp[kq];
+                        axf[1] = rowp[4 + kq];
+                    }
+                } else if (net.embedded) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int f = tid + 256 * j, row = f >> 6, q4 = f & 63, b = b0 + row;
@@ -257,38 +300,68 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     ev[j] = b < B ? *reinterpret_cast<const float4*>(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 
-            // ---- decoder LSTM cell: two independent fma chains per gate column
+            // ---- decoder LSTM cell: W_hh.h and the input side as independent fma chains per gate column
             f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax1 = ah0;
             mfma_chain_pair<LDH>(hs, c, kq, wBh[0], wBh[1], ah0, ah1);
-            if (k > 0) {
-                if (net.embedded) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int f = tid + 256 * j, row = f >> 6, q4 = f & 63;
-                        float* d = &xs[row * LDH + q4 * 4];
-                        d[0] = xg[j].x; d[1] = xg[j].y; d[2] = xg[j].z; d[3] = xg[j].w;
-                    }
-                } else {
-                    if (tid < ROWS * 8) xin[tid >> 3][tid & 7] = xraw;
-                    __syncthreads();
-                    // x[row][tid] = (sum_i inputs[row][i] * emb_w[tid][i], i ascending, from 0) + emb_b[tid]:
-                    // the k-ordered chain + bias of gnnpn_linear_f32 -> the same bits as the stored row
-#pragma unroll
-                    for (int row = 0; row < ROWS; ++row) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc = fmaf(xin[row][i], ew[i], acc);
-                        xs[row * LDH + tid] = __fadd_rn(acc, eb);
-                    }
-                }
-                __syncthreads();
+            if (stamps) {
+                asm volatile("" ::"v"(ah0[0]), "v"(ah1[0]));
+                st[3] = phase_stamp();
             }
-            mfma_chain_pair<LDH>(xs, c, kq, wBx[0], wBx[1], ax0, ax1);
+            float gx[2][4];
+            if constexpr (FOLDX) {
+                if (k > 0) {
+                    ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[0], wXf[0][0], ax0, 0, 0, 0);
+                    ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[0], wXf[1][0], ax1, 0, 0, 0);
+                    ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[1], wXf[0][1], ax0, 0, 0, 0);
+                    ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[1], wXf[1][1], ax1, 0, 0, 0);
+                }
+                if (stamps) st[4] = st[5] = phase_stamp();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx[0][r] = k > 0 ? __fadd_rn(ax0[r], bi[0]) : sg[0];
+                    gx[1][r] = k > 0 ? __fadd_rn(ax1[r], bi[1]) : sg[1];
+                }
+            } else {
+                if (k > 0) {
+                    if (net.embedded) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int f = tid + 256 * j, row = f >> 6, q4 = f & 63;
+                            float* d = &xs[row * LDH + q4 * 4];
+                            d[0] = xg[j].x; d[1] = xg[j].y; d[2] = xg[j].z; d[3] = xg[j].w;
+                        }
+                    } else {
+                        if (tid < ROWS * 8) xin[tid >> 3][tid & 7] = xraw;
+                        __syncthreads();
+                        // x[row][tid] = (sum_i inputs[row][i] * emb_w[tid][i], i ascending, from 0) + emb_b[tid]:
+                        // the k-ordered chain + bias of gnnpn_linear_f32 -> the same bits as the stored row
+#pragma unroll
+                        for (int row = 0; row < ROWS; ++row) {
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) acc = fmaf(xin[row][i], ew[i], acc);
+                            xs[row * LDH + tid] = __fadd_rn(acc, eb);
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (stamps) st[4] = phase_stamp();
+                mfma_chain_pair<LDH>(xs, c, kq, wBx[0], wBx[1], ax0, ax1);
+                if (stamps) {
+                    asm volatile("" ::"v"(ax0[0]), "v"(ax1[0]));
+                    st[5] = phase_stamp();
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx[0][r] = __fadd_rn(ax0[r], bi[0]);
+                    gx[1][r] = __fadd_rn(ax1[r], bi[1]);
+                }
+            }
             u64* out_h = xh_g + (step & 1) * (ROWS * H);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float g0 = __fadd_rn(__fadd_rn(ah0[r], bh[0]), __fadd_rn(ax0[r], bi[0]));
-                const float g1 = __fadd_rn(__fadd_rn(ah1[r], bh[1]), __fadd_rn(ax1[r], bi[1]));
+                const float g0 = __fadd_rn(__fadd_rn(ah0[r], bh[0]), gx[0][r]);
+                const float g1 = __fadd_rn(__fadd_rn(ah1[r], bh[1]), gx[1][r]);
                 cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);
                 if (c < 8) {
                     const int row = kq * 4 + r;
@@ -297,18 +370,37 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
                 }
             }
+            if (stamps) {
+                asm volatile("" ::"v"(hl[3]));
+                st[6] = phase_stamp();
+            }
             __syncthreads();
             // ---- partial attention dots of the step-k window against the own h_k slice
             if (pdot) {
                 float p = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    p = fmaf(ev[j].x, hsl[prow][4 * j + 0], p);
-                    p = fmaf(ev[j].y, hsl[prow][4 * j + 1], p);
-                    p = fmaf(ev[j].z, hsl[prow][4 * j + 2], p);
-                    p = fmaf(ev[j].w, hsl[prow][4 * j + 3], p);
+                    const float4 hv = *reinterpret_cast<const float4*>(&hsl[prow][4 * j]);
+                    p = fmaf(ev[j].x, hv.x, p);
+                    p = fmaf(ev[j].y, hv.y, p);
+                    p = fmaf(ev[j].z, hv.z, p);
+                    p = fmaf(ev[j].w, hv.w, p);
                 }
                 granule_store(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p);
+            }
+            if (stamps) {
+                st[7] = phase_stamp();
+                if (blockIdx.x == 0 && tid == 0 && k > 0) {
+                    u64* prof = reinterpret_cast<u64*>(err) + 4;
+                    prof[0] += st[1] - st[0];   // combined sweep + LDS fill
+                    prof[1] += st[2] - st[1];   // barrier, logits+argmax, barrier, actions
+                    prof[2] += st[3] - st[2];   // gathers issue + W_hh.h MFMAs
+                    prof[3] += st[4] - st[3];   // input side: folded MFMAs | x embedding into LDS
+                    prof[4] += st[5] - st[4];   // W_ih.x MFMAs (unfolded only)
+                    prof[5] += st[6] - st[5];   // cell + publish h
+                    prof[6] += st[7] - st[6];   // barrier + partial dots + publish
+                    prof[7] += 1;
+                }
             }
             ++step;
         }
@@ -331,6 +423,10 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: cannot query the device");
+    bool fold = args.net[0].xw_fold != nullptr;
+    for (int n = 0; n < n_nets; ++n)
+        if ((args.net[n].xw_fold != nullptr) != fold)
+            GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: all nets of a call must use the same input-side form");
     const int n_tiles = (args.B + ROWS - 1) / ROWS;
     int gpx = n_cu / (8 * G);
     if (gpx > 8) gpx = 8;
@@ -348,9 +444,15 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
     char* base = static_cast<char*>(workspace);
-    hipLaunchKernelGGL(pointer_decode_coop_kernel, dim3(groups * G), dim3(256), 0, s, args,
-                       reinterpret_cast<u64*>(base + 256), reinterpret_cast<u64*>(base + 256 + h_bytes),
-                       reinterpret_cast<u64*>(base + 256 + h_bytes + p_bytes), reinterpret_cast<unsigned*>(base),
-                       n_nets, groups_per_net);
+    u64* p_h = reinterpret_cast<u64*>(base + 256);
+    u64* p_p = reinterpret_cast<u64*>(base + 256 + h_bytes);
+    u64* p_l = reinterpret_cast<u64*>(base + 256 + h_bytes + p_bytes);
+    unsigned* p_err = reinterpret_cast<unsigned*>(base);
+    if (fold)
+        hipLaunchKernelGGL(pointer_decode_coop_kernel<true>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l,
+                           p_err, n_nets, groups_per_net, gnnpn_option_lstm_ablate());
+    else
+        hipLaunchKernelGGL(pointer_decode_coop_kernel<false>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l,
+                           p_err, n_nets, groups_per_net, gnnpn_option_lstm_ablate());
     return GNNPN_OK;
 }

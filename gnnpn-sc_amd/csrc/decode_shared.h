@@ -16,6 +16,9 @@ struct DecodeNet {
     const float* latent_win;
     const float* emb_w;
     const float* emb_b;
+    const float* xw_fold;
+    const float* xb_fold;
+    const float* start_fold;
     int32_t* idx;
     float* win_logits;
     float* pick_prob;

@@ -124,6 +124,11 @@ class PointerNet(nn.Module):
             dev = self.embedding2.weight.device
             self._packed["enc_wfold"] = (w_ih @ w_e).float().contiguous().to(dev)
             self._packed["enc_bfold"] = b.float().contiguous().to(dev)
+            # the same for the decoder cell's input side, plus its step-0 gates W_ih.start + b_ih
+            d_ih, d_b = self.decoder.weight_ih_l0.detach().double().cpu(), self.decoder.bias_ih_l0.detach().double().cpu()
+            self._packed["dec_wfold"] = (d_ih @ w_e).float().contiguous().to(dev)
+            self._packed["dec_bfold"] = (d_ih @ self.embedding2.bias.detach().double().cpu() + d_b).float().contiguous().to(dev)
+            self._packed["dec_sfold"] = (d_ih @ self.decoder_start_input.detach().double().cpu() + d_b).float().contiguous().to(dev)
         return self._packed
 
     def encode_args(self, inputs, fold=None):
@@ -142,13 +147,17 @@ class PointerNet(nn.Module):
         return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
             embedded.view(B, L, H)
 
-    def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1):
+    def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1, fold=None):
         """One entry of the ``nets`` list of ops.pointer_decode (embedded=None: picks are embedded
-        in-kernel from the raw rows)."""
+        in-kernel from the raw rows; fold: the cell's input side uses the folded [4H,8] matrix)."""
         w = self.packed()
-        return {"embedded": embedded, "emb_w": w["emb_w"], "emb_b": w["emb_b"], "enc_out": enc_out, "h0": h_n,
-                "c0": c_n, "start": w["start"], "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"],
-                "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from}
+        fold = FOLD_INPUT_PROJECTION if fold is None else fold
+        d = {"embedded": embedded, "emb_w": w["emb_w"], "emb_b": w["emb_b"], "enc_out": enc_out, "h0": h_n,
+             "c0": c_n, "start": w["start"], "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"],
+             "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from}
+        if fold and embedded is None:
+            d.update(xw_fold=w["dec_wfold"], xb_fold=w["dec_bfold"], start_fold=w["dec_sfold"])
+        return d
 
     @torch.no_grad()
     def run(self, inputs, latent=None, want_queries=False, fold=None):
@@ -157,7 +166,8 @@ class PointerNet(nn.Module):
         enc_args, embedded = self.encode_args(inputs, fold)
         enc, h_n, c_n = ops.lstm_encode([enc_args])
         out = ops.pointer_decode(
-            [self.decode_args(embedded, enc[0], h_n[0], c_n[0], _window_tensor(latent, self.serCategory, self.serNumber))],
+            [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
+                              _window_tensor(latent, self.serCategory, self.serNumber), fold=fold)],
             inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
         out["enc_out"] = enc[0]
         return out
@@ -268,8 +278,8 @@ def two_level_greedy(low, high, inputs, fold=None):
     enc_h, emb_h = ha.encode_args(inputs, fold)
     enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h])
     del enc_l, enc_h
-    dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0]),
-                                 ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0)],
+    dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
+                                 ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold)],
                                 inputs, la.serCategory, la.serNumber, la.C, la.use_tanh)
     R = ops.qos_reward(dh["actions"], high.level)
     return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],

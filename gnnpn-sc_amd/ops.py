@@ -232,8 +232,13 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         for name, key in (("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"), ("start", "start"),
                           ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"), ("bhh", "bhh")):
             setattr(a, name, dev_ptr(d[key], F32, f"nets[{i}].{key}").value)
+        coop = coop_supported(H, n_per, "decode_impl")
+        if d.get("xw_fold") is not None and coop:                          # folded input side (cooperative form)
+            a.xw_fold = dev_ptr(d["xw_fold"], F32, f"nets[{i}].xw_fold").value
+            a.xb_fold = dev_ptr(d["xb_fold"], F32, f"nets[{i}].xb_fold").value
+            a.start_fold = dev_ptr(d["start_fold"], F32, f"nets[{i}].start_fold").value
         emb = d.get("embedded")
-        if emb is None and not coop_supported(H, n_per, "decode_impl"):   # no in-kernel embedding there
+        if emb is None and not coop:                                       # no in-kernel embedding there
             emb = linear(inputs.reshape(B * L, inputs.shape[2]), d["emb_w"], d["emb_b"]).view(B, L, H)
             outs[-1]["_embedded"] = emb
         a.embedded = None if emb is None else dev_ptr(emb, F32, f"nets[{i}].embedded").value

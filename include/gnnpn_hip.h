@@ -163,6 +163,10 @@ int gnnpn_set_option(const char* name, int value);
  *   embedded [B,L,H] (decoder inputs = rows of it), or NULL with emb_w [H,8] / emb_b [H]: the picked
  *            row is then computed in-kernel as inputs[pick] . emb_w^T + emb_b (same k-ordered fma
  *            chain + bias as gnnpn_linear_f32, so bit-identical to the stored row; cooperative form)
+ *   xw_fold [4H,8], xb_fold [4H], start_fold [4H] or NULL (all three): folded input side of the
+ *            decoder cell, xw_fold = W_ih.W_emb, xb_fold = W_ih.b_emb + b_ih, start_fold =
+ *            W_ih.start + b_ih; the step input is then evaluated from the raw row of the pick
+ *            (cooperative form only; same exact identity as gnnpn_encode_net_t.w_in)
  *   enc_out [B,L,H]  h0,c0 [B,H]  start [H]
  *   wih_packed / whh_packed / bih / bhh : decoder LSTM (packed as for the encoder)
  *   latent_win  [B,T,n_per] or NULL : window logits of a Low net computed EARLIER, added before the
@@ -191,6 +195,9 @@ typedef struct {
     const float* latent_win;
     const float* emb_w;
     const float* emb_b;
+    const float* xw_fold;
+    const float* xb_fold;
+    const float* start_fold;
     int32_t* idx;
     float* win_logits;
     float* pick_prob;

@@ -1,0 +1,20 @@
+"""Phase stamps of the cooperative decoder (diagnostic option; timing only)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnnpn_sc_amd import ops
+from gnnpn_sc_amd.modelPN import two_level_greedy
+from bench import build_models
+dev = torch.device("cuda:0")
+T, K, B = 47, 5, 256
+net, low, high = build_models(T, 2507, K, dev)
+g = torch.Generator().manual_seed(0)
+x = torch.rand(B, T * K, 8, generator=g).to(dev)
+for _ in range(3): two_level_greedy(low, high, x)
+ops.set_option("lstm_ablate", 32)
+two_level_greedy(low, high, x); torch.cuda.synchronize()
+ws = ops.decode_workspace(dev, B, T, K)
+prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
+n = max(prof[7], 1)
+names = ["sweep+fill", "logits/argmax (3 barriers)", "W_hh.h MFMA", "x embed->LDS", "W_ih.x MFMA", "cell+publish h", "partial dots"]
+print({k: round(v / n) for k, v in zip(names, prof[:7])}, "steps", n, "total", round(sum(prof[:7]) / n))
+ops.set_option("lstm_ablate", 0)
