@@ -14,6 +14,60 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
                        __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
 }
 
+// ---- same-XCD fast path --------------------------------------------------------------------------
+// The CUs of one XCD share its L2, so a granule stored WITHOUT sc bits (it stays in that L2) is found
+// there by a same-XCD reader's sc1 (L1-bypassing) load ~0.2 us sooner than a write-through store that
+// has to come back from the memory side (measured: 4.87 -> 4.47 us per encoder step).  Across XCDs it
+// would never become visible, and workgroup -> XCD placement is not a contract — so each group
+// ESTABLISHES it at kernel start: every member publishes its HW_REG_XCC_ID through the
+// placement-independent sc1 path, every member reads all G ids, and only if they are all equal does
+// the group use L2-resident stores.  All members read the same G values, so they decide alike.
+constexpr int COOP_STATUS_BYTES = 8192;      // [0,256) status + stamps, [1024, 5120) hello granules
+constexpr int COOP_HELLO_OFFSET = 1024;
+constexpr unsigned COOP_HELLO_TAG = 0x48454c4fu;
+
+__device__ __forceinline__ unsigned xcc_id() {
+    return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;   // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+
+__device__ __forceinline__ void granule_store_l2(u64* p, unsigned tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void granule_publish(u64* p, unsigned tag, float v, bool same_xcd) {
+    if (same_xcd) granule_store_l2(p, tag, v);
+    else granule_store(p, tag, v);
+}
+
+// Called by every thread of the workgroup.  Returns 1 (group on one XCD), 0 (not), -1 (a member did
+// not show up within the spin bound).  `flag` is one int of LDS.
+template <int G>
+__device__ __forceinline__ int group_same_xcd(unsigned* status, int group, int member, int* flag, unsigned spin_limit) {
+    u64* hello = reinterpret_cast<u64*>(reinterpret_cast<char*>(status) + COOP_HELLO_OFFSET) + (size_t)group * G;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned mine = xcc_id();
+        if (lane == 0)
+            __hip_atomic_store(hello + member, ((u64)COOP_HELLO_TAG << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int res = -1;
+        for (unsigned spins = 0; spins <= spin_limit; ++spins) {
+            bool ok = true, same = true;
+            if (lane < G) {
+                const u64 x = granule_load(hello + lane);
+                ok = (unsigned)(x >> 32) == COOP_HELLO_TAG;
+                same = (unsigned)x == mine;
+            }
+            if (__all(ok)) {
+                res = __all(same) ? 1 : 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane == 0) *flag = res;
+    }
+    __syncthreads();
+    return *flag;
+}
+
 // value of lane (l ^ 8) within each row of 16 lanes, as a DPP row rotate (no LDS round trip)
 __device__ __forceinline__ float swap8(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xF, 0xF, false));

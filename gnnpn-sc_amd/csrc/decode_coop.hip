@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];
     if (tid == 0) abort_flag = 0;
+    __shared__ int xcd_flag;
+    const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
+    if (same < 0) {
+        if (tid == 0) atomicOr(err, 4u);
+        return;
+    }
+    const bool same_xcd = same == 1 && !(ablate & 128);   // h and partial-dot granules stay inside the group
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);
                 if (c < 8) {
                     const int row = kq * 4 + r;
-                    granule_store(out_h + row * H + unit, step + 1, hl[r]);
+                    granule_publish(out_h + row * H + unit, step + 1, hl[r], same_xcd);
                     hsl[row][wave * 8 + (c & 7)] = hl[r];
                     if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
                 }
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     p = fmaf(ev[j].z, hv.z, p);
                     p = fmaf(ev[j].w, hv.w, p);
                 }
-                granule_store(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p);
+                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p, same_xcd);
             }
             if (stamps) {
                 st[7] = phase_stamp();
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
     const int64_t groups = 64, tiles = (B + ROWS - 1) / ROWS;
-    return 256 + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
+    return COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
            tiles * T * ROWS * (int64_t)n_per * 8;
 }
 
@@ -438,15 +445,15 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     const int64_t h_bytes = (int64_t)groups * 2 * ROWS * H * 8;
     const int64_t p_bytes = (int64_t)groups * 2 * G * ROWS * args.K * 8;
     const int64_t l_bytes = (int64_t)n_tiles * args.T * ROWS * args.K * 8;
-    const int64_t need = 256 + h_bytes + p_bytes + l_bytes;
+    const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
     char* base = static_cast<char*>(workspace);
-    u64* p_h = reinterpret_cast<u64*>(base + 256);
-    u64* p_p = reinterpret_cast<u64*>(base + 256 + h_bytes);
-    u64* p_l = reinterpret_cast<u64*>(base + 256 + h_bytes + p_bytes);
+    u64* p_h = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES);
+    u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
+    u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
     if (fold)
         hipLaunchKernelGGL(pointer_decode_coop_kernel<true>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l,

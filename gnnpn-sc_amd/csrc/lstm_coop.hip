@@ -75,6 +75,14 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
+    __shared__ int xcd_flag;
+    const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
+    if (same < 0) {
+        if (threadIdx.x == 0) atomicOr(err, 4u);
+        return;
+    }
+    const bool same_xcd = same == 1 && !(ablate & 128);
+    if (threadIdx.x == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the fast path
 
     const float* __restrict__ pre = nets.pregates[net];
     const float* __restrict__ xin = nets.inputs[net];     // used when pre == nullptr (F = 8)
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
                 cell_update_pair(g0, g1, c < 8, cst[r], hlast[r]);
                 if (c < 8) {
                     const int row = kq * 4 + r;
-                    if (!(ablate & 16)) granule_store(out_buf + row * H + unit, step + 1, hlast[r]);
+                    if (!(ablate & 16)) granule_publish(out_buf + row * H + unit, step + 1, hlast[r], same_xcd);
                     hst[row][wave * 8 + (c & 7)] = hlast[r];
                 }
             }
@@ -237,9 +245,10 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
     if (abort_flag && threadIdx.x == 0) atomicOr(err, 1u);
 }
 
-// workspace: [0,256) status words (word 0 = error), then the exchange buffers
+// workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
+// stamps, hello granules), then the exchange buffers
 extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
-    return 256 + (int64_t)64 * 2 * ROWS * H * sizeof(u64);   // up to 64 groups
+    return COOP_STATUS_BYTES + (int64_t)64 * 2 * ROWS * H * sizeof(u64);   // up to 64 groups
 }
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
@@ -257,14 +266,14 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     const int groups = gpx * 8;
     if (groups < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups, n_nets);
     const int groups_per_net = groups / n_nets;
-    const int64_t need = 256 + (int64_t)groups * 2 * ROWS * H * sizeof(u64);
+    const int64_t need = COOP_STATUS_BYTES + (int64_t)groups * 2 * ROWS * H * sizeof(u64);
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
     // zero the status word and every tag before each launch (tags start at 1)
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
     hipLaunchKernelGGL(lstm_encode_coop_kernel, dim3(groups * G), dim3(256), 0, s, nets,
-                       reinterpret_cast<u64*>(static_cast<char*>(workspace) + 256),
+                       reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES),
                        reinterpret_cast<unsigned*>(workspace), B, L, n_nets, groups_per_net,
                        gnnpn_option_lstm_ablate());
     return GNNPN_OK;

@@ -172,12 +172,15 @@ def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
         ops.set_option("lstm_impl", 2)
         out = ops.lstm_encode(args)
         out2 = ops.lstm_encode(args)       # back-to-back launches reuse the hand-off buffers
+        ops.set_option("lstm_ablate", 128)  # force the placement-independent (write-through) hand-off
+        out3 = ops.lstm_encode(args)
     finally:
         ops.set_option("lstm_impl", 0)
+        ops.set_option("lstm_ablate", 0)
     ops.check_status(dev)
     for n in range(nets):
-        for a, b, c in zip(ref, out, out2):
-            assert torch.equal(a[n], b[n]) and torch.equal(a[n], c[n])
+        for a, b, c, d in zip(ref, out, out2, out3):
+            assert torch.equal(a[n], b[n]) and torch.equal(a[n], c[n]) and torch.equal(a[n], d[n])
 
 
 def test_in_kernel_input_projection_equals_materialised(dev):

@@ -138,11 +138,15 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
         ops.set_option("decode_impl", 2)
         out = two_level_greedy(low, high, x)
         out2 = two_level_greedy(low, high, x)
+        ops.set_option("lstm_ablate", 128)      # force the placement-independent (write-through) hand-off
+        out3 = two_level_greedy(low, high, x)
     finally:
         ops.set_option("decode_impl", 0)
+        ops.set_option("lstm_ablate", 0)
     ops.check_status(dev)
     for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions", "action_probs"):
         assert torch.equal(out[k], out2[k]), k                    # deterministic across launches
+        assert torch.equal(out[k], out3[k]), k                    # and across the two hand-off paths
     win_ref = torch.stack([ref["win_low"], ref["win_high_raw"] + ref["win_low"]]).cpu()
     m = opn.decision_margin(win_ref[0], x.cpu()), opn.decision_margin(win_ref[1], x.cpu())
     robust = (m[0] > 1e-3).all(1) & (m[1] > 1e-3).all(1)

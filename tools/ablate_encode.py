@@ -44,3 +44,10 @@ names = ["sweep+LDS fill", "barrier 1", "A-frag reads + MFMA (+flush)", "project
 print("phase cycles per step (wg 0, wave 0):", {k: round(v / n) for k, v in zip(names, prof[:5])}, "steps", n,
       "total", round(sum(prof[:5]) / n))
 ops.set_option("lstm_ablate", 0)
+
+ops.set_option("lstm_ablate", 0)
+ops.lstm_encode(nets); torch.cuda.synchronize()
+ws = ops.encode_workspace(dev)
+print("status", int(ws[:4].view(torch.int32).item()), "workgroups on the same-XCD fast path:", int(ws[4:8].view(torch.int32).item()))
+timeit("write-through hand-off forced", 128)
+ops.set_option("lstm_ablate", 0)
