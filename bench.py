@@ -239,11 +239,24 @@ def main():
         kernels.append({"kernel": name, "launches_per_step": n // n_timed, "avg_ms": round(avg_ms, 4),
                         "bound": c["bound"], "achieved": round(achieved, 3), "peak": c["peak"], "unit": c["unit"],
                         "frac": round(achieved / c["peak"], 5)})
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
+    # profiles/r01_pmc_traffic.json, FETCH_SIZE doubled as the gfx950 guide prescribes; only quoted
+    # when this run is the workload those passes measured.
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if args.workload == "qws" and B == 256:
+            traffic = {k: v["traffic"] for k, v in pmc["kernels"].items()}
+    except (OSError, ValueError, KeyError):
+        pass
+    for k in kernels:
+        k["traffic"] = traffic.get(k["kernel"])
     roof = None
     if kernels:
         k0 = kernels[0]
         roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
-                "unit": k0["unit"], "frac": k0["frac"], "traffic": None}
+                "unit": k0["unit"], "frac": k0["frac"], "traffic": k0["traffic"]}
     line = {
         "metric": "service-composition problems/sec (ML+2PN inference)", "value": round(value, 2),
         "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
