@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as one HIP graph (default); 0: eager")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent steps (batches) in flight on separate HIP streams (needs --graph 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,26 +200,45 @@ def main():
         timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
         timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
 
-    run_once = pipe.capture(svc, batch) if args.graph else (lambda: pipe.run(svc, batch))
+    # Steps are independent batches.  Each of `inflight` slots is one captured HIP graph of the whole
+    # step with its own outputs and hand-off workspaces; step i replays slot i % inflight on that slot's
+    # stream, so the latency-bound recurrent kernels of one step overlap the next step's other kernels.
+    n_slots = max(1, args.inflight) if args.graph else 1
+    if args.graph:
+        slots = [pipe.capture(svc, batch, slot=s) for s in range(n_slots)]
+    else:
+        slots = [lambda: pipe.run(svc, batch)]
+    streams = [torch.cuda.Stream() for _ in range(n_slots)] if n_slots > 1 else [torch.cuda.current_stream()]
 
-    def step():
-        out = run_once()
-        if world > 1:
-            return gdist.all_gather_indices(out["idx_high"]), out["R"]
-        return out["idx_high"], out["R"]
+    def step(i):
+        s = i % n_slots
+        with torch.cuda.stream(streams[s]):
+            out = slots[s]()
+            if world > 1:
+                return gdist.all_gather_indices(out["idx_high"]), out["R"]
+            return out["idx_high"], out["R"]
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
     gdist.barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        idx, R = step()
+    for i in range(args.steps):
+        idx, R = step(i)
     torch.cuda.synchronize()
     gdist.barrier(world)
     elapsed = time.perf_counter() - t0
     elapsed = gdist.max_over_ranks(elapsed, dev, world)
     ops.check_status(dev)            # a timed-out hand-off would have invalidated the run
+    # self-check: every slot's (overlapped) result equals a plain eager run of the same batch
+    ref = pipe.run(svc, batch)
+    torch.cuda.synchronize()
+    if args.graph:
+        for s in range(n_slots):
+            o = slots[s].outputs
+            if not (torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])):
+                raise SystemExit(f"slot {s}: overlapped result differs from the eager run")
 
     # per-kernel durations: HIP events around the same launches, eager, after the timed region
     # (events cannot be read back from inside a replayed graph)
@@ -263,7 +284,8 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
-                   "launch": "hipGraph replay" if args.graph else "eager",
+                   "launch": (f"hipGraph replay, {n_slots} independent step(s) in flight on separate streams"
+                              if args.graph else "eager"),
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}"},
         "roofline": roof, "kernels": kernels,
     }

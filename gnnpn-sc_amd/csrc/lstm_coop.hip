@@ -29,15 +29,23 @@ constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
+constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + sentinels
 }  // namespace
 
 // Sweep this wave's quarter (rows 4w..4w+3, all 256 units) of one parity buffer until every
 // granule carries `tag`; values go to LDS.  Returns false on timeout.
-__device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, float* hs, int wave, int lane,
-                                              bool keep, bool nowait = false) {
+// The first pass is optimistic (peers run in lock step, so it normally succeeds).  If it does not,
+// the wave does NOT keep re-reading its 1024 granules — with two launches sharing the CUs that
+// polling traffic (8 KB per wave per pass) swamps the L2 and slows the very peers it waits for.
+// Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
+// growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
+// a hint when to sweep again, validity is still decided by the granules' own tags.
+__device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
+                                              int wave, int lane, bool keep, bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
     unsigned v[16];
-    for (unsigned spins = 0;; ++spins) {
+    unsigned spins = 0;
+    for (;;) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -46,8 +54,16 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
             ok &= (unsigned)(x >> 32) == tag;
         }
         if (__all(ok) || nowait) break;
-        if (spins > SPIN_LIMIT) return false;
-        __builtin_amdgcn_s_sleep(1);
+        int nap = 1;
+        for (;;) {                                           // wait for the hint
+            bool seen = true;
+            if (lane < 4 * G) seen = (unsigned)(granule_load(sentinels + lane) >> 32) >= tag;
+            if (__all(seen)) break;
+            if (++spins > SPIN_LIMIT) return false;
+            for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+            if (nap < 16) nap <<= 1;
+        }
+        if (++spins > SPIN_LIMIT) return false;
     }
     if (keep) {
 #pragma unroll
@@ -59,7 +75,7 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
     return true;
 }
 
-__global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
+__global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
                                                                   int n_nets, int groups_per_net, int ablate) {
     __shared__ float hs[ROWS * LDH];
@@ -88,7 +104,8 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
     const float* __restrict__ xin = nets.inputs[net];     // used when pre == nullptr (F = 8)
     const float* __restrict__ Wp = nets.whh[net];
     float* __restrict__ enc = nets.enc_out[net];
-    u64* xg = xchg + (size_t)group * (2 * ROWS * H);
+    u64* xg = xchg + (size_t)group * GROUP_GRANULES;
+    u64* sent = xg + 2 * ROWS * H;                        // [parity][4*G] sentinels
 
     // this lane's two gate columns: tile 0 = [i | f], tile 1 = [g | o], 8 units per wave
     const int unit = member * UNITS + wave * 8 + (c & 7);
@@ -154,9 +171,9 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
             bool ok = true;
             if (t == 0) {
                 for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
-                if (!first_tile) ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
+                if (!first_tile) ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
             } else if (!(ablate & 8)) {
-                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true, ablate & 4);
+                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
             if (stamps) s1 = phase_stamp();
@@ -208,6 +225,8 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
                     hst[row][wave * 8 + (c & 7)] = hlast[r];
                 }
             }
+            if (lane == 0 && !(ablate & 16))                    // hint for waiting peers (see sweep_quarter)
+                granule_publish(sent + (step & 1) * (4 * G) + member * 4 + wave, step + 1, 0.0f, same_xcd);
             if (stamps) {
                 asm volatile("" ::"v"(hlast[3]));
                 s5 = phase_stamp();
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void lstm_encode_coop_kernel(LstmNets nets,
 // workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
 // stamps, hello granules), then the exchange buffers
 extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
-    return COOP_STATUS_BYTES + (int64_t)64 * 2 * ROWS * H * sizeof(u64);   // up to 64 groups
+    return COOP_STATUS_BYTES + (int64_t)64 * GROUP_GRANULES * sizeof(u64);   // up to 64 groups
 }
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
@@ -266,7 +285,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     const int groups = gpx * 8;
     if (groups < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups, n_nets);
     const int groups_per_net = groups / n_nets;
-    const int64_t need = COOP_STATUS_BYTES + (int64_t)groups * 2 * ROWS * H * sizeof(u64);
+    const int64_t need = COOP_STATUS_BYTES + (int64_t)groups * GROUP_GRANULES * sizeof(u64);
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
     // zero the status word and every tag before each launch (tags start at 1)

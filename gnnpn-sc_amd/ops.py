@@ -118,6 +118,14 @@ def pack_lstm_weight(w):
 
 _workspaces = {}
 _options = {}
+_slot = 0
+
+
+def set_workspace_slot(slot):
+    """Cooperative kernels of launches that may be in flight at the same time (two pipelined steps on
+    two streams) must not share hand-off buffers: select the workspace set used by subsequent calls."""
+    global _slot
+    _slot = int(slot)
 
 
 def set_option(name, value):
@@ -128,7 +136,7 @@ def set_option(name, value):
 
 def encode_workspace(device):
     """Per-device workspace of the cooperative encoder (status word + hand-off buffers)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, "encode", _slot)
     if key not in _workspaces:
         n = int(_lib.load().gnnpn_lstm_encode_workspace_bytes())
         _workspaces[key] = torch.zeros(n, dtype=torch.uint8, device=device)
@@ -198,7 +206,7 @@ def lstm_encode(nets):
 
 def decode_workspace(device, B, T, n_per):
     """Per-device workspace of the cooperative decoder, grown on demand."""
-    key = (device.type, device.index, "decode")
+    key = (device.type, device.index, "decode", _slot)
     need = int(_lib.load().gnnpn_pointer_decode_workspace_bytes(B, T, n_per))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:

@@ -102,21 +102,26 @@ class ML2PNPipeline:
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
-    def capture(self, services, batch, warmup=2):
+    def capture(self, services, batch, warmup=2, slot=0):
         """Record one whole pass over (services, batch) into a HIP graph and return a callable that
-        replays it (one launch per step instead of ~25).  The returned dict's tensors are the
-        graph's static outputs: they are overwritten by every replay.  All kernels already run on
-        the current stream with caller-visible workspaces, so stream capture needs nothing else."""
-        stream = torch.cuda.Stream()
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
-            for _ in range(warmup):              # allocate workspaces / pack weights outside the capture
-                self.run(services, batch)
-        torch.cuda.current_stream().wait_stream(stream)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.run(services, batch)
+        replays it on the CURRENT stream (one launch per step instead of ~25).  The returned dict's
+        tensors are the graph's static outputs: they are overwritten by every replay.  ``slot``
+        selects a private set of cooperative-kernel workspaces, so that graphs of different slots
+        may be in flight at the same time on different streams (independent batches pipelined)."""
+        ops.set_workspace_slot(slot)
+        try:
+            stream = torch.cuda.Stream()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                for _ in range(warmup):          # allocate workspaces / pack weights outside the capture
+                    self.run(services, batch)
+            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.run(services, batch)
+        finally:
+            ops.set_workspace_slot(0)
 
         def replay():
             graph.replay()
