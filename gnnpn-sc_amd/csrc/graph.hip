@@ -13,7 +13,12 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(
     const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     float* __restrict__ y, int64_t ldy, int32_t n_rows, int32_t C) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so give every
+    // XCD one CONTIGUOUS range of destination rows — neighbouring rows share source rows (always true
+    // for the block-diagonal batch of service graphs), which then hit that XCD's own L2.
+    const int nb = gridDim.x, q = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    const int blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    const int row = blk * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const int e_begin = rowptr[row], e_end = rowptr[row + 1];
     constexpr int V = VEC4 ? 4 : 1;

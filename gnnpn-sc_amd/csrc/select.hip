@@ -126,3 +126,30 @@ extern "C" int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* 
     GNNPN_CHECK_LAUNCH("rank_rows");
     return GNNPN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// P@k of TrainML.test (trainML.py:63-70): fraction of the top-k ranked services whose label is 1.
+__global__ void precision_at_k_kernel(const int32_t* __restrict__ ranking, int64_t ld_rank,
+                                      const float* __restrict__ labels, int64_t ld_lab, int32_t B, int32_t S,
+                                      const int32_t* __restrict__ ks, int32_t n_k, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_k) return;
+    const int b = i / n_k, k = ks[i - b * n_k];
+    int hits = 0;
+    for (int j = 0; j < k && j < S; ++j) {
+        const int s = ranking[(int64_t)b * ld_rank + j];
+        hits += (s >= 0 && s < S && labels[(int64_t)b * ld_lab + s] == 1.0f);
+    }
+    out[i] = (float)hits / (float)k;
+}
+
+extern "C" int gnnpn_precision_at_k(const int32_t* ranking, int64_t ld_rank, const float* labels, int64_t ld_lab,
+                                    int32_t B, int32_t S, const int32_t* ks, int32_t n_k, float* out, void* stream) {
+    GNNPN_REQUIRE(ranking && labels && ks && out, "precision_at_k: null operand");
+    GNNPN_REQUIRE(B >= 0 && S > 0 && n_k > 0 && ld_rank >= 1 && ld_lab >= S, "precision_at_k: bad shape");
+    if (B == 0) return GNNPN_OK;
+    hipLaunchKernelGGL(precision_at_k_kernel, dim3((B * n_k + 127) / 128), dim3(128), 0, (hipStream_t)stream, ranking,
+                       ld_rank, labels, ld_lab, B, S, ks, n_k, out);
+    GNNPN_CHECK_LAUNCH("precision_at_k");
+    return GNNPN_OK;
+}

@@ -1,0 +1,46 @@
+"""The two-level evaluation harness of the reference's PNHigh driver
+(/root/reference/src/models/trainPNHigh.py): ``SCDataset`` (:15-41) and the eval block of
+``TrainModel.train_and_validate`` (:131-144) — Low greedy -> latent -> High greedy per batch of 128,
+actions accumulated as ``allActions[T][nTest][8]`` (the artefact ``ML2PN.check`` reads).  Training
+(:76-112) is out of scope.
+"""
+import torch
+
+from .modelPN import two_level_greedy
+
+
+class SCDataset(torch.utils.data.Dataset):
+    """trainPNHigh.py:15-41.  ``dataset`` = loadDataPN rows [P][L][9]; with embeddingTag=False column 0
+    (the category id) is dropped -> FloatTensor [L,8] per problem."""
+
+    def __init__(self, dataset, targets, embeddingTag=False):
+        super().__init__()
+        if embeddingTag:
+            raise NotImplementedError("embeddingTag=1 is outside the ML+2PN inference configuration")
+        self.data_set = [torch.FloatTensor([row[1:] for row in rows]) for rows in dataset]
+        self.label = list(targets)
+        self.serviceNumbers = [0] * len(self.data_set)
+        self.size = len(self.data_set)
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, idx):
+        return self.data_set[idx], self.label[idx]
+
+
+@torch.no_grad()
+def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device="cuda:0"):
+    """trainPNHigh.py:131-144: -> (allActions [T][n][8] python lists, val_tour = mean R per batch)."""
+    dev = torch.device(device)
+    all_actions = [[] for _ in range(serCategory)]
+    val_tour = []
+    for lo in range(0, len(val_dataset), batch_size):
+        items = [val_dataset[i][0] for i in range(lo, min(len(val_dataset), lo + batch_size))]
+        inputs = torch.stack(items).to(dev)
+        out = two_level_greedy(low_model, model, inputs)
+        act = out["actions"].cpu().numpy()
+        for a in range(serCategory):
+            all_actions[a] += act[:, a, :].tolist()
+        val_tour.append(float(out["R"].mean().item()))
+    return all_actions, val_tour

@@ -107,6 +107,17 @@ def rank_rows(scores):
     return ranking
 
 
+def precision_at_k(ranking, labels, ks=(1, 5)):
+    """[B, n_k] fraction of the top-k ranked services with label 1 (trainML.py:63-70)."""
+    B, S = labels.shape
+    kt = torch.tensor(list(ks), dtype=I32, device=labels.device)
+    out = torch.empty((B, len(ks)), dtype=F32, device=labels.device)
+    check(_lib.load().gnnpn_precision_at_k(dev_ptr(ranking, I32, "ranking"), ranking.shape[1],
+                                           dev_ptr(labels, F32, "labels"), S, B, S, dev_ptr(kt, I32, "ks"), len(ks),
+                                           dev_ptr(out, F32, "out"), stream_ptr()), "gnnpn_precision_at_k")
+    return out
+
+
 def pack_lstm_weight(w):
     """[4H, H] (gate-major rows, torch.nn.LSTM layout) -> [H/4, 4, H, 4]: element [k4][g][j][i] =
     w[g*H + j][4*k4 + i].  A one-time layout change at weight-load time (no arithmetic)."""

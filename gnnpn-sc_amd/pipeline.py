@@ -133,3 +133,11 @@ class ML2PNPipeline:
     def rankings(self, services, batch):
         """The artefact TrainML.test writes (trainML.py:62-68,148-149): full ranking per problem."""
         return ops.rank_rows(self.scores(services, batch))
+
+    @torch.no_grad()
+    def test(self, services, batch, labels):
+        """TrainML.test (trainML.py:49-72): (idxList = full ranking per problem, [P@1, P@5]).
+        ``labels`` [B,S] 0/1 (float32 device tensor).  Rankings stay on the device (int32 [B,S])."""
+        ranking = self.rankings(services, batch)
+        pk = ops.precision_at_k(ranking, labels.float().contiguous(), (1, 5))
+        return ranking, [float(v) for v in pk.mean(0).tolist()]

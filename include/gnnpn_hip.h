@@ -115,6 +115,12 @@ int gnnpn_select_candidates(const float* scores, int64_t ld_scores, const int32_
 int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
                     void* stream);
 
+/* P@k: out[b, i] = #(labels[b, ranking[b, j]] == 1 for j < ks[i]) / ks[i].  ranking [B, >=max k]
+ * int32, labels [B,S] fp32 (0/1), ks [n_k] int32 (device), out [B, n_k] fp32.
+ * Replaces the P@1 / P@5 loop of TrainML.test (src/models/trainML.py:63-70). */
+int gnnpn_precision_at_k(const int32_t* ranking, int64_t ld_rank, const float* labels, int64_t ld_lab,
+                         int32_t B, int32_t S, const int32_t* ks, int32_t n_k, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pointer-network LSTM encoder recurrence for `n_nets` independent nets in one launch
  * (Low and High encoders are independent given the inputs).  Per net (gnnpn_encode_net_t):

@@ -161,3 +161,44 @@ def test_full_size_properties(dev):
         pb.present[::-1].copy(), pb.global_bounds[::-1].copy()), dev)
     out3 = pipe.run(svc, rev)
     assert torch.equal(out3["idx_high"].flip(0), out["idx_high"]) and torch.equal(out3["R"].flip(0), out["R"])
+
+
+def test_trainml_test_and_eval_block_mirrors(dev):
+    """TrainML.test (rankings + P@1/P@5) and the PNHigh eval block (SCDataset + allActions) on a dataset in
+    the reference's JSON format, against the oracle."""
+    import json, os
+    from conftest import GOLDEN
+    from gnnpn_sc_amd import loadData as ld
+    from gnnpn_sc_amd.evalPN import SCDataset, evaluate
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
+    fx = json.load(open(os.path.join(GOLDEN, "data_small.json")))
+    ds, K, T, S, P = fx["dataset"], fx["K"], fx["T"], fx["S"], fx["P"]
+    table, pb = ld.tables_from_dataset(ds)
+    sd_ml = oml.make_state_dict(128, 20, 2, 2, seed=3)
+    net = Net(128, S, 20, 2, 2)
+    net.load_state_dict(sd_ml)
+    H = 32
+    low = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="Low")
+    high = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="High")
+    low.load_state_dict(opn.make_state_dict(H, 1))
+    high.load_state_dict(opn.make_state_dict(H, 2))
+    pipe = ML2PNPipeline(net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval(), K)
+    labels = torch.tensor(ds["labels"], dtype=torch.float32)
+    ranking, (p1, p5) = pipe.test(DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev),
+                                  labels.to(dev))
+    want_p = oml.precision_at(ranking.cpu().long(), labels)
+    assert abs(p1 - want_p[0]) < 1e-6 and abs(p5 - want_p[1]) < 1e-6
+    assert sorted(ranking[0].tolist()) == list(range(S))
+    # eval block on the reference-format rows of the shared-ranking reduction
+    val = SCDataset(fx["rows_shared"], ds["minCostList"])
+    assert len(val) == P and val[0][0].shape == (T * K, 8) and val[0][1] == ds["minCostList"][0]
+    acts, tour = evaluate(low, high, val, T, batch_size=5, device=str(dev))
+    assert len(acts) == T and len(acts[0]) == P and len(acts[0][0]) == 8 and len(tour) == 4
+    x = torch.stack([val[i][0] for i in range(P)])
+    ref = opn.two_level_greedy(opn.make_state_dict(H, 1), opn.make_state_dict(H, 2), x, T, K)
+    robust = robust_problems(ref["margin_low"], ref["margin_high"])
+    got = torch.tensor(acts).permute(1, 0, 2)                      # [P,T,8]
+    same = (got == ref["actions"]).all(-1).all(-1)
+    assert bool(same[robust].all()) and bool(robust.any())
