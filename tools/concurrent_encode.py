@@ -29,3 +29,21 @@ def run(n_streams, reps=20):
     print(f"{n_streams} stream(s): {ms:.3f} ms per encode launch (2 nets x 256 problems)")
 run(1); run(2); run(3)
 ops.check_status(dev)
+
+# phase stamps while two launches share the CUs
+names = ["sweep+LDS fill", "barrier 1", "A-frag reads + MFMA (+flush)", "projection + barrier 2", "cell + publish"]
+ops.set_option("lstm_ablate", 32)
+streams = [torch.cuda.Stream() for _ in range(2)]
+for rep in range(3):
+    for i in range(2):
+        ops.set_workspace_slot(i)
+        with torch.cuda.stream(streams[i]): ops.lstm_encode(nets)
+torch.cuda.synchronize()
+for i in range(2):
+    ops.set_workspace_slot(i)
+    ws = ops.encode_workspace(dev)
+    prof = ws[32:32 + 48].view(torch.int64).cpu().tolist()
+    n = max(prof[5], 1)
+    print(f"slot {i} (co-running):", {k: round(v / n) for k, v in zip(names, prof[:5])}, "total", round(sum(prof[:5]) / n))
+ops.set_workspace_slot(0)
+ops.set_option("lstm_ablate", 0)
