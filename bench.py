@@ -211,6 +211,8 @@ def main():
     # region cost ~25 % throughput), so the per-kernel durations come from a separate eager pass on one
     # stream right after the timed region; --graph 0 records them inside the timed region instead.
     n_slots = max(1, args.inflight)
+    if n_slots > 1 and args.graph:
+        ops.set_option("decode_impl", 3)   # 256-register decoder: shares the SIMDs with the other step's encoder
     streams = [torch.cuda.Stream() for _ in range(n_slots)]
     if args.graph:
         slots = [pipe.capture(svc, batch, slot=s) for s in range(n_slots)]
@@ -251,7 +253,7 @@ def main():
     elapsed = gdist.max_over_ranks(elapsed, dev, world)
     ops.check_status(dev)            # a timed-out hand-off would have invalidated the run
     # self-check: every slot's (overlapped) result equals a plain single-stream run of the same batch
-    ref = pipe.run(svc, batch)
+    ref = pipe.run(svc, batch)           # same kernels (same decode_impl), one stream, nothing overlapped
     torch.cuda.synchronize()
     for s in range(n_slots):
         o = last[s]
@@ -267,6 +269,7 @@ def main():
             pipe.run(svc, batch)
         torch.cuda.synchronize()
         timers.enabled = False
+    ops.set_option("decode_impl", 0)
 
     if rank != 0:
         gdist.destroy(world)

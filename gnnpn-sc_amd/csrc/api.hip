@@ -26,7 +26,7 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
         return GNNPN_OK;
     }
     if (!strcmp(name, "decode_impl")) {
-        GNNPN_REQUIRE(value >= 0 && value <= 2, "set_option: decode_impl must be 0 (auto), 1 (streaming) or 2 (cooperative)");
+        GNNPN_REQUIRE(value >= 0 && value <= 3, "set_option: decode_impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups) or 3 (16-CU groups)");
         g_decode_impl = value;
         return GNNPN_OK;
     }

@@ -196,9 +196,19 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     args.K = n_per;
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int impl = gnnpn_option_decode_impl();   // 0 auto, 1 streaming, 2 cooperative
-    if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl == 2)) {
-        const int rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+    const int impl = gnnpn_option_decode_impl();   // 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 (16-CU groups)
+    if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl >= 2)) {
+        // auto / 2: 8-member groups — fastest when the launch has the GPU to itself (0.32 ms at QWS B=256).
+        // 3: 16-member groups — 0.52 ms alone, but 256 registers, i.e. it shares every SIMD with a wave of the
+        // cooperative encoder of ANOTHER batch in flight on a second stream (bench.py turns it on when it
+        // pipelines two steps: 1.345 -> 1.313 ms/step).
+        int rc;
+        if (impl == 3) {
+            rc = gnnpn_launch_decode_coop2(args, n_nets, workspace, workspace_bytes, s);
+            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+        } else {
+            rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+        }
         if (rc != GNNPN_OK) return rc;
         GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
         return GNNPN_OK;

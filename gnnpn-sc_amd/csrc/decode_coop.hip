@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     __shared__ float hs[ROWS * LDH];
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
-    __shared__ float part[ROWS][KMAX][G];
+    __shared__ float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [member][row%4][cand]
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
     __shared__ float xin[FOLDX ? 1 : ROWS][8];
@@ -152,17 +152,10 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 const int par = (step - 1) & 1;
                 {
                     const u64* src_h = xh_g + par * (ROWS * H) + wave * 4 * H;
-                    const u64* src_p = xp_g + par * (G * ROWS * K);
+                    const u64* src_p = xp_g + par * (G * ROWS * K) + wave * (G * 4 * K);   // [quarter][member][row%4][cand]
                     const u64* src_l = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
                     const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all members
                     const int n_l = 4 * K;
-                    int p_at[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int q = lane + 64 * j;
-                        const int m = q / (4 * K), rem = q - m * 4 * K;
-                        p_at[j] = (m * ROWS + wave * 4 + rem / K) * K + rem % K;
-                    }
                     unsigned vh[16], vp[8], vl = 0;
                     bool ok = false;
                     for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
@@ -176,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             if (lane + 64 * j < n_p) {
-                                const u64 x = granule_load(src_p + p_at[j]);
+                                const u64 x = granule_load(src_p + lane + 64 * j);
                                 vp[j] = (unsigned)x;
                                 good &= (unsigned)(x >> 32) == tag;
                             }
@@ -200,11 +193,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int q = lane + 64 * j;
-                        if (q < n_p) {
-                            const int m = q / (4 * K), rem = q - m * 4 * K;
-                            part[wave * 4 + rem / K][rem % K][m] = __uint_as_float(vp[j]);
-                        }
+                        if (lane + 64 * j < n_p) part_lin[wave][lane + 64 * j] = __uint_as_float(vp[j]);
                     }
                     if (lane < n_l) {
                         float lv = 0.0f;
@@ -228,9 +217,9 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     const bool live = r < K;
                     float dot = 0.0f;
                     if (live) {
-                        dot = part[row][r][0];
+                        dot = part_lin[wave][kq * K + r];
 #pragma unroll
-                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part[row][r][m]);   // member order
+                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part_lin[wave][(m * 4 + kq) * K + r]);   // member order
                     }
                     // C*tanh with the device-library tanhf: these values decide the pick
                     float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;
@@ -393,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     p = fmaf(ev[j].z, hv.z, p);
                     p = fmaf(ev[j].w, hv.w, p);
                 }
-                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + (member * ROWS + prow) * K + pcand, step + 1, p, same_xcd);
+                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + (((prow >> 2) * G + member) * 4 + (prow & 3)) * K + pcand, step + 1, p, same_xcd);
             }
             if (stamps) {
                 st[7] = phase_stamp();
@@ -418,8 +407,10 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
     const int64_t groups = 64, tiles = (B + ROWS - 1) / ROWS;
-    return COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
-           tiles * T * ROWS * (int64_t)n_per * 8;
+    const int64_t a8 = COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
+                       tiles * T * ROWS * (int64_t)n_per * 8;
+    const int64_t a16 = gnnpn_decode_coop2_workspace_bytes(B, T, n_per);
+    return a8 > a16 ? a8 : a16;
 }
 
 bool gnnpn_decode_coop_supported(int32_t H_, int32_t n_per) { return H_ == H && n_per <= KMAX; }

@@ -135,7 +135,9 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     try:
         ops.set_option("decode_impl", 1)
         ref = two_level_greedy(low, high, x)
-        ops.set_option("decode_impl", 2)
+        ops.set_option("decode_impl", 2)          # 8-CU groups
+        out8 = two_level_greedy(low, high, x)
+        ops.set_option("decode_impl", 3)          # 16-CU groups (256 registers: co-resident with an encoder wave)
         out = two_level_greedy(low, high, x)
         out2 = two_level_greedy(low, high, x)
         ops.set_option("lstm_ablate", 128)      # force the placement-independent (write-through) hand-off
@@ -158,6 +160,10 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     assert float((out["win_high_raw"][s] - ref["win_high_raw"][s]).abs().max()) < 1e-4
     assert float((out["R"][s] - ref["R"][s]).abs().max()) <= R_ATOL
     assert float((out["action_probs"][s] - ref["action_probs"][s]).abs().max()) < 1e-4
+    s8 = (assert_index_parity(out8["idx_low"], ref["idx_low"], robust, "coop8/low", 0.8, x.cpu()) &
+          assert_index_parity(out8["idx_high"], ref["idx_high"], robust, "coop8/high", 0.8, x.cpu())).to(dev)
+    assert float((out8["win_low"][s8] - ref["win_low"][s8]).abs().max()) < 1e-4
+    assert float((out8["R"][s8] - ref["R"][s8]).abs().max()) <= R_ATOL
 
 
 @pytest.mark.parametrize("name", ["qws", "normal"])
