@@ -154,7 +154,8 @@ def test_lstm_encode_vs_torch(dev, H, B, L):
     assert torch.equal(enc[0], enc[1])      # two nets in one launch are independent and deterministic
 
 
-@pytest.mark.parametrize("B,L,nets", [(16, 12, 1), (37, 30, 2), (256, 235, 2), (300, 20, 3), (1040, 9, 2)])
+@pytest.mark.parametrize("B,L,nets", [(1, 1, 1), (17, 3, 2), (16, 12, 1), (37, 30, 2), (256, 235, 2), (300, 20, 3),
+                                      (1040, 9, 2), (530, 7, 4)])
 def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
     """The cooperative form (weights in registers, per-step granule hand-off between 8 CUs) and the
     per-workgroup streaming form are the same k-ordered fp32 fma chains: bit-identical outputs.

@@ -117,7 +117,8 @@ def test_fresh_oracle_batch(dev):
     assert float((out["R"].cpu()[s] - ref["R"][s]).abs().max()) <= R_ATOL
 
 
-@pytest.mark.parametrize("B,T,K", [(16, 6, 3), (40, 47, 5), (256, 47, 5), (300, 12, 10), (23, 9, 16)])
+@pytest.mark.parametrize("B,T,K", [(1, 3, 1), (17, 1, 4), (16, 6, 3), (40, 47, 5), (256, 47, 5), (300, 12, 10),
+                                   (23, 9, 16), (530, 5, 8)])
 def test_decode_cooperative_vs_streaming(dev, B, T, K):
     """Cooperative decoder (both nets in one launch, weights in registers, per-step hand-off) vs the
     per-workgroup streaming decoder on the same encoder outputs.  The LSTM cells are the same fma
