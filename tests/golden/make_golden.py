@@ -73,8 +73,15 @@ def pn_inputs(B, T, K, seed, dummy_every=0):
     return torch.from_numpy(x)
 
 
-def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0):
+def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0, weight_scale=1.0):
     sd_low, sd_high = opn.make_state_dict(H, seed), opn.make_state_dict(H, seed + 1)
+    if weight_scale != 1.0:
+        # large recurrent weights drive |dot| past ~9 where 10*tanh(x) rounds to exactly 10.0f: exact ties
+        # inside a window, which torch.max resolves to the FIRST maximum (SURVEY.md §7 "hard parts" (i))
+        for sd in (sd_low, sd_high):
+            for k in sd:
+                if "encoder" in k or "decoder." in k:
+                    sd[k] = sd[k] * weight_scale
     L = T * K
 
     def build(level, sd):
@@ -103,11 +110,12 @@ def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0):
     lat1 = latent[1]
     assert torch.isinf(lat1[torch.arange(B), idx_low[0]]).all()
     out = {k: v.numpy() for k, v in ref.items()}
-    out.update(inputs=x.numpy(), hidden=H, n_cat=T, n_per=K, seed_low=seed, seed_high=seed + 1,
+    out.update(inputs=x.numpy(), hidden=H, n_cat=T, n_per=K, seed_low=seed, seed_high=seed + 1, weight_scale=weight_scale,
                margin_low=orc["margin_low"].numpy(), margin_high=orc["margin_high"].numpy(),
                latent_step1=lat1.numpy())
     np.savez_compressed(os.path.join(HERE, f"pn_{name}.npz"), **out)
-    print(f"pn_{name}: B={B} T={T} K={K} H={H} min margin low/high = "
+    n_tie = int((ref["win_low"] == 10.0).sum() + (ref["win_low"] == -10.0).sum())
+    print(f"pn_{name}: B={B} T={T} K={K} H={H} saturated window logits: {n_tie}; min margin low/high = "
           f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
 
 
@@ -274,6 +282,7 @@ def main():
     gen_pn(modelPN, "dummy", H=32, T=7, K=2, B=3, seed=21, dummy_every=3)
     gen_pn(modelPN, "qws", H=256, T=47, K=5, B=8, seed=31)
     gen_pn(modelPN, "normal", H=256, T=50, K=10, B=4, seed=41)
+    gen_pn(modelPN, "saturated", H=256, T=12, K=5, B=8, seed=51, weight_scale=6.0)
     gen_reward(modelPN)
     gen_data(loadData_mod, ML2PN_mod)
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)

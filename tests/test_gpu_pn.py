@@ -185,3 +185,57 @@ def test_folded_vs_two_stage_input_projection(dev, name):
         assert np.abs(out["win_low"].cpu().numpy()[s] - fx["win_low"][s]).max() < LOGIT_ATOL
     same = ((a["idx_low"] == b["idx_low"]).all(1) & (a["idx_high"] == b["idx_high"]).all(1))
     assert float((a["win_low"][same] - b["win_low"][same]).abs().max()) < LOGIT_ATOL
+
+
+def test_saturated_logits_first_max_wins(dev):
+    """10*tanh(x) rounds to exactly 10.0f once |x| is large: exact ties inside a window, which torch.max
+    (CPU) resolves to the FIRST maximum.  Fixture pn_saturated (recurrent weights x6, generated by the
+    reference) has such ties; both cooperative decoder forms and the streaming form must make the same
+    pick wherever they see the same tie."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
+    fx = golden("pn_saturated.npz")
+    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    nets = []
+    for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
+        sd = opn.make_state_dict(H, seed)
+        for k in sd:
+            if "encoder" in k or "decoder." in k:
+                sd[k] = sd[k] * float(fx["weight_scale"])
+        m = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level=level)
+        m.load_state_dict(sd)
+        nets.append(m.to(dev).eval())
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    ties_checked = 0
+    try:
+        for impl in (1, 2, 3):
+            ops.set_option("decode_impl", impl)
+            out = two_level_greedy(nets[0], nets[1], x, fold=False)    # literal two-stage order: closest to the fixture
+            got_low, win = out["idx_low"].cpu().numpy(), out["win_low"].cpu().numpy()
+            for b in range(x.shape[0]):
+                for t in range(T):
+                    if (got_low[b, :t] != fx["idx_low"][b, :t]).any():
+                        break                                           # history diverged: later steps not comparable
+                    w_ref, w_got = fx["win_low"][b, t], win[b, t]
+                    top = w_ref.max()
+                    if (w_ref == top).sum() >= 2 and (w_got == w_got.max()).sum() >= 2 and \
+                            np.array_equal(w_got == w_got.max(), w_ref == top):
+                        assert got_low[b, t] == fx["idx_low"][b, t] == t * K + int(np.argmax(w_ref == top))
+                        ties_checked += 1
+    finally:
+        ops.set_option("decode_impl", 0)
+    assert ties_checked >= 3, f"only {ties_checked} exact ties were comparable"
+
+
+def test_all_dummy_problem_gives_nan_reward_like_numpy(dev):
+    """A problem whose every action is a dummy row has no real service: the reference divides by zero
+    (modelPN.py:29, numpy float32 -> nan, and round(nan) stays nan); so does the kernel."""
+    from gnnpn_sc_amd import ops
+    act = torch.zeros(2, 4, 8)
+    act[:, :, 0:4] = torch.tensor([0.0, 1.0, 1.0, 1.0])
+    act[1, 2, 0] = 0.3                                   # second problem has one real service
+    act[:, 0, 4:8] = torch.tensor([0.5, 1.0, 0.5, 1.0])
+    want = opn.reward([act[:, t] for t in range(4)], "High")
+    got = ops.qos_reward(act.to(dev), "High").cpu()
+    assert torch.isnan(want[0]) and torch.isnan(got[0])
+    assert abs(float(got[1]) - float(want[1])) <= R_ATOL

@@ -13,13 +13,18 @@ from oracle import ml as oml
 from oracle import pn as opn
 
 
-@pytest.mark.parametrize("name", ["small", "dummy", "qws", "normal"])
+@pytest.mark.parametrize("name", ["small", "dummy", "qws", "normal", "saturated"])
 def test_pn_oracle_reproduces_reference(name):
     fx = golden(f"pn_{name}.npz")
     torch.set_num_threads(1)
     H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
-    out = opn.two_level_greedy(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])),
-                               torch.from_numpy(fx["inputs"]), T, K)
+    sds = [opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"]))]
+    scale = float(fx["weight_scale"]) if "weight_scale" in fx.files else 1.0
+    for sd in sds:
+        for k in sd:
+            if scale != 1.0 and ("encoder" in k or "decoder." in k):
+                sd[k] = sd[k] * scale
+    out = opn.two_level_greedy(sds[0], sds[1], torch.from_numpy(fx["inputs"]), T, K)
     assert np.array_equal(out["idx_low"].numpy(), fx["idx_low"])
     assert np.array_equal(out["idx_high"].numpy(), fx["idx_high"])
     assert np.array_equal(out["actions"].numpy(), fx["actions"])
