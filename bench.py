@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="f16: opt-in fp16-operand encoder (BASELINE configs[4]); NOT the headline dtype — the line "
+                         "then carries the agreement with the f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", type=int, default=1,
@@ -194,7 +197,7 @@ def main():
     w["E"] = int(table.edge_index.shape[1]) + S            # + self loops
     pb = synth.make_problem_batch(table, B, seed=1 + rank, tasks_per_problem=w["n_t"])
     net, low, high = build_models(T, S, K, dev, w["n_gcn"])
-    pipe = ML2PNPipeline(net, low, high, K)
+    pipe = ML2PNPipeline(net, low, high, K, precision=args.precision)
     svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
 
     timers = KernelTimers()
@@ -255,6 +258,14 @@ def main():
     # self-check: every slot's (overlapped) result equals a plain single-stream run of the same batch
     ref = pipe.run(svc, batch)           # same kernels (same decode_impl), one stream, nothing overlapped
     torch.cuda.synchronize()
+    agreement = None
+    if args.precision != "f32":       # agreement of the reduced-precision mode with the f32 path: same batch,
+        r32 = ML2PNPipeline(net, low, high, K).run(svc, batch)   # same kernels otherwise; compared on the SELECTED
+        torch.cuda.synchronize()                                  # rows (dummy / duplicate candidates are one selection)
+        same = (ref["actions"] == r32["actions"]).all(-1)
+        agreement = {"problems_with_identical_selection": round(float(same.all(1).float().mean()), 4),
+                     "identical_decisions": round(float(same.float().mean()), 5),
+                     "mean_abs_R_diff": round(float((ref["R"] - r32["R"]).abs().mean()), 6)}
     for s in range(n_slots):
         o = last[s]
         if o is not None and not (torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])):
@@ -306,7 +317,8 @@ def main():
         "metric": "service-composition problems/sec (ML+2PN inference)", "value": round(value, 2),
         "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16 encoder operands / f32 rest",
+        "data": "synthetic",
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
                    "launch": (f"{'hipGraph replay' if args.graph else 'eager'}, {n_slots} independent step(s) "
                               f"in flight on separate HIP streams"),
@@ -316,6 +328,8 @@ def main():
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}"},
         "roofline": roof, "kernels": kernels,
     }
+    if agreement is not None:
+        line["agreement_vs_f32"] = agreement
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, table, pb, net, low, high)
     print(json.dumps(line), flush=True)

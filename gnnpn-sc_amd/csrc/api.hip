@@ -9,7 +9,8 @@ extern "C" int gnnpn_abi_version(void) { return GNNPN_ABI_VERSION; }
 extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 
 // ---- run-time options (A/B switches for tests and benchmarks) ---------------------------------
-static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0;
+static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0, g_lstm_precision = 0;
+int gnnpn_option_lstm_precision() { return g_lstm_precision; }
 int gnnpn_option_lstm_ablate() { return g_lstm_ablate; }
 int gnnpn_option_lstm_impl() { return g_lstm_impl; }
 int gnnpn_option_decode_impl() { return g_decode_impl; }
@@ -23,6 +24,11 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "lstm_ablate")) {   // bit0 no MFMA, bit1 no transcendentals, bit2 no tag wait, bit3 no sweep, bit4 no publish
         g_lstm_ablate = value;
+        return GNNPN_OK;
+    }
+    if (!strcmp(name, "lstm_precision")) {   // 0 fp32, 1 fp16 operands in the encoder's recurrent product (cooperative form)
+        GNNPN_REQUIRE(value == 0 || value == 1, "set_option: lstm_precision must be 0 (fp32) or 1 (fp16)");
+        g_lstm_precision = value;
         return GNNPN_OK;
     }
     if (!strcmp(name, "decode_impl")) {

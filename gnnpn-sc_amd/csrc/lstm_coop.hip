@@ -28,6 +28,7 @@ constexpr int G = 8;              // workgroups per group
 constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
+constexpr int LDH16 = 264;        // fp16 tile: row stride in halfs (528 B: 16-B aligned, slots spread)
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + sentinels
 }  // namespace
@@ -40,6 +41,7 @@ constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 pari
 // Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
 // growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
 // a hint when to sweep again, validity is still decided by the granules' own tags.
+template <bool F16>
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
                                               int wave, int lane, bool keep, bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
@@ -69,12 +71,20 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentine
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = j * 64 + lane;            // 0..1023 within the quarter
-            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
+            if (F16) reinterpret_cast<_Float16*>(hs)[(wave * 4 + (i >> 8)) * LDH16 + (i & 255)] = (_Float16)__uint_as_float(v[j]);
+            else hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
         }
     }
     return true;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 = the reduced-precision encoder of BASELINE configs[4]: W_hh and h_{t-1} enter the recurrent
+// product as fp16 (v_mfma_f32_16x16x32_f16, fp32 accumulate: 16 MFMAs per step instead of 128); bias,
+// input projection, cell update, state c, the published h and enc_out stay fp32.  Opt-in, NOT
+// parity-exact: callers report an index-agreement rate against the fp32 path.
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
                                                                   int n_nets, int groups_per_net, int ablate) {
@@ -112,19 +122,29 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     int wrow[2];
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
-    float wB[2][64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
+    float wB[F16 ? 1 : 2][F16 ? 1 : 64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
+    f16x8 wB16[F16 ? 2 : 1][F16 ? 8 : 1];   // fp16 B-fragments: lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = nets.bhh[net][wrow[tl]];
+        if constexpr (F16) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wB16[tl][kk][j] = (_Float16)Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
+        }
         if (!pre) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
             wX[tl][0] = nets.w_in[net][wrow[tl] * 8 + kq];
             wX[tl][1] = nets.w_in[net][wrow[tl] * 8 + 4 + kq];
             bx[tl] = nets.b_in[net][wrow[tl]];
         }
+        if constexpr (!F16) {
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk)   // packed layout: W[g*H+u][4kk+kq] = Wp[((kk*4+g)*H+u)*4+kq]
-            wB[tl][kk] = Wp[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+            for (int kk = 0; kk < 64; ++kk)   // packed layout: W[g*H+u][4kk+kq] = Wp[((kk*4+g)*H+u)*4+kq]
+                wB[tl][kk] = Wp[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+        }
     }
 
     const int n_tiles = (B + ROWS - 1) / ROWS;
@@ -171,9 +191,9 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             bool ok = true;
             if (t == 0) {
                 for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
-                if (!first_tile) ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
+                if (!first_tile) ok = sweep_quarter<F16>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
             } else if (!(ablate & 8)) {
-                ok = sweep_quarter(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
+                ok = sweep_quarter<F16>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
             if (stamps) s1 = phase_stamp();
@@ -192,7 +212,21 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             }
 
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDH>(hs, c, kq, wB[0], wB[1], acc0, acc1);
+            if constexpr (F16) {
+                if (t > 0) {
+                    const _Float16* base = reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq;
+                    f16x8 a16[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) a16[kk] = *reinterpret_cast<const f16x8*>(base + 32 * kk);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[kk], wB16[0][kk], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[kk], wB16[1][kk], acc1, 0, 0, 0);
+                    }
+                }
+            } else {
+                if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDH>(hs, c, kq, wB[0], wB[F16 ? 0 : 1], acc0, acc1);
+            }
             if (stamps) {
                 asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));   // the MFMA chains have retired
                 s3 = phase_stamp();
@@ -293,9 +327,13 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     // zero the status word and every tag before each launch (tags start at 1)
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
-    hipLaunchKernelGGL(lstm_encode_coop_kernel, dim3(groups * G), dim3(256), 0, s, nets,
-                       reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES),
-                       reinterpret_cast<unsigned*>(workspace), B, L, n_nets, groups_per_net,
-                       gnnpn_option_lstm_ablate());
+    u64* p_x = reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES);
+    unsigned* p_e = reinterpret_cast<unsigned*>(workspace);
+    if (gnnpn_option_lstm_precision() == 1)
+        hipLaunchKernelGGL(lstm_encode_coop_kernel<true>, dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L,
+                           n_nets, groups_per_net, gnnpn_option_lstm_ablate());
+    else
+        hipLaunchKernelGGL(lstm_encode_coop_kernel<false>, dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L,
+                           n_nets, groups_per_net, gnnpn_option_lstm_ablate());
     return GNNPN_OK;
 }

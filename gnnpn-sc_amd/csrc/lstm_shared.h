@@ -23,4 +23,5 @@ int gnnpn_launch_encode_coop2(const LstmNets& nets, int n_nets, int32_t B, int32
                               int64_t workspace_bytes, hipStream_t s);
 int64_t gnnpn_encode_coop2_workspace_bytes();
 int gnnpn_option_lstm_impl();
+int gnnpn_option_lstm_precision();   // 0 fp32 (default, parity), 1 fp16 operands in the recurrent product (opt-in)
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

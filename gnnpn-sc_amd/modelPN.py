@@ -266,7 +266,7 @@ class CombinatorialRL(nn.Module):
 
 
 @torch.no_grad()
-def two_level_greedy(low, high, inputs, fold=None):
+def two_level_greedy(low, high, inputs, fold=None, precision="f32"):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
@@ -276,7 +276,7 @@ def two_level_greedy(low, high, inputs, fold=None):
     la, ha = low.actor, high.actor
     enc_l, emb_l = la.encode_args(inputs, fold)
     enc_h, emb_h = ha.encode_args(inputs, fold)
-    enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h])
+    enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h], precision=precision)
     del enc_l, enc_h
     dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
                                  ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold)],

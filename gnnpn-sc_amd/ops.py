@@ -173,8 +173,12 @@ def coop_supported(H, n_per=1, option=None):
     return H == 256 and n_per <= 16 and _options.get(option, 0) != 1
 
 
-def lstm_encode(nets):
+def lstm_encode(nets, precision="f32"):
     """Run the encoder recurrence of len(nets) nets in ONE launch (gnnpn_lstm_encode_f32).
+
+    precision="f16" (opt-in, cooperative form only): W_hh and h_{t-1} enter the recurrent product as
+    fp16 with fp32 accumulation (BASELINE configs[4] "fp16 encoder MFMA path"); everything else stays
+    fp32.  Not parity-exact — report an agreement rate against "f32".
 
     nets: list of dicts with whh (packed), bhh and EITHER pregates [B,L,4H] OR inputs [B,L,8] +
     w_in [4H,8] + b_in [4H] (input projection evaluated inside the cooperative kernel; for shapes
@@ -209,9 +213,19 @@ def lstm_encode(nets):
         a.bhh = dev_ptr(d["bhh"], F32, f"nets[{i}].bhh").value
         a.enc_out, a.h_n, a.c_n = (dev_ptr(t, F32, "out").value for t in (e, hn, cn))
     ws = encode_workspace(dev) if coop else None
-    check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, dev_ptr(ws, torch.uint8, "workspace", True),
-                                            0 if ws is None else ws.numel(), stream_ptr()),
-          "gnnpn_lstm_encode_f32")
+    if precision not in ("f32", "f16"):
+        raise GnnpnError(f"lstm_encode: unknown precision {precision!r}")
+    if precision == "f16" and not coop:
+        raise GnnpnError("lstm_encode: precision='f16' needs the cooperative form (H = 256)")
+    lib = _lib.load()
+    if precision == "f16":
+        check(lib.gnnpn_set_option(b"lstm_precision", 1), "gnnpn_set_option")
+    try:
+        check(lib.gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, dev_ptr(ws, torch.uint8, "workspace", True),
+                                        0 if ws is None else ws.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
+    finally:
+        if precision == "f16":
+            check(lib.gnnpn_set_option(b"lstm_precision", 0), "gnnpn_set_option")
     return enc, h_n, c_n
 
 

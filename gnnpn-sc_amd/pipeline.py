@@ -80,8 +80,9 @@ class DeviceBatch:
 class ML2PNPipeline:
     """net: modelML.Net; low/high: modelPN.CombinatorialRL (levels "Low"/"High")."""
 
-    def __init__(self, net, low, high, n_per):
+    def __init__(self, net, low, high, n_per, precision="f32"):
         self.net, self.low, self.high, self.n_per = net, low, high, n_per
+        self.precision = precision       # "f16": opt-in fp16-operand encoder (not parity-exact)
 
     @torch.no_grad()
     def scores(self, services, batch):
@@ -98,7 +99,7 @@ class ML2PNPipeline:
     def run(self, services, batch):
         scores = self.scores(services, batch)
         rows, ids = self.candidates(services, batch, scores)
-        out = two_level_greedy(self.low, self.high, rows)
+        out = two_level_greedy(self.low, self.high, rows, precision=self.precision)
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
