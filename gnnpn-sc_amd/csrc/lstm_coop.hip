@@ -84,7 +84,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // product as fp16 (v_mfma_f32_16x16x32_f16, fp32 accumulate: 16 MFMAs per step instead of 128); bias,
 // input projection, cell update, state c, the published h and enc_out stay fp32.  Opt-in, NOT
 // parity-exact: callers report an index-agreement rate against the fp32 path.
-template <bool F16>
+template <bool F16, bool PRE>   // PRE: the input side arrives as stored pre-gates (else: folded, from the raw rows)
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
                                                                   int n_nets, int groups_per_net, int ablate) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     const bool same_xcd = same == 1 && !(ablate & 128);
     if (threadIdx.x == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the fast path
 
-    const float* __restrict__ pre = nets.pregates[net];
+    const float* __restrict__ pre = PRE ? nets.pregates[net] : nullptr;
     const float* __restrict__ xin = nets.inputs[net];     // used when pre == nullptr (F = 8)
     const float* __restrict__ Wp = nets.whh[net];
     float* __restrict__ enc = nets.enc_out[net];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                 for (int j = 0; j < 8; ++j)
                     wB16[tl][kk][j] = (_Float16)Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
         }
-        if (!pre) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
+        if constexpr (!PRE) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
             wX[tl][0] = nets.w_in[net][wrow[tl] * 8 + kq];
             wX[tl][1] = nets.w_in[net][wrow[tl] * 8 + 4 + kq];
             bx[tl] = nets.b_in[net][wrow[tl]];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
         float pg[2][4], pg_next[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float ax[2] = {0.f, 0.f}, ax_next[2] = {0.f, 0.f};
         auto load_input = [&](int t, float (&pgv)[2][4], float (&axv)[2]) {
-            if (pre) {
+            if constexpr (PRE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = b0 + kq * 4 + r;
@@ -200,18 +200,9 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             __syncthreads();
             if (abort_flag) break;
             if (stamps) s2 = phase_stamp();
-            if (t + 1 < L) load_input(t + 1, pg_next, ax_next);
-            // enc_out of the PREVIOUS step leaves now: after the hand-off wait (stores retire in issue
-            // order with the sweep's loads, so storing before the sweep would lengthen it), as whole
-            // 128-B lines (one per problem row) out of the LDS staging tile.
-            if (t > 0 && threadIdx.x < ROWS * 8) {
-                const int row = threadIdx.x >> 3, q = threadIdx.x & 7;
-                if (b0 + row < B)
-                    *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (t - 1)) * H + member * UNITS + 4 * q) =
-                        *reinterpret_cast<const float4*>(&hst[row][4 * q]);
-            }
-
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            u64 s2a = 0;
+            if (stamps) s2a = phase_stamp();
             if constexpr (F16) {
                 if (t > 0) {
                     const _Float16* base = reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq;
@@ -227,11 +218,23 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             } else {
                 if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDH>(hs, c, kq, wB[0], wB[F16 ? 0 : 1], acc0, acc1);
             }
+            if (t + 1 < L && !(ablate & 0x400)) load_input(t + 1, pg_next, ax_next);
+            // Issued BEHIND the MFMA stream (they would otherwise sit in front of it: measured 1.3k cycles per
+            // step): the next step's input loads, and enc_out of the PREVIOUS step — after the hand-off wait
+            // (stores retire in issue order with the sweep's loads, so storing before the sweep would lengthen
+            // it), as whole 128-B lines (one per problem row) out of the LDS staging tile.
+            if (t > 0 && threadIdx.x < ROWS * 8 && !(ablate & 0x200)) {
+                const int row = threadIdx.x >> 3, q = threadIdx.x & 7;
+                if (b0 + row < B)
+                    *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (t - 1)) * H + member * UNITS + 4 * q) =
+                        *reinterpret_cast<const float4*>(&hst[row][4 * q]);
+            }
+
             if (stamps) {
                 asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));   // the MFMA chains have retired
                 s3 = phase_stamp();
             }
-            if (!pre) {   // x_t . w_in^T as its own k-ordered chain, then + b_in (as gnnpn_linear_f32 would)
+            if constexpr (!PRE) {   // x_t . w_in^T as its own k-ordered chain, then + b_in (as gnnpn_linear_f32 would)
                 f32x4 px0 = {0.f, 0.f, 0.f, 0.f}, px1 = {0.f, 0.f, 0.f, 0.f};
                 px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[0][0], px0, 0, 0, 0);
                 px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[1][0], px1, 0, 0, 0);
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                     prof[0] += s1 - s0;   // input copy + hand-off sweep + LDS fill
                     prof[1] += s2 - s1;   // barrier
                     prof[2] += s3 - s2;   // input prefetch issue + enc_out flush + A-fragment reads + 128 MFMAs
+                    prof[6] += s2a - s2;  // ... of which: input prefetch issue + enc_out flush
                     prof[3] += s4 - s3;   // input projection + barrier
                     prof[4] += s5 - s4;   // cell update + publish
                     prof[5] += 1;
@@ -329,11 +333,19 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
     u64* p_x = reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES);
     unsigned* p_e = reinterpret_cast<unsigned*>(workspace);
-    if (gnnpn_option_lstm_precision() == 1)
-        hipLaunchKernelGGL(lstm_encode_coop_kernel<true>, dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L,
-                           n_nets, groups_per_net, gnnpn_option_lstm_ablate());
-    else
-        hipLaunchKernelGGL(lstm_encode_coop_kernel<false>, dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L,
-                           n_nets, groups_per_net, gnnpn_option_lstm_ablate());
+    bool pre = nets.pregates[0] != nullptr;
+    for (int n = 0; n < n_nets; ++n)
+        if ((nets.pregates[n] != nullptr) != pre)
+            GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
+    const bool f16 = gnnpn_option_lstm_precision() == 1;
+    const int abl = gnnpn_option_lstm_ablate();
+#define GNNPN_ENC(F16_, PRE_)                                                                                       \
+    hipLaunchKernelGGL((lstm_encode_coop_kernel<F16_, PRE_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L, \
+                       n_nets, groups_per_net, abl)
+    if (f16 && pre) GNNPN_ENC(true, true);
+    else if (f16) GNNPN_ENC(true, false);
+    else if (pre) GNNPN_ENC(false, true);
+    else GNNPN_ENC(false, false);
+#undef GNNPN_ENC
     return GNNPN_OK;
 }

@@ -23,6 +23,9 @@ def timeit(label, abl):
     ms = e0.elapsed_time(e1) / 10
     print(f"{label:40s} ablate={abl:2d}  {ms:.3f} ms  {ms * 1e3 / L:.2f} us/step", flush=True)
 timeit("full", 0)
+timeit("no enc_out flush", 0x200)
+timeit("no input prefetch", 0x400)
+timeit("neither", 0x600)
 timeit("no MFMA", 1)
 timeit("no transcendentals", 2)
 timeit("no MFMA, no transcendentals", 3)
@@ -38,8 +41,9 @@ ops.set_option("lstm_ablate", 0)
 ops.set_option("lstm_ablate", 32)
 ops.lstm_encode(nets); torch.cuda.synchronize()
 ws = ops.encode_workspace(dev)
-prof = ws[32:32 + 48].view(torch.int64).cpu().tolist()
+prof = ws[32:32 + 56].view(torch.int64).cpu().tolist()
 n = max(prof[5], 1)
+print("flush + input prefetch part of the MFMA phase:", round(prof[6] / n))
 names = ["sweep+LDS fill", "barrier 1", "A-frag reads + MFMA (+flush)", "projection + barrier 2", "cell + publish"]
 print("phase cycles per step (wg 0, wave 0):", {k: round(v / n) for k, v in zip(names, prof[:5])}, "steps", n,
       "total", round(sum(prof[:5]) / n))
