@@ -49,11 +49,13 @@ __device__ __forceinline__ int ror16(int v, int n) {
     }
 }
 
-template <bool FOLDX>
+// DIAG: diagnostic build with phase stamps (tools/stamp_decode.py); production carries none of it.
+template <bool FOLDX, bool DIAG>
 __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, int n_nets,
-                                                                     int groups_per_net, int ablate) {
+                                                                     int groups_per_net, int ablate_arg) {
+    const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
     __shared__ float hs[ROWS * LDH];
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
         for (int k = 0; k <= T; ++k) {
             float4 xg[4];
             float xraw = 0.0f, axf[2] = {0.f, 0.f};
-            const bool stamps = ablate & 32;
+            const bool stamps = DIAG && (ablate & 32);
             u64 st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (stamps) st[0] = phase_stamp();
             if (k > 0) {
@@ -446,11 +448,15 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    if (fold)
-        hipLaunchKernelGGL(pointer_decode_coop_kernel<true>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l,
-                           p_err, n_nets, groups_per_net, gnnpn_option_lstm_ablate());
+    const int abl = gnnpn_option_lstm_ablate();
+    if (fold && (abl & 32))
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+                           p_l, p_err, n_nets, groups_per_net, abl);
+    else if (fold)
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+                           p_l, p_err, n_nets, groups_per_net, abl);
     else
-        hipLaunchKernelGGL(pointer_decode_coop_kernel<false>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l,
-                           p_err, n_nets, groups_per_net, gnnpn_option_lstm_ablate());
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+                           p_l, p_err, n_nets, groups_per_net, abl);
     return GNNPN_OK;
 }

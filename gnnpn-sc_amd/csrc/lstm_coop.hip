@@ -84,10 +84,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // product as fp16 (v_mfma_f32_16x16x32_f16, fp32 accumulate: 16 MFMAs per step instead of 128); bias,
 // input projection, cell update, state c, the published h and enc_out stay fp32.  Opt-in, NOT
 // parity-exact: callers report an index-agreement rate against the fp32 path.
-template <bool F16, bool PRE>   // PRE: the input side arrives as stored pre-gates (else: folded, from the raw rows)
+// PRE: the input side arrives as stored pre-gates (else: folded, from the raw rows).  DIAG: the diagnostic
+// build (phase stamps / ablation switches of tools/ablate_encode.py); the production instantiation carries
+// none of that code (`ablate` is then the constant 0).
+template <bool F16, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
-                                                                  int n_nets, int groups_per_net, int ablate) {
+                                                                  int n_nets, int groups_per_net, int ablate_arg) {
+    const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 (force the write-through hand-off) is a tested mode
     __shared__ float hs[ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
     __shared__ int abort_flag;
@@ -339,13 +343,16 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const bool f16 = gnnpn_option_lstm_precision() == 1;
     const int abl = gnnpn_option_lstm_ablate();
-#define GNNPN_ENC(F16_, PRE_)                                                                                       \
-    hipLaunchKernelGGL((lstm_encode_coop_kernel<F16_, PRE_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, p_e, B, L, \
-                       n_nets, groups_per_net, abl)
-    if (f16 && pre) GNNPN_ENC(true, true);
-    else if (f16) GNNPN_ENC(true, false);
-    else if (pre) GNNPN_ENC(false, true);
-    else GNNPN_ENC(false, false);
+#define GNNPN_ENC(F16_, PRE_, DIAG_)                                                                            \
+    hipLaunchKernelGGL((lstm_encode_coop_kernel<F16_, PRE_, DIAG_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, \
+                       p_e, B, L, n_nets, groups_per_net, abl)
+    if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
+        if (f16 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
+        GNNPN_ENC(false, false, true);
+    } else if (f16 && pre) GNNPN_ENC(true, true, false);
+    else if (f16) GNNPN_ENC(true, false, false);
+    else if (pre) GNNPN_ENC(false, true, false);
+    else GNNPN_ENC(false, false, false);
 #undef GNNPN_ENC
     return GNNPN_OK;
 }
