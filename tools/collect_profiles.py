@@ -1,0 +1,36 @@
+"""Copy the summaries produced by tools/refresh_profiles.sh from gpurun_out/refresh/ into profiles/."""
+import collections, csv, glob, json, os, shutil
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O, P = os.path.join(R, "gpurun_out", "refresh"), os.path.join(R, "profiles")
+def cp(src, dst):
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(P, dst)); print("->", dst)
+cp(f"{O}/bench_default.json", "r01_final_qws_b256_bench.json")
+cp(f"{O}/bench_f16.json", "r01_optin_fp16_encoder_qws_b256_bench.json")
+cp(f"{O}/bench_normal.json", "r01_normal_b1024_bench.json")
+cp(f"{O}/bench_synth4.json", "r01_synth4_b512_bench.json")
+cp(f"{O}/aggregate_roofline.json", "r01_csr_aggregate_replicated_roofline.json")
+for d, name in (("prof_default", "r01_final_default_cmd_kernel_stats.csv"), ("prof_solo", "r01_final_solo_eager_kernel_stats.csv")):
+    f = glob.glob(f"{O}/{d}/*/*kernel_stats.csv")
+    if f: cp(f[0], name)
+vals = collections.defaultdict(dict)
+for name in ("fetch", "write"):
+    f = glob.glob(f"{O}/pmc_{name}/*/*counter_collection.csv")
+    if not f: continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])): agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    with open(os.path.join(P, f"r01_final_pmc_{name}_size_summary.csv"), "w") as o:
+        o.write("kernel,dispatches,mean_counter_value_KB\n")
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            o.write(f"\"{k[:90]}\",{len(v)},{sum(v) / len(v):.1f}\n"); vals[k][name] = sum(v) / len(v)
+if vals:
+    out = {"workload": "qws B=256 (bench.py default shape), eager single-stream launches, 1 x MI355X", "unit": "bytes per launch",
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE; counters are KB; FETCH_SIZE "
+                     "doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as read", "kernels": {}}
+    short = {"lstm_encode_coop_kernel": "lstm_encode", "pointer_decode_coop_kernel": "pointer_decode", "csr_aggregate_kernel<true>": "csr_aggregate_gcn"}
+    for k, v in vals.items():
+        for pat, label in short.items():
+            if pat in k:
+                fe, wr = v.get("fetch", 0) * 1024, v.get("write", 0) * 1024
+                out["kernels"][label] = {"fetch_size_raw": round(fe), "fetch_corrected": round(2 * fe), "write_size": round(wr), "traffic": round(2 * fe + wr)}
+    json.dump(out, open(os.path.join(P, "r01_pmc_traffic.json"), "w"), indent=1); print("-> r01_pmc_traffic.json")
