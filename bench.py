@@ -207,38 +207,28 @@ def main():
         timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
         timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
 
-    # Steps are independent batches.  Each of `inflight` slots has its own HIP stream, outputs and
-    # hand-off workspaces; step i runs on slot i % inflight, so the latency-bound recurrent kernels of
-    # one step overlap the next step's kernels.  Default: each slot is one captured HIP graph (events
-    # cannot be read back from a replayed graph, and event pairs between the kernels of an eager timed
-    # region cost ~25 % throughput), so the per-kernel durations come from a separate eager pass on one
-    # stream right after the timed region; --graph 0 records them inside the timed region instead.
-    n_slots = max(1, args.inflight)
-    if n_slots > 1 and args.graph:
-        ops.set_option("decode_impl", 3)   # 256-register decoder: shares the SIMDs with the other step's encoder
-    streams = [torch.cuda.Stream() for _ in range(n_slots)]
-    if args.graph:
-        slots = [pipe.capture(svc, batch, slot=s) for s in range(n_slots)]
-    else:
-        def eager(s):
-            def run():
-                ops.set_workspace_slot(s)
-                try:
-                    return pipe.run(svc, batch)
-                finally:
-                    ops.set_workspace_slot(0)
-            return run
-        slots = [eager(s) for s in range(n_slots)]
-    last = [None] * n_slots
+    # Steps are independent batches.  Default: pipeline.PipelinedRunner — `inflight` slots, each one
+    # captured HIP graph of the whole pass with its own stream, outputs and hand-off workspaces; step i
+    # runs on slot i % inflight, so the latency-bound recurrent kernels of one step overlap the next
+    # step's kernels.  Events cannot be read back from a replayed graph, and event pairs between the
+    # kernels of an eager timed region cost ~25 % throughput, so the per-kernel durations come from a
+    # separate eager pass on one stream right after the timed region; --graph 0 (eager, one stream)
+    # records them inside the timed region instead.
+    from gnnpn_sc_amd.pipeline import PipelinedRunner
+    n_slots = max(1, args.inflight) if args.graph else 1
+    runner = PipelinedRunner(pipe, svc, batch, slots=n_slots) if args.graph else None
 
     def step(i):
-        s = i % n_slots
-        with torch.cuda.stream(streams[s]):
-            out = slots[s]()
-            last[s] = out
-            if world > 1 or force_dist:
+        if runner is not None:
+            out, s = runner.submit()
+            stream = runner.stream(s)
+        else:
+            out, stream = pipe.run(svc, batch), torch.cuda.current_stream()
+        step.last = out
+        if world > 1 or force_dist:
+            with torch.cuda.stream(stream):
                 return gdist.all_gather_indices(out["idx_high"]), out["R"]
-            return out["idx_high"], out["R"]
+        return out["idx_high"], out["R"]
 
     for i in range(args.warmup):
         step(i)
@@ -255,32 +245,30 @@ def main():
     timers.enabled = False
     elapsed = gdist.max_over_ranks(elapsed, dev, world)
     ops.check_status(dev)            # a timed-out hand-off would have invalidated the run
-    # self-check: every slot's (overlapped) result equals a plain single-stream run of the same batch
-    ref = pipe.run(svc, batch)           # same kernels (same decode_impl), one stream, nothing overlapped
+    # self-check: the (overlapped) results equal a single-stream run of the same kernels on the same batch
+    ref = runner.reference_run(0) if runner is not None else pipe.run(svc, batch)
     torch.cuda.synchronize()
     agreement = None
     if args.precision != "f32":       # agreement of the reduced-precision mode with the f32 path: same batch,
-        r32 = ML2PNPipeline(net, low, high, K).run(svc, batch)   # same kernels otherwise; compared on the SELECTED
-        torch.cuda.synchronize()                                  # rows (dummy / duplicate candidates are one selection)
+        r32 = ML2PNPipeline(net, low, high, K).run(svc, batch)   # compared on the SELECTED rows (dummy /
+        torch.cuda.synchronize()                                  # duplicate candidates are one selection)
         same = (ref["actions"] == r32["actions"]).all(-1)
         agreement = {"problems_with_identical_selection": round(float(same.all(1).float().mean()), 4),
                      "identical_decisions": round(float(same.float().mean()), 5),
                      "mean_abs_R_diff": round(float((ref["R"] - r32["R"]).abs().mean()), 6)}
-    for s in range(n_slots):
-        o = last[s]
-        if o is not None and not (torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])):
-            raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
+    if runner is not None:
+        for s in range(n_slots):
+            o = runner.graphs[s].outputs
+            if not (torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])):
+                raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
     n_timed = args.steps
     if args.graph and not args.no_kernel_timers:
-        # events cannot be read back from inside a replayed graph: time the kernels in a separate
-        # single-stream eager pass (NOT overlapped; say so in the output)
         timers.enabled = True
         n_timed = min(args.steps, 10)
         for _ in range(n_timed):
-            pipe.run(svc, batch)
+            runner.reference_run(0)
         torch.cuda.synchronize()
         timers.enabled = False
-    ops.set_option("decode_impl", 0)
 
     if rank != 0:
         gdist.destroy(world)

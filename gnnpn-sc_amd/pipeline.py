@@ -142,3 +142,66 @@ class ML2PNPipeline:
         ranking = self.rankings(services, batch)
         pk = ops.precision_at_k(ranking, labels.float().contiguous(), (1, 5))
         return ranking, [float(v) for v in pk.mean(0).tolist()]
+
+
+class PipelinedRunner:
+    """Throughput mode: ``slots`` independent batches in flight on ``slots`` HIP streams.
+
+    The recurrent kernels are step-latency-bound and leave most of the machine idle, so consecutive
+    (independent) batches are overlapped: every slot owns one captured HIP graph of the whole pass, its
+    own static input/output tensors and its own cooperative-kernel hand-off workspaces; batch i runs on
+    slot i % slots.  With two slots the 16-member decoder form is selected (256 registers: it shares
+    every SIMD with a wave of the other slot's encoder).  All batches must have the shapes of
+    ``example_batch`` (graphs are shape-static); ``submit`` copies a new batch into the slot's static
+    tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
+    """
+
+    def __init__(self, pipe, services, example_batch, slots=2):
+        self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
+        self.streams = [torch.cuda.Stream() for _ in range(self.n_slots)]
+        self.decode_impl = 3 if self.n_slots > 1 else 0
+        ops.set_option("decode_impl", self.decode_impl)
+        try:
+            self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
+            self.graphs = [pipe.capture(services, self.batches[s], slot=s) for s in range(self.n_slots)]
+        finally:
+            ops.set_option("decode_impl", 0)
+        self.count = 0
+
+    @staticmethod
+    def _clone(b):
+        c = graph.CSR(b.wf_csr.rowptr.clone(), b.wf_csr.col.clone(), None, b.wf_csr.n)
+        return DeviceBatch(b.x.clone(), c, b.seg_ptr.clone(), b.local_bounds.clone(), b.present.clone(),
+                           b.global_bounds.clone())
+
+    def submit(self, batch=None):
+        """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
+        consume them (or record an event) before the slot comes round again, ``slots`` submits later."""
+        s = self.count % self.n_slots
+        self.count += 1
+        with torch.cuda.stream(self.streams[s]):
+            if batch is not None:
+                dst = self.batches[s]
+                for a, b in ((dst.x, batch.x), (dst.wf_csr.rowptr, batch.wf_csr.rowptr), (dst.wf_csr.col, batch.wf_csr.col),
+                             (dst.seg_ptr, batch.seg_ptr), (dst.local_bounds, batch.local_bounds),
+                             (dst.present, batch.present), (dst.global_bounds, batch.global_bounds)):
+                    if a.shape != b.shape:
+                        raise ops.GnnpnError(f"PipelinedRunner: batch shape {tuple(b.shape)} != captured {tuple(a.shape)}")
+                    a.copy_(b, non_blocking=True)
+            out = self.graphs[s]()
+        return out, s
+
+    def stream(self, slot):
+        return self.streams[slot]
+
+    def reference_run(self, slot=0):
+        """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
+        ops.set_option("decode_impl", self.decode_impl)
+        try:
+            return self.pipe.run(self.services, self.batches[slot])
+        finally:
+            ops.set_option("decode_impl", 0)
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()

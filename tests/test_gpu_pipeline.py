@@ -202,3 +202,36 @@ def test_trainml_test_and_eval_block_mirrors(dev):
     got = torch.tensor(acts).permute(1, 0, 2)                      # [P,T,8]
     same = (got == ref["actions"]).all(-1).all(-1)
     assert bool(same[robust].all()) and bool(robust.any())
+
+
+def test_pipelined_runner_matches_single_stream(dev):
+    """PipelinedRunner (2 captured graphs on 2 streams, private workspaces, new batches copied into the
+    static inputs) gives, batch by batch, what a plain single-stream run of the same kernels gives."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 48
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=10 + i, tasks_per_problem=10), dev)
+               for i in range(5)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    got = []
+    for b in batches:
+        out, slot = runner.submit(b)
+        with torch.cuda.stream(runner.stream(slot)):          # consume before the slot is reused
+            got.append((out["idx_high"].clone(), out["R"].clone(), out["candidate_ids"].clone()))
+    runner.synchronize()
+    ops.check_status(dev)
+    ops.set_option("decode_impl", 3)                           # the decoder form the 2-slot runner uses
+    try:
+        for b, (idx, R, ids) in zip(batches, got):
+            ref = pipe.run(svc, b)
+            assert torch.equal(ids, ref["candidate_ids"]) and torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
+    finally:
+        ops.set_option("decode_impl", 0)
+    with pytest.raises(ops.GnnpnError):
+        runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
