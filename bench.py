@@ -263,6 +263,8 @@ def main():
                 raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
     n_timed = args.steps
     if args.graph and not args.no_kernel_timers:
+        runner.reference_run(0)          # untimed: first eager launch of each kernel in this process
+        torch.cuda.synchronize()
         timers.enabled = True
         n_timed = min(args.steps, 10)
         for _ in range(n_timed):
