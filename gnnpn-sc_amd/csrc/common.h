@@ -88,7 +88,9 @@ __device__ __forceinline__ float cell_rcp(float d) {        // 1/d, d finite and
 // and the other half sigmoid (the [g | o] MFMA tile of the cooperative kernels).
 __device__ __forceinline__ float cell_act(float x, bool is_tanh) {
     const float ax = fminf(fabsf(x), 43.0f);
-    const float u = is_tanh ? __fmul_rn(2.0f, ax) : fminf(fmaxf(-x, -87.0f), 87.0f);
+    float ut = __fmul_rn(2.0f, ax), us = fminf(fmaxf(-x, -87.0f), 87.0f);
+    asm volatile("" : "+v"(ut), "+v"(us));                   // both sides computed, then ONE v_cndmask (no exec-mask dance)
+    const float u = is_tanh ? ut : us;
     const float r = cell_rcp(__fadd_rn(1.0f, cell_exp(u)));   // sigmoid(x), or 1/(e^{2|x|}+1)
     // tanh: |x| >= 0.25: 1 - 2/(e^{2|x|}+1);  below: odd Taylor polynomial (truncation < 3e-9 relative)
     const float big = __fsub_rn(1.0f, __fmul_rn(2.0f, r));

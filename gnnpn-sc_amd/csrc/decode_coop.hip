@@ -360,10 +360,20 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
             for (int r = 0; r < 4; ++r) {
                 const float g0 = __fadd_rn(__fadd_rn(ah0[r], bh[0]), gx[0][r]);
                 const float g1 = __fadd_rn(__fadd_rn(ah1[r], bh[1]), gx[1][r]);
-                cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);
-                if (c < 8) {
+                cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);   // four independent chains, no stores in between
+            }
+            if (c < 8) {
+                u64* dst = out_h + (kq * 4) * H + unit;
+                if (same_xcd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) granule_store_l2(dst + r * H, step + 1, hl[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) granule_store(dst + r * H, step + 1, hl[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     const int row = kq * 4 + r;
-                    granule_publish(out_h + row * H + unit, step + 1, hl[r], same_xcd);
                     hsl[row][wave * 8 + (c & 7)] = hl[r];
                     if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
                 }

@@ -271,10 +271,20 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                 const float r4 = ror16v(a0, 4), r8 = ror16v(a0, 8), r12 = ror16v(a0, 12);
                 const float ig = a0, fg = r12, gg = r8, og = r4;   // valid in the lanes of gate 0
                 cst[r] = __fadd_rn(__fmul_rn(fg, cst[r]), __fmul_rn(ig, gg));
-                hl[r] = __fmul_rn(og, cell_act(cst[r], true));
-                if (gate == 0) {
+                hl[r] = __fmul_rn(og, cell_act(cst[r], true));   // four independent chains, no stores in between
+            }
+            if (gate == 0) {
+                u64* dst = out_h + (kq * 4) * H + unit;
+                if (same_xcd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) granule_store_l2(dst + r * H, step + 1, hl[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) granule_store(dst + r * H, step + 1, hl[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     const int row = kq * 4 + r;
-                    granule_publish(out_h + row * H + unit, step + 1, hl[r], same_xcd);
                     hsl[row][wave * 4 + (c & 3)] = hl[r];
                     if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
                 }

@@ -254,17 +254,28 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             if (stamps) s4 = phase_stamp();
 
             u64* out_buf = xg + (step & 1) * (ROWS * H);
+            // all four rows' cells first (straight-line: the compiler interleaves the four dependent chains),
+            // then ONE predicated block of stores
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // gates = (h.W_hh^T + b_hh) + (x.W_ih^T + b_ih); lanes c<8 hold (i,g), c>=8 hold (f,o)
                 const float g0 = __fadd_rn(__fadd_rn(acc0[r], bh[0]), pg[0][r]);
                 const float g1 = __fadd_rn(__fadd_rn(acc1[r], bh[1]), pg[1][r]);
                 cell_update_pair(g0, g1, c < 8, cst[r], hlast[r]);
-                if (c < 8) {
-                    const int row = kq * 4 + r;
-                    if (!(ablate & 16)) granule_publish(out_buf + row * H + unit, step + 1, hlast[r], same_xcd);
-                    hst[row][wave * 8 + (c & 7)] = hlast[r];
+            }
+            if (c < 8) {
+                u64* dst = out_buf + (kq * 4) * H + unit;
+                if (!(ablate & 16)) {
+                    if (same_xcd) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) granule_store_l2(dst + r * H, step + 1, hlast[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) granule_store(dst + r * H, step + 1, hlast[r]);
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hst[kq * 4 + r][wave * 8 + (c & 7)] = hlast[r];
             }
             if (lane == 0 && !(ablate & 16))                    // hint for waiting peers (see sweep_quarter)
                 granule_publish(sent + (step & 1) * (4 * G) + member * 4 + wave, step + 1, 0.0f, same_xcd);

@@ -23,6 +23,9 @@ def timeit(label, abl):
     ms = e0.elapsed_time(e1) / 10
     print(f"{label:40s} ablate={abl:2d}  {ms:.3f} ms  {ms * 1e3 / L:.2f} us/step", flush=True)
 timeit("full", 0)
+timeit("diagnostic build, stamps on", 32)
+timeit("full", 0)
+timeit("diagnostic build, stamps on", 32)
 timeit("no enc_out flush", 0x200)
 timeit("no input prefetch", 0x400)
 timeit("neither", 0x600)

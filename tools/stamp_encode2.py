@@ -9,7 +9,11 @@ nets = [{"inputs": x, "w_in": ((torch.rand(4 * H, 8, generator=g) * 2 - 1) * 0.3
          "b_in": ((torch.rand(4 * H, generator=g) * 2 - 1) * 0.3).to(dev),
          "whh": ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev),
          "bhh": ((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev)} for n in range(2)]
+ops.set_option("lstm_impl", 3)
 for _ in range(3): ops.lstm_encode(nets)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ops.lstm_encode(nets); e1.record(); torch.cuda.synchronize(); print("coop2 ms", e0.elapsed_time(e1))
 ops.set_option("lstm_ablate", 32)
 ops.lstm_encode(nets); torch.cuda.synchronize()
 ws = ops.encode_workspace(dev)
@@ -19,3 +23,4 @@ for h in range(2):
     n = max(prof[4], 1)
     print("half", h, {k: round(v / n) for k, v in zip(names, prof[:4])}, "steps", n, "total", round(sum(prof[:4]) / n))
 ops.set_option("lstm_ablate", 0)
+ops.set_option("lstm_impl", 0)
