@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     __shared__ float hs[ROWS * LDH];
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
-    __shared__ float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [member][row%4][cand]
+    __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
     __shared__ float xin[FOLDX ? 1 : ROWS][8];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 const int par = (step - 1) & 1;
                 {
                     const u64* src_h = xh_g + par * (ROWS * H) + wave * 4 * H;
-                    const u64* src_p = xp_g + par * (G * ROWS * K) + wave * (G * 4 * K);   // [quarter][member][row%4][cand]
+                    const u64* src_p = xp_g + par * (G * ROWS * K) + wave * (G * 4 * K);   // [quarter][row%4][cand][member]
                     const u64* src_l = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
                     const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all members
                     const int n_l = 4 * K;
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     const bool live = r < K;
                     float dot = 0.0f;
                     if (live) {
-                        dot = part_lin[wave][kq * K + r];
-#pragma unroll
-                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part_lin[wave][(m * 4 + kq) * K + r]);   // member order
+                        // the G members' partial dots of (row, candidate) are contiguous: two 16-byte LDS reads
+                        const float4 p0 = *reinterpret_cast<const float4*>(&part_lin[wave][(kq * K + r) * G]);
+                        const float4 p1 = *reinterpret_cast<const float4*>(&part_lin[wave][(kq * K + r) * G + 4]);
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(p0.x, p0.y), p0.z), p0.w);                      // member order
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(dot, p1.x), p1.y), p1.z), p1.w);
                     }
                     // C*tanh with the device-library tanhf: these values decide the pick
                     float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;
@@ -258,21 +260,33 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     }
                 }
                 __syncthreads();
-                if (member == 0 && tid < ROWS * 8) {
+                if constexpr (FOLDX) {
+                    // raw 8-feature row of the pick as MFMA A-fragments (row c), in flight under the W_hh.h MFMAs.
+                    // Unconditional loads (row clamped, zeroed at the use): a branch here makes the compiler wait
+                    // for them at the join, in front of the MFMA chain.  The same registers ARE the action row
+                    // (lane (c, kq) holds features kq and 4+kq of row c): wave 0 of member 0 stores them below,
+                    // once they have arrived, instead of a load -> wait -> store on the group's critical path.
+                    const int bc = min(b0 + c, B - 1);
+                    const float* rowp = a.inputs + ((int64_t)bc * L + sel[c]) * 8;
+                    axf[0] = rowp[kq];
+                    axf[1] = rowp[4 + kq];
+                } else if (member == 0 && tid < ROWS * 8) {
                     const int row = tid >> 3, b = b0 + row;
                     if (b < B)
                         net.actions[((int64_t)b * T + (k - 1)) * 8 + (tid & 7)] =
                             a.inputs[((int64_t)b * L + sel[row]) * 8 + (tid & 7)];
                 }
-                if (k == T) break;
+                if (k == T) {
+                    if (FOLDX && member == 0 && wave == 0 && b0 + c < B) {   // last pick: nothing left to hide the load behind
+                        float* act = net.actions + ((int64_t)(b0 + c) * T + (k - 1)) * 8;
+                        act[kq] = axf[0];
+                        act[4 + kq] = axf[1];
+                    }
+                    break;
+                }
                 if (stamps) st[2] = phase_stamp();
                 // decoder input of step k, in flight under the W_hh.h MFMAs
-                if constexpr (FOLDX) {            // raw 8-feature row of the pick as MFMA A-fragments (row c)
-                    if (b0 + c < B) {
-                        const float* rowp = a.inputs + ((int64_t)(b0 + c) * L + sel[c]) * 8;
-                        axf[0] = rowp[kq];
-                        axf[1] = rowp[4 + kq];
-                    }
+                if constexpr (FOLDX) {
                 } else if (net.embedded) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -312,6 +326,11 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[0], wXf[1][0], ax1, 0, 0, 0);
                     ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[1], wXf[0][1], ax0, 0, 0, 0);
                     ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(axf[1], wXf[1][1], ax1, 0, 0, 0);
+                    if (member == 0 && wave == 0 && b0 + c < B) {   // the action row of pick k-1 (see the load above)
+                        float* act = net.actions + ((int64_t)(b0 + c) * T + (k - 1)) * 8;
+                        act[kq] = axf[0];
+                        act[4 + kq] = axf[1];
+                    }
                 }
                 if (stamps) st[4] = st[5] = phase_stamp();
 #pragma unroll
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                     p = fmaf(ev[j].z, hv.z, p);
                     p = fmaf(ev[j].w, hv.w, p);
                 }
-                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + (((prow >> 2) * G + member) * 4 + (prow & 3)) * K + pcand, step + 1, p, same_xcd);
+                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + ((size_t)prow * K + pcand) * G + member, step + 1, p, same_xcd);
             }
             if (stamps) {
                 st[7] = phase_stamp();

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                                                                       int groups_per_net, int ablate) {
     __shared__ float hs[ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
-    __shared__ float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [member][row%4][cand]
+    __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
     __shared__ int abort_flag;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                 const int par = (step - 1) & 1;
                 {
                     const u64* src_h = xh_g + par * (ROWS * H) + wave * 4 * H;
-                    const u64* src_p = xp_g + par * (G * ROWS * K) + wave * (G * 4 * K);   // [quarter][member][row%4][cand]
+                    const u64* src_p = xp_g + par * (G * ROWS * K) + wave * (G * 4 * K);   // [quarter][row%4][cand][member]
                     const u64* src_l = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
                     const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all 16 members
                     const int n_l = 4 * K;
@@ -170,9 +170,13 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                     const bool live = r < K;
                     float dot = 0.0f;
                     if (live) {
-                        dot = part_lin[wave][kq * K + r];
-#pragma unroll
-                        for (int m = 1; m < G; ++m) dot = __fadd_rn(dot, part_lin[wave][(m * 4 + kq) * K + r]);   // member order
+                        // the G members' partial dots of (row, candidate) are contiguous: four 16-byte LDS reads
+                        const float4* pp = reinterpret_cast<const float4*>(&part_lin[wave][(kq * K + r) * G]);
+                        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(p0.x, p0.y), p0.z), p0.w);                      // member order
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(dot, p1.x), p1.y), p1.z), p1.w);
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(dot, p2.x), p2.y), p2.z), p2.w);
+                        dot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(dot, p3.x), p3.y), p3.z), p3.w);
                     }
                     float v = a.use_tanh ? __fmul_rn(a.tanh_c, tanhf(dot)) : dot;   // device-library tanhf: decides the pick
                     if (live && member == 0) {
@@ -206,17 +210,21 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                     }
                 }
                 __syncthreads();
-                if (member == 0 && tid < ROWS * 8) {
-                    const int row = tid >> 3, b = b0 + row;
-                    if (b < B)
-                        net.actions[((int64_t)b * T + (k - 1)) * 8 + (tid & 7)] =
-                            a.inputs[((int64_t)b * L + sel[row]) * 8 + (tid & 7)];
-                }
-                if (k == T) break;
-                if (b0 + c < B) {   // raw 8-feature row of the pick as MFMA A-fragments (row c), under the MFMAs
-                    const float* rowp = a.inputs + ((int64_t)(b0 + c) * L + sel[c]) * 8;
+                {   // raw 8-feature row of the pick as MFMA A-fragments (row c), in flight under the MFMAs; loaded
+                    // unconditionally (row clamped) so that no join waits for it, and stored as the action row by
+                    // wave 0 of member 0 once it has arrived (see decode_coop.hip)
+                    const int bc = min(b0 + c, B - 1);
+                    const float* rowp = a.inputs + ((int64_t)bc * L + sel[c]) * 8;
                     axf0 = rowp[kq];
                     axf1 = rowp[4 + kq];
+                }
+                if (k == T) {
+                    if (member == 0 && wave == 0 && b0 + c < B) {
+                        float* act = net.actions + ((int64_t)(b0 + c) * T + (k - 1)) * 8;
+                        act[kq] = axf0;
+                        act[4 + kq] = axf1;
+                    }
+                    break;
                 }
             }
 
@@ -257,6 +265,11 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                 f32x4 ax = {0.f, 0.f, 0.f, 0.f};
                 ax = __builtin_amdgcn_mfma_f32_16x16x4f32(axf0, wXf0, ax, 0, 0, 0);
                 ax = __builtin_amdgcn_mfma_f32_16x16x4f32(axf1, wXf1, ax, 0, 0, 0);
+                if (member == 0 && wave == 0 && b0 + c < B) {   // the action row of pick k-1
+                    float* act = net.actions + ((int64_t)(b0 + c) * T + (k - 1)) * 8;
+                    act[kq] = axf0;
+                    act[4 + kq] = axf1;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gx[r] = __fadd_rn(ax[r], bi);
             } else {
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                     p = fmaf(ev[j].z, hv.z, p);
                     p = fmaf(ev[j].w, hv.w, p);
                 }
-                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + (((prow >> 2) * G + member) * 4 + (prow & 3)) * K + pcand, step + 1, p, same_xcd);
+                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + ((size_t)prow * K + pcand) * G + member, step + 1, p, same_xcd);
             }
             ++step;
         }
