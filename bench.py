@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "split"],
                     help="f16: opt-in fp16-operand encoder (BASELINE configs[4]); NOT the headline dtype — the line "
                          "then carries the agreement with the f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,7 +321,8 @@ def main():
         "metric": "service-composition problems/sec (ML+2PN inference)", "value": round(value, 2),
         "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16 encoder operands / f32 rest",
+        "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 encoder operands / f32 rest",
+                                       "split": "f32 with the encoder's W_hh.h product as fp16 hi+lo split operands (fp32 accumulate) / f32 rest"}[args.precision],
         "data": "synthetic",
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
                    "launch": (f"{'hipGraph replay' if args.graph else 'eager'}, {n_slots} independent step(s) "

@@ -26,8 +26,8 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
         g_lstm_ablate = value;
         return GNNPN_OK;
     }
-    if (!strcmp(name, "lstm_precision")) {   // 0 fp32, 1 fp16 operands in the encoder's recurrent product (cooperative form)
-        GNNPN_REQUIRE(value == 0 || value == 1, "set_option: lstm_precision must be 0 (fp32) or 1 (fp16)");
+    if (!strcmp(name, "lstm_precision")) {   // encoder's recurrent product (cooperative form): 0 fp32, 1 fp16 operands, 2 fp16-split operands
+        GNNPN_REQUIRE(value >= 0 && value <= 2, "set_option: lstm_precision must be 0 (fp32), 1 (fp16) or 2 (fp16 split)");
         g_lstm_precision = value;
         return GNNPN_OK;
     }

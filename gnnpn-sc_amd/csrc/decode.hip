@@ -294,13 +294,24 @@ __global__ void qos_reward_kernel(const float* __restrict__ actions, float* __re
     float prod2 = 1.0f, prod3 = 1.0f, mn = INFINITY;
     double sum0 = 0.0;
     int n_real = 0;
-    for (int t = 0; t < T; ++t) {
-        const float q0 = a[t * 8 + 0], q1 = a[t * 8 + 1], q2 = a[t * 8 + 2], q3 = a[t * 8 + 3];
-        sum0 += (double)q0;                       // np.sum(float32) is pairwise; fp64 then one rounding
-        n_real += q0 > 0.0f;                      // :26-28
-        mn = fminf(mn, q1);
-        prod2 = t == 0 ? q2 : __fmul_rn(prod2, q2);   // np.cumprod float32 (:20)
-        prod3 = t == 0 ? q3 : __fmul_rn(prod3, q3);
+    // rows are fetched eight at a time (one 16-byte load each, all in flight together: the loop is
+    // load-latency-bound), the arithmetic stays strictly in step order
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            q[i] = *reinterpret_cast<const float4*>(a + (int64_t)min(t0 + i, T - 1) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                sum0 += (double)q[i].x;                   // np.sum(float32) is pairwise; fp64 then one rounding
+                n_real += q[i].x > 0.0f;                  // :26-28
+                mn = fminf(mn, q[i].y);
+                prod2 = t == 0 ? q[i].z : __fmul_rn(prod2, q[i].z);   // np.cumprod float32 (:20)
+                prod3 = t == 0 ? q[i].w : __fmul_rn(prod3, q[i].w);
+            }
+        }
     }
     int violate = 0;
     if (prod2 < lo0 || prod2 > hi0) ++violate;    // :23

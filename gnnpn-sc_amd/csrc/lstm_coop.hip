@@ -29,6 +29,7 @@ constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
 constexpr int LDH16 = 264;        // fp16 tile: row stride in halfs (528 B: 16-B aligned, slots spread)
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;   // 2^11: the low halves of the fp16 split
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + sentinels
 }  // namespace
@@ -41,7 +42,7 @@ constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 pari
 // Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
 // growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
 // a hint when to sweep again, validity is still decided by the granules' own tags.
-template <bool F16>
+template <int PREC>
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
                                               int wave, int lane, bool keep, bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
@@ -71,8 +72,16 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentine
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = j * 64 + lane;            // 0..1023 within the quarter
-            if (F16) reinterpret_cast<_Float16*>(hs)[(wave * 4 + (i >> 8)) * LDH16 + (i & 255)] = (_Float16)__uint_as_float(v[j]);
-            else hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
+            if constexpr (PREC == 0) {
+                hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
+            } else {
+                _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
+                const float x = __uint_as_float(v[j]);
+                const _Float16 hi = (_Float16)x;
+                h16[0] = hi;
+                if constexpr (PREC == 2)   // residual, scaled by 2^11 into fp16's normal range (exact scaling)
+                    h16[ROWS * LDH16] = (_Float16)__fmul_rn(__fsub_rn(x, (float)hi), SPLIT_SCALE);
+            }
         }
     }
     return true;
@@ -87,12 +96,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // PRE: the input side arrives as stored pre-gates (else: folded, from the raw rows).  DIAG: the diagnostic
 // build (phase stamps / ablation switches of tools/ablate_encode.py); the production instantiation carries
 // none of that code (`ablate` is then the constant 0).
-template <bool F16, bool PRE, bool DIAG>
+// PREC 2 = split operands: W_hh and h_{t-1} each as an fp16 pair (hi, lo*2^11), product = hi.hi + (hi.lo + lo.hi)/2^11
+// on the fp16 matrix cores with fp32 accumulation (48 MFMAs per step).  The dropped lo.lo term and the fp16
+// rounding of the two residuals leave a relative error <= 3*2^-22 per term — the size of fp32's own
+// accumulation-order noise — at about a fifth of the fp32-MFMA issue time.  Opt-in; see DESIGN.md.
+template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, int32_t B, int32_t L,
                                                                   int n_nets, int groups_per_net, int ablate_arg) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 (force the write-through hand-off) is a tested mode
-    __shared__ float hs[ROWS * LDH];
+    constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi tile + lo tile (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
     __shared__ int abort_flag;
 
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     wrow[1] = (2 + (c >> 3)) * H + unit;
     float wB[F16 ? 1 : 2][F16 ? 1 : 64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
     f16x8 wB16[F16 ? 2 : 1][F16 ? 8 : 1];   // fp16 B-fragments: lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
+    f16x8 wL16[SPLIT ? 2 : 1][SPLIT ? 8 : 1];   // split: the scaled low halves
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
@@ -136,8 +151,12 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    wB16[tl][kk][j] = (_Float16)Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
+                for (int j = 0; j < 8; ++j) {
+                    const float w = Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
+                    const _Float16 hi = (_Float16)w;
+                    wB16[tl][kk][j] = hi;
+                    if constexpr (SPLIT) wL16[tl][kk][j] = (_Float16)__fmul_rn(__fsub_rn(w, (float)hi), SPLIT_SCALE);
+                }
         }
         if constexpr (!PRE) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
             wX[tl][0] = nets.w_in[net][wrow[tl] * 8 + kq];
@@ -194,10 +213,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             // this member is about to overwrite.
             bool ok = true;
             if (t == 0) {
-                for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
-                if (!first_tile) ok = sweep_quarter<F16>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
+                for (int i = threadIdx.x; i < ROWS * LDH16; i += 256) hs[i] = 0.0f;
+                if (!first_tile) ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
             } else if (!(ablate & 8)) {
-                ok = sweep_quarter<F16>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
+                ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
             if (stamps) s1 = phase_stamp();
@@ -207,7 +226,33 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             u64 s2a = 0;
             if (stamps) s2a = phase_stamp();
-            if constexpr (F16) {
+            if constexpr (SPLIT) {
+                if (t > 0) {
+                    const _Float16* base = reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq;
+                    f32x4 lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
+                    f16x8 ah[2], al[2];
+                    ah[0] = *reinterpret_cast<const f16x8*>(base);
+                    al[0] = *reinterpret_cast<const f16x8*>(base + ROWS * LDH16);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        if (kk < 7) {   // next k-block's fragments in flight under this block's six MFMAs
+                            ah[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + 32 * (kk + 1));
+                            al[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + ROWS * LDH16 + 32 * (kk + 1));
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wB16[0][kk], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wB16[1][kk], acc1, 0, 0, 0);
+                        lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wL16[0][kk], lo0, 0, 0, 0);
+                        lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wL16[1][kk], lo1, 0, 0, 0);
+                        lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wB16[0][kk], lo0, 0, 0, 0);
+                        lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wB16[1][kk], lo1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc0[r] = fmaf(lo0[r], SPLIT_INV, acc0[r]);
+                        acc1[r] = fmaf(lo1[r], SPLIT_INV, acc1[r]);
+                    }
+                }
+            } else if constexpr (F16) {
                 if (t > 0) {
                     const _Float16* base = reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq;
                     f16x8 a16[8];
@@ -352,18 +397,20 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     for (int n = 0; n < n_nets; ++n)
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
-    const bool f16 = gnnpn_option_lstm_precision() == 1;
+    const int prec = gnnpn_option_lstm_precision();   // 0 fp32, 1 fp16 operands, 2 fp16-split operands
     const int abl = gnnpn_option_lstm_ablate();
-#define GNNPN_ENC(F16_, PRE_, DIAG_)                                                                            \
-    hipLaunchKernelGGL((lstm_encode_coop_kernel<F16_, PRE_, DIAG_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, \
+#define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
+    hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, \
                        p_e, B, L, n_nets, groups_per_net, abl)
     if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
-        if (f16 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
-        GNNPN_ENC(false, false, true);
-    } else if (f16 && pre) GNNPN_ENC(true, true, false);
-    else if (f16) GNNPN_ENC(true, false, false);
-    else if (pre) GNNPN_ENC(false, true, false);
-    else GNNPN_ENC(false, false, false);
+        if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
+        GNNPN_ENC(0, false, true);
+    } else if (prec == 2 && pre) GNNPN_ENC(2, true, false);
+    else if (prec == 2) GNNPN_ENC(2, false, false);
+    else if (prec == 1 && pre) GNNPN_ENC(1, true, false);
+    else if (prec == 1) GNNPN_ENC(1, false, false);
+    else if (pre) GNNPN_ENC(0, true, false);
+    else GNNPN_ENC(0, false, false);
 #undef GNNPN_ENC
     return GNNPN_OK;
 }

