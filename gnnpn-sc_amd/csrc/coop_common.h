@@ -109,6 +109,65 @@ __device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq,
     }
 }
 
+// ---- split-operand recurrent product ("split" precision) ---------------------------------------------
+// x = hi + lo/2^11 with hi = fp16(x), lo = fp16((x - hi) * 2^11): W_hh.h ~= hi.hi + (hi.lo + lo.hi)/2^11 on the
+// fp16 matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate).  Dropped: lo.lo/2^22 and the fp16 rounding of
+// the two residuals, <= 3*2^-22 relative per term — measured error of the encoder output against an fp64 LSTM
+// equals the fp32 chain's (tools/split_encode.py).  LDS tile: 16 rows of LDH16 halfs, hi tile then lo tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDH16 = 264;            // row stride in halfs (528 B: 16-B aligned, bank slots spread)
+constexpr int SPLIT_LO = 16 * LDH16;  // offset of the lo tile, in halfs
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_store(_Float16* hi_at, float x) {   // hi_at: element address inside the hi tile
+    const _Float16 hi = (_Float16)x;
+    hi_at[0] = hi;
+    hi_at[SPLIT_LO] = (_Float16)__fmul_rn(__fsub_rn(x, (float)hi), SPLIT_SCALE);
+}
+// B-fragments of one 16-column tile from the packed weight layout Wp[((k/4*4 + gate)*H + u)*4 + k%4]:
+// lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
+template <int HD>
+__device__ __forceinline__ void split_weights(const float* __restrict__ Wp, int gate, int u, int kq, f16x8 (&wh)[8],
+                                              f16x8 (&wl)[8]) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * HD + u) * 4 + (j & 3)];
+            const _Float16 hi = (_Float16)w;
+            wh[kk][j] = hi;
+            wl[kk][j] = (_Float16)__fmul_rn(__fsub_rn(w, (float)hi), SPLIT_SCALE);
+        }
+}
+// base = hi tile + c * LDH16 + 8 * kq.  NT column tiles sharing the A-fragments; returns hi + lo/2^11 per tile.
+template <int NT>
+__device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&wh)[NT][8], const f16x8 (&wl)[NT][8],
+                                            f32x4 (&acc)[NT]) {
+    f32x4 lo[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) lo[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 ah[2], al[2];
+    ah[0] = *reinterpret_cast<const f16x8*>(base);
+    al[0] = *reinterpret_cast<const f16x8*>(base + SPLIT_LO);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        if (kk < 7) {   // next k-block's fragments in flight under this block's MFMAs
+            ah[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + 32 * (kk + 1));
+            al[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + SPLIT_LO + 32 * (kk + 1));
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wh[n][kk], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wl[n][kk], lo[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wh[n][kk], lo[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = fmaf(lo[n][r], SPLIT_INV, acc[n][r]);
+}
+
 // LSTM cell update for the [i | f] / [g | o] tile pair: lanes c < 8 hold (i, g), lanes c >= 8 hold
 // (f, o) of the same hidden unit; one DPP swap per value, then both halves update (c, h) alike.
 // Same arithmetic as lstm_cell_update (recurrent.h): cy = f*c + i*g ; hy = o*tanh(cy), products and

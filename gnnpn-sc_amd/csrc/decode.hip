@@ -13,6 +13,7 @@
 #include <string.h>
 #include "recurrent.h"
 #include "decode_shared.h"
+#include "lstm_shared.h"
 
 template <int H, int BT>
 __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_kernel(
@@ -213,6 +214,8 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
         return GNNPN_OK;
     }
+    if (gnnpn_option_lstm_precision() == 2)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand precision needs the cooperative form (H = 256)");
     for (int n = 0; n < n_nets; ++n) {   // streaming form: one net after the other (Low before High)
         const DecodeNet& d = args.net[n];
         if (!d.embedded) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the streaming form needs the embedded tensor");

@@ -50,13 +50,14 @@ __device__ __forceinline__ int ror16(int v, int n) {
 }
 
 // DIAG: diagnostic build with phase stamps (tools/stamp_decode.py); production carries none of it.
-template <bool FOLDX, bool DIAG>
+// SPLIT: W_hh.h with fp16 hi+lo operands (coop_common.h); everything else as in the fp32 form
+template <bool FOLDX, bool DIAG, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, int n_nets,
                                                                      int groups_per_net, int ablate_arg) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
-    __shared__ float hs[ROWS * LDH];
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
@@ -95,13 +96,18 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
     int wrow[2];
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
-    float wBh[2][64], wBx[FOLDX ? 1 : 2][FOLDX ? 1 : 64], bh[2], bi[2], wXf[2][2], sg[2];
+    float wBh[SPLIT ? 1 : 2][SPLIT ? 1 : 64], wBx[FOLDX ? 1 : 2][FOLDX ? 1 : 64], bh[2], bi[2], wXf[2][2], sg[2];
+    f16x8 wH16[SPLIT ? 2 : 1][8], wL16[SPLIT ? 2 : 1][8];
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = net.bhh[wrow[tl]];
+        if constexpr (SPLIT) {
+            split_weights<H>(net.whh, gate, u, kq, wH16[tl], wL16[tl]);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+            for (int kk = 0; kk < 64; ++kk) wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
+        }
         if constexpr (FOLDX) {   // B-fragments of (W_ih W_e) [4H,8], its bias, and the step-0 gates W_ih.start + b_ih
             wXf[tl][0] = net.xw_fold[wrow[tl] * 8 + kq];
             wXf[tl][1] = net.xw_fold[wrow[tl] * 8 + 4 + kq];
@@ -136,7 +142,9 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
         }
         __syncthreads();   // previous tile is completely done with the LDS arrays
         for (int j = 0; j < ROWS; ++j) {
-            hs[j * LDH + tid] = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
+            const float h0v = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
+            if constexpr (SPLIT) split_store(reinterpret_cast<_Float16*>(hs) + j * LDH16 + tid, h0v);
+            else hs[j * LDH + tid] = h0v;
             if (!FOLDX) xs[j * LDH + tid] = net.start[tid];
         }
         __syncthreads();
@@ -191,7 +199,10 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int i = j * 64 + lane;
-                        hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
+                        if constexpr (SPLIT)
+                            split_store(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), __uint_as_float(vh[j]));
+                        else
+                            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -314,7 +325,14 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
 
             // ---- decoder LSTM cell: W_hh.h and the input side as independent fma chains per gate column
             f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax1 = ah0;
-            mfma_chain_pair<LDH>(hs, c, kq, wBh[0], wBh[1], ah0, ah1);
+            if constexpr (SPLIT) {
+                f32x4 acc[2] = {ah0, ah1};
+                split_chain<2>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, acc);
+                ah0 = acc[0];
+                ah1 = acc[1];
+            } else {
+                mfma_chain_pair<LDH>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah0, ah1);
+            }
             if (stamps) {
                 asm volatile("" ::"v"(ah0[0]), "v"(ah1[0]));
                 st[3] = phase_stamp();
@@ -478,14 +496,20 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate();
-    if (fold && (abl & 32))
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+    const bool split = gnnpn_option_lstm_precision() == 2;   // "split" precision: fp16 hi+lo operands in W_hh.h
+    if (split && (!fold || (abl & 32)))
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
+    if (split)
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+                           p_l, p_err, n_nets, groups_per_net, abl);
+    else if (fold && (abl & 32))
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, true, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
                            p_l, p_err, n_nets, groups_per_net, abl);
     else if (fold)
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
                            p_l, p_err, n_nets, groups_per_net, abl);
     else
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<false, false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
                            p_l, p_err, n_nets, groups_per_net, abl);
     return GNNPN_OK;
 }

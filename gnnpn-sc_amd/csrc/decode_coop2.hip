@@ -37,12 +37,12 @@ __device__ __forceinline__ float ror16v(float v, int n) { return __int_as_float(
 
 // NP = granule loads per lane for the partial dots (= smallest built size >= n_per): sizing the sweep's
 // registers by the actual K keeps the kernel inside 256 registers without spills.
-template <int NP>
+template <int NP, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                       u64* __restrict__ xp, u64* __restrict__ xl,
                                                                       unsigned* __restrict__ err, int n_nets,
                                                                       int groups_per_net, int ablate) {
-    __shared__ float hs[ROWS * LDH];
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
     __shared__ float lat[ROWS][KMAX];
@@ -78,9 +78,14 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
     // this lane's gate column: unit = 16m + 4w + (c&3), gate = c>>2
     const int unit = member * UNITS + wave * 4 + (c & 3);
     const int wrow = gate * H + unit;
-    float wBh[64];
+    float wBh[SPLIT ? 1 : 64];
+    f16x8 wH16[1][8], wL16[1][8];
+    if constexpr (SPLIT) {
+        split_weights<H>(net.whh, gate, unit, kq, wH16[0], wL16[0]);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) wBh[kk] = net.whh[((size_t)(kk * 4 + gate) * H + unit) * 4 + kq];
+        for (int kk = 0; kk < 64; ++kk) wBh[kk] = net.whh[((size_t)(kk * 4 + gate) * H + unit) * 4 + kq];
+    }
     const float bh = net.bhh[wrow], bi = net.xb_fold[wrow], sg = net.start_fold[wrow];
     const float wXf0 = net.xw_fold[wrow * 8 + kq], wXf1 = net.xw_fold[wrow * 8 + 4 + kq];
 
@@ -96,7 +101,11 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
             hl[r] = 0.0f;
         }
         __syncthreads();   // previous tile is completely done with the LDS arrays
-        for (int j = 0; j < ROWS; ++j) hs[j * LDH + tid] = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
+        for (int j = 0; j < ROWS; ++j) {
+            const float h0v = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
+            if constexpr (SPLIT) split_store(reinterpret_cast<_Float16*>(hs) + j * LDH16 + tid, h0v);
+            else hs[j * LDH + tid] = h0v;
+        }
         __syncthreads();
 
         for (int k = 0; k <= T; ++k) {
@@ -144,7 +153,10 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int i = j * 64 + lane;
-                        hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
+                        if constexpr (SPLIT)
+                            split_store(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), __uint_as_float(vh[j]));
+                        else
+                            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
@@ -242,7 +254,11 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
 
             // ---- decoder LSTM cell: W_hh.h as one k-ordered fma chain per gate column, folded input side
             f32x4 ah = {0.f, 0.f, 0.f, 0.f};
-            {
+            if constexpr (SPLIT) {
+                f32x4 acc[1] = {ah};
+                split_chain<1>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, acc);
+                ah = acc[0];
+            } else {
                 const float* base = hs + c * LDH + kq;
                 float av[2][8];   // A-fragments fetched 8 k-steps ahead (one chain: 8 MFMAs = 256 cycles of cover)
 #pragma unroll
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        ah = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ch & 1][i], wBh[8 * ch + i], ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ch & 1][i], wBh[SPLIT ? 0 : 8 * ch + i], ah, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -360,9 +376,16 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, void* workspac
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate();
+    const bool split = gnnpn_option_lstm_precision() == 2;
 #define GNNPN_DEC2(NP_)                                                                                          \
-    hipLaunchKernelGGL(pointer_decode_coop2_kernel<NP_>, dim3(groups * G), dim3(256), 0, s, args, p_h, p_p, p_l, p_e, \
-                       n_nets, groups_per_net, abl)
+    do {                                                                                                         \
+        if (split)                                                                                               \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, \
+                               p_p, p_l, p_e, n_nets, groups_per_net, abl);                                      \
+        else                                                                                                     \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, \
+                               p_p, p_l, p_e, n_nets, groups_per_net, abl);                                      \
+    } while (0)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);
     else if (args.K <= 10) GNNPN_DEC2(10);

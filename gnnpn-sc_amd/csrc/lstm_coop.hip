@@ -28,8 +28,6 @@ constexpr int G = 8;              // workgroups per group
 constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
-constexpr int LDH16 = 264;        // fp16 tile: row stride in halfs (528 B: 16-B aligned, slots spread)
-constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;   // 2^11: the low halves of the fp16 split
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + sentinels
 }  // namespace
@@ -76,18 +74,14 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentine
                 hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
             } else {
                 _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
-                const float x = __uint_as_float(v[j]);
-                const _Float16 hi = (_Float16)x;
-                h16[0] = hi;
-                if constexpr (PREC == 2)   // residual, scaled by 2^11 into fp16's normal range (exact scaling)
-                    h16[ROWS * LDH16] = (_Float16)__fmul_rn(__fsub_rn(x, (float)hi), SPLIT_SCALE);
+                if constexpr (PREC == 2) split_store(h16, __uint_as_float(v[j]));
+                else h16[0] = (_Float16)__uint_as_float(v[j]);
             }
         }
     }
     return true;
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // F16 = the reduced-precision encoder of BASELINE configs[4]: W_hh and h_{t-1} enter the recurrent
 // product as fp16 (v_mfma_f32_16x16x32_f16, fp32 accumulate: 16 MFMAs per step instead of 128); bias,
@@ -141,22 +135,20 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
     float wB[F16 ? 1 : 2][F16 ? 1 : 64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
-    f16x8 wB16[F16 ? 2 : 1][F16 ? 8 : 1];   // fp16 B-fragments: lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
-    f16x8 wL16[SPLIT ? 2 : 1][SPLIT ? 8 : 1];   // split: the scaled low halves
+    f16x8 wB16[F16 ? 2 : 1][8];   // fp16 B-fragments: lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
+    f16x8 wL16[SPLIT ? 2 : 1][8];   // split: the scaled low halves
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = nets.bhh[net][wrow[tl]];
-        if constexpr (F16) {
+        if constexpr (SPLIT) {
+            split_weights<H>(Wp, gate, u, kq, wB16[tl], wL16[tl]);
+        } else if constexpr (F16) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float w = Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
-                    const _Float16 hi = (_Float16)w;
-                    wB16[tl][kk][j] = hi;
-                    if constexpr (SPLIT) wL16[tl][kk][j] = (_Float16)__fmul_rn(__fsub_rn(w, (float)hi), SPLIT_SCALE);
-                }
+                for (int j = 0; j < 8; ++j)
+                    wB16[tl][kk][j] = (_Float16)Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * H + u) * 4 + (j & 3)];
         }
         if constexpr (!PRE) {   // B-fragments of the folded input projection: w_in[wrow][4*kk2 + kq], kk2 = 0,1
             wX[tl][0] = nets.w_in[net][wrow[tl] * 8 + kq];
@@ -228,29 +220,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             if (stamps) s2a = phase_stamp();
             if constexpr (SPLIT) {
                 if (t > 0) {
-                    const _Float16* base = reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq;
-                    f32x4 lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
-                    f16x8 ah[2], al[2];
-                    ah[0] = *reinterpret_cast<const f16x8*>(base);
-                    al[0] = *reinterpret_cast<const f16x8*>(base + ROWS * LDH16);
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        if (kk < 7) {   // next k-block's fragments in flight under this block's six MFMAs
-                            ah[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + 32 * (kk + 1));
-                            al[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + ROWS * LDH16 + 32 * (kk + 1));
-                        }
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wB16[0][kk], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wB16[1][kk], acc1, 0, 0, 0);
-                        lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wL16[0][kk], lo0, 0, 0, 0);
-                        lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wL16[1][kk], lo1, 0, 0, 0);
-                        lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wB16[0][kk], lo0, 0, 0, 0);
-                        lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wB16[1][kk], lo1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc0[r] = fmaf(lo0[r], SPLIT_INV, acc0[r]);
-                        acc1[r] = fmaf(lo1[r], SPLIT_INV, acc1[r]);
-                    }
+                    f32x4 acc[2] = {acc0, acc1};
+                    split_chain<2>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wB16, wL16, acc);
+                    acc0 = acc[0];
+                    acc1 = acc[1];
                 }
             } else if constexpr (F16) {
                 if (t > 0) {

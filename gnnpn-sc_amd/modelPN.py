@@ -271,7 +271,9 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32"):
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
     action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
-    win_high_raw + win_low (modelPN.py:216)."""
+    win_high_raw + win_low (modelPN.py:216).
+    precision: "f32" (default) | "split" (fp16 hi+lo operands in both W_hh.h products, fp32 accumulate: measured as
+    accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision)."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
     enc_l, emb_l = la.encode_args(inputs, fold)
@@ -280,7 +282,8 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32"):
     del enc_l, enc_h
     dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
                                  ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold)],
-                                inputs, la.serCategory, la.serNumber, la.C, la.use_tanh)
+                                inputs, la.serCategory, la.serNumber, la.C, la.use_tanh,
+                                precision="split" if precision == "split" else "f32")
     R = ops.qos_reward(dh["actions"], high.level)
     return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
             "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

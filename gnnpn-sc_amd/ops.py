@@ -244,15 +244,19 @@ def decode_workspace(device, B, T, n_per):
     return ws
 
 
-def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False):
+def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32"):
     """Greedy decode of 1 or 2 pointer networks in ONE call (gnnpn_pointer_decode_f32).
 
     nets: list of dicts with keys enc_out, h0, c0, start, wih, whh, bih, bhh, EITHER embedded [B,L,H]
     OR emb_w [H,8] + emb_b [H] (picked rows embedded in-kernel), and optionally latent_win ([B,T,K]
     tensor computed earlier) or latent_from (index of an earlier net of this call).
     Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
-    queries [B,T,H] | None."""
+    queries [B,T,H] | None.
+    precision="split": the W_hh.h product with fp16 hi+lo operands (cooperative, folded form only); "f16" is an
+    encoder-only mode and leaves the decoder in fp32."""
     B, L, H = nets[0]["enc_out"].shape
+    if precision not in _PRECISIONS:
+        raise GnnpnError(f"pointer_decode: unknown precision {precision!r}")
     if L != n_cat * n_per:
         raise GnnpnError(f"pointer_decode: seq_len {L} != {n_cat}*{n_per}")   # modelPN.py:182
     dev = nets[0]["enc_out"].device
@@ -291,10 +295,17 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         a.actions = dev_ptr(out["actions"], F32, "actions").value
         a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
     ws = decode_workspace(dev, B, n_cat, n_per) if coop_supported(H, n_per, "decode_impl") else None
-    check(_lib.load().gnnpn_pointer_decode_f32(
-        len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
-        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
-        "gnnpn_pointer_decode_f32")
+    lib = _lib.load()
+    if precision == "split":
+        check(lib.gnnpn_set_option(b"lstm_precision", 2), "gnnpn_set_option")
+    try:
+        check(lib.gnnpn_pointer_decode_f32(
+            len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
+            dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
+            "gnnpn_pointer_decode_f32")
+    finally:
+        if precision == "split":
+            check(lib.gnnpn_set_option(b"lstm_precision", 0), "gnnpn_set_option")
     return outs
 
 
