@@ -158,7 +158,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "split"],
@@ -166,6 +166,8 @@ def main():
                          "then carries the agreement with the f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-split-line", action="store_true",
+                    help="skip the second measurement (same workload, precision='split') that an f32 run appends")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): replay each step as one captured HIP graph, per-kernel HIP events in a "
                          "separate eager pass; 0: eager launches with the HIP events inside the timed region "
@@ -222,7 +224,7 @@ def main():
     n_slots = max(1, args.inflight) if args.graph else 1
     runner = PipelinedRunner(pipe, svc, batch, slots=n_slots) if args.graph else None
 
-    def step(i):
+    def step(i, runner=runner):
         if runner is not None:
             out, s = runner.submit()
             stream = runner.stream(s)
@@ -286,6 +288,37 @@ def main():
         timers.enabled = False
     gc.enable()
 
+    # Second measurement, reported beside the headline and never as `value`: the same workload with the
+    # recurrent W_hh.h products computed from fp16 hi+lo operand pairs (precision="split").
+    split_line = None
+    if args.precision == "f32" and args.graph and not args.no_split_line:
+        pipe_s = ML2PNPipeline(net, low, high, K, precision="split")
+        runner_s = PipelinedRunner(pipe_s, svc, batch, slots=n_slots)
+        gc.collect()
+        gc.disable()
+        for i in range(args.warmup):
+            step(i, runner_s)
+        torch.cuda.synchronize()
+        gdist.barrier(world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, runner_s)
+        torch.cuda.synchronize()
+        gdist.barrier(world)
+        el_s = gdist.max_over_ranks(time.perf_counter() - t0, dev, world)
+        gc.enable()
+        ops.check_status(dev)
+        out_s = runner_s.graphs[0].outputs
+        same = (out_s["actions"] == ref["actions"]).all(-1)
+        split_line = {"precision": "W_hh.h of encoder and decoder from fp16 hi+lo operand pairs, fp32 accumulate; rest f32",
+                      "value": round(world * B * args.steps / el_s, 2), "unit": "problems/s",
+                      "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                      "agreement_vs_f32": {"problems_with_identical_selection": round(float(same.all(1).float().mean()), 4),
+                                           "identical_decisions": round(float(same.float().mean()), 5),
+                                           "max_abs_R_diff": round(float((out_s["R"] - ref["R"]).abs().max()), 6)}}
+        del runner_s
+
     if rank != 0:
         gdist.destroy(world)
         return
@@ -335,6 +368,8 @@ def main():
     }
     if agreement is not None:
         line["agreement_vs_f32"] = agreement
+    if split_line is not None:
+        line["split_operands"] = split_line
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, table, pb, net, low, high)
     print(json.dumps(line), flush=True)
