@@ -158,8 +158,17 @@ int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B,
  * bounded inter-workgroup wait timed out (outputs are then invalid). */
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
-/* Run-time switches for A/B measurements: "lstm_impl" / "decode_impl" = 0 auto, 1 streaming,
- * 2 cooperative. */
+/* Run-time switches (process-wide; they select among implementations of the SAME entry points):
+ *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative, two recurrences per workgroup
+ *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups)
+ *   "lstm_precision" operands of the recurrent W_hh.h product of the cooperative kernels:
+ *                    0 fp32 (default); 1 fp16 operands, encoder only (opt-in reduced precision);
+ *                    2 split operands, encoder and decoder: every operand as an fp16 pair (hi, lo*2^11),
+ *                      product = hi.hi + (hi.lo + lo.hi)/2^11 with fp32 accumulation — measured as accurate as
+ *                      the fp32 chain against an fp64 LSTM
+ *   "lstm_ablate"    diagnostics only (tools/): results are wrong when non-zero, except bit 7 = force the
+ *                    placement-independent hand-off.
+ * Unknown names / out-of-range values: GNNPN_E_ARG. */
 int gnnpn_set_option(const char* name, int value);
 
 /* Greedy pointer decode of up to two pointer networks in one call: T steps of {decoder LSTM cell;

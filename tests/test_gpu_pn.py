@@ -304,3 +304,53 @@ def test_split_encoder_matches_fp32_accuracy(dev):
     assert float(same.float().mean()) >= 0.95
     s = same.cpu()
     assert float((a["R"] - b["R"]).abs()[s].max()) <= R_ATOL
+
+
+@pytest.mark.parametrize("B,T,K", [(1, 3, 1), (17, 1, 4), (40, 47, 5), (300, 12, 10), (23, 9, 16)])
+def test_split_precision_ragged_shapes(dev, B, T, K):
+    """precision="split" in both cooperative decoder forms and the encoder on ragged shapes (batch not a multiple
+    of the 16-problem tile, one category, one candidate, K = 16): window logits within 1e-5 of the fp32 path, picks
+    identical wherever the fp32 decision margin exceeds 1e-4, and deterministic across launches."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": T, "n_per": K, "seed_low": 15 + B, "seed_high": 16 + B}
+    low, high = build(cfg, dev)
+    g = torch.Generator().manual_seed(B * T + 1)
+    x = torch.rand(B, T * K, 8, generator=g)
+    x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
+    x[:, K:, 4:] = 0
+    x = x.to(dev)
+    ref = two_level_greedy(low, high, x)
+    outs = []
+    try:
+        for impl in (2, 3, 3):
+            ops.set_option("decode_impl", impl)
+            outs.append(two_level_greedy(low, high, x, precision="split"))
+    finally:
+        ops.set_option("decode_impl", 0)
+    ops.check_status(dev)
+    for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions"):
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    win_ref = torch.stack([ref["win_low"], ref["win_high_raw"] + ref["win_low"]]).cpu()
+    m = opn.decision_margin(win_ref[0], x.cpu()), opn.decision_margin(win_ref[1], x.cpu())
+    robust = (m[0] > 1e-4).all(1) & (m[1] > 1e-4).all(1)
+    for tag, out in (("split8", outs[0]), ("split16", outs[1])):
+        same = assert_index_parity(out["idx_low"], ref["idx_low"], robust, tag + "/low", 0.8, x.cpu()) & \
+            assert_index_parity(out["idx_high"], ref["idx_high"], robust, tag + "/high", 0.8, x.cpu())
+        s = same.to(dev)
+        if bool(s.any()):
+            assert float((out["win_low"][s] - ref["win_low"][s]).abs().max()) < 1e-5
+            assert float((out["win_high_raw"][s] - ref["win_high_raw"][s]).abs().max()) < 1e-5
+            assert float((out["R"][s] - ref["R"][s]).abs().max()) <= R_ATOL
+
+
+def test_split_precision_needs_the_cooperative_form(dev):
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 32, "n_cat": 4, "n_per": 3, "seed_low": 1, "seed_high": 2}
+    low, high = build(cfg, dev)
+    x = torch.rand(3, 12, 8).to(dev)
+    with pytest.raises(ops.GnnpnError):
+        two_level_greedy(low, high, x, precision="split")
+    two_level_greedy(low, high, x)                     # and the failed call left no option behind
+    ops.check_status(dev)
