@@ -102,6 +102,40 @@ __device__ __forceinline__ float cell_act(float x, bool is_tanh) {
     const float th = copysignf(ax < 0.25f ? small : big, x);
     return is_tanh ? th : r;
 }
+// The same activation on TWO values at once: every fmul/fma/fadd of the scalar form becomes one packed
+// instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two results per issue slot); min/max/select and the
+// two transcendentals stay per component.  Operation for operation the same roundings as cell_act, so the
+// results are bit-identical (tests: cooperative == streaming kernels, which use the scalar form).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_set(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 cell_exp2v(f32x2 x) {
+    const f32x2 t = x * pk_set(1.44269502e+00f);
+    f32x2 r = pk_fma(x, pk_set(1.44269502e+00f), -t);
+    r = pk_fma(x, pk_set(1.92596303e-08f), r);
+    const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    return pk_fma(e, r * pk_set(0.693147182f), e);
+}
+__device__ __forceinline__ f32x2 cell_rcp2v(f32x2 d) {
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return pk_fma(pk_fma(-d, r, pk_set(1.0f)), r, r);
+}
+__device__ __forceinline__ f32x2 cell_act2(f32x2 x, bool is_tanh) {
+    const f32x2 ax = {fminf(fabsf(x.x), 43.0f), fminf(fabsf(x.y), 43.0f)};
+    f32x2 ut = pk_set(2.0f) * ax;
+    f32x2 us = {fminf(fmaxf(-x.x, -87.0f), 87.0f), fminf(fmaxf(-x.y, -87.0f), 87.0f)};
+    asm volatile("" : "+v"(ut), "+v"(us));
+    const f32x2 u = is_tanh ? ut : us;
+    const f32x2 r = cell_rcp2v(pk_set(1.0f) + cell_exp2v(u));
+    const f32x2 big = pk_set(1.0f) - pk_set(2.0f) * r;
+    const f32x2 x2 = ax * ax;
+    f32x2 p = pk_fma(x2, pk_set(2.18694885e-02f), pk_set(-5.39682540e-02f));
+    p = pk_fma(x2, p, pk_set(1.33333333e-01f));
+    p = pk_fma(x2, p, pk_set(-3.33333333e-01f));
+    const f32x2 small = pk_fma(ax * x2, p, ax);
+    const f32x2 th = {copysignf(ax.x < 0.25f ? small.x : big.x, x.x), copysignf(ax.y < 0.25f ? small.y : big.y, x.y)};
+    return is_tanh ? th : r;
+}
 __device__ __forceinline__ float cell_sigmoid(float x) { return cell_act(x, false); }
 __device__ __forceinline__ float cell_tanh(float x) { return cell_act(x, true); }
 

@@ -172,6 +172,16 @@ __device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&
 // (f, o) of the same hidden unit; one DPP swap per value, then both halves update (c, h) alike.
 // Same arithmetic as lstm_cell_update (recurrent.h): cy = f*c + i*g ; hy = o*tanh(cy), products and
 // sum rounded separately.
+// two problem rows at once (packed arithmetic, see cell_act2)
+__device__ __forceinline__ void cell_update_pair2(f32x2 g0, f32x2 g1, bool lo_half, f32x2& cst, f32x2& h) {
+    const f32x2 a0 = cell_act2(g0, false);
+    const f32x2 a1 = cell_act2(g1, lo_half);
+    const f32x2 p0 = {swap8(a0.x), swap8(a0.y)}, p1 = {swap8(a1.x), swap8(a1.y)};
+    const f32x2 ig = lo_half ? a0 : p0, gg = lo_half ? a1 : p1;
+    const f32x2 fg = lo_half ? p0 : a0, og = lo_half ? p1 : a1;
+    cst = fg * cst + ig * gg;          // -ffp-contract=off: two rounded products, one rounded sum
+    h = og * cell_act2(cst, true);
+}
 __device__ __forceinline__ void cell_update_pair(float g0, float g1, bool lo_half, float& cst, float& h) {
     const float a0 = cell_act(g0, false);            // sigmoid(i) | sigmoid(f)
     const float a1 = cell_act(g1, lo_half);          // tanh(g)    | sigmoid(o)

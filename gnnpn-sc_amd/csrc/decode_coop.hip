@@ -394,10 +394,15 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
             }
             u64* out_h = xh_g + (step & 1) * (ROWS * H);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float g0 = __fadd_rn(__fadd_rn(ah0[r], bh[0]), gx[0][r]);
-                const float g1 = __fadd_rn(__fadd_rn(ah1[r], bh[1]), gx[1][r]);
-                cell_update_pair(g0, g1, c < 8, cst[r], hl[r]);   // four independent chains, no stores in between
+            for (int r = 0; r < 4; r += 2) {   // two rows per pass: packed fp32 arithmetic, no stores in between
+                const f32x2 g0 = (f32x2{ah0[r], ah0[r + 1]} + pk_set(bh[0])) + f32x2{gx[0][r], gx[0][r + 1]};
+                const f32x2 g1 = (f32x2{ah1[r], ah1[r + 1]} + pk_set(bh[1])) + f32x2{gx[1][r], gx[1][r + 1]};
+                f32x2 cs = {cst[r], cst[r + 1]}, hh;
+                cell_update_pair2(g0, g1, c < 8, cs, hh);
+                cst[r] = cs.x;
+                cst[r + 1] = cs.y;
+                hl[r] = hh.x;
+                hl[r + 1] = hh.y;
             }
             if (c < 8) {
                 u64* dst = out_h + (kq * 4) * H + unit;

@@ -275,11 +275,16 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             // all four rows' cells first (straight-line: the compiler interleaves the four dependent chains),
             // then ONE predicated block of stores
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; r += 2) {   // two rows per pass: packed fp32 arithmetic (cell_act2)
                 // gates = (h.W_hh^T + b_hh) + (x.W_ih^T + b_ih); lanes c<8 hold (i,g), c>=8 hold (f,o)
-                const float g0 = __fadd_rn(__fadd_rn(acc0[r], bh[0]), pg[0][r]);
-                const float g1 = __fadd_rn(__fadd_rn(acc1[r], bh[1]), pg[1][r]);
-                cell_update_pair(g0, g1, c < 8, cst[r], hlast[r]);
+                const f32x2 g0 = (f32x2{acc0[r], acc0[r + 1]} + pk_set(bh[0])) + f32x2{pg[0][r], pg[0][r + 1]};
+                const f32x2 g1 = (f32x2{acc1[r], acc1[r + 1]} + pk_set(bh[1])) + f32x2{pg[1][r], pg[1][r + 1]};
+                f32x2 cs = {cst[r], cst[r + 1]}, hh;
+                cell_update_pair2(g0, g1, c < 8, cs, hh);
+                cst[r] = cs.x;
+                cst[r + 1] = cs.y;
+                hlast[r] = hh.x;
+                hlast[r + 1] = hh.y;
             }
             if (c < 8) {
                 u64* dst = out_buf + (kq * 4) * H + unit;
