@@ -14,6 +14,8 @@ and is computed ONCE per forward from the first ``outChannels`` rows of ``data.x
 reference's B-fold replication inside a PyG batch (modelML.py:145-156,167-172) averages B copies
 of the same thing.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -105,6 +107,8 @@ class Net(nn.Module):
         self.noServicesLins = nn.ModuleList(                                       # :108-115 (state_dict parity)
             nn.Linear(c + self.qosNumber if i == 0 else 2 * h, 2 * h) for i in range(numLayersGCN))
         self._prep = None
+        self.parallel_branches = os.environ.get("GNNPN_SERIAL_BRANCHES") != "1"   # scores(): GCN branch on a side stream
+        self._side_streams = {}
 
     def reset_parameters(self):                                                    # :117-129
         self.nodeEncoder.reset_parameters()
@@ -183,8 +187,23 @@ class Net(nn.Module):
 
     @torch.no_grad()
     def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr):
+        """The two branches are independent until the score product: the service branch (GCN) is forked onto
+        a side stream and joined before the GEMM, so ~20 small launch-latency-bound kernels run two abreast
+        (fork/join is stream-capturable: inside a HIP graph it becomes two parallel branches)."""
+        if not self.parallel_branches:
+            xr = self.request_embedding(x, wf_csr, seg_ptr)
+            xs = self.service_embedding(x_service, svc_csr)
+            return ops.linear(xr, xs, act=ACT_SIGMOID)                                          # :173-176
+        cur = torch.cuda.current_stream(x.device)
+        side = self._side_streams.get(x.device)
+        if side is None:
+            side = self._side_streams[x.device] = torch.cuda.Stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            xs = self.service_embedding(x_service, svc_csr)
         xr = self.request_embedding(x, wf_csr, seg_ptr)
-        xs = self.service_embedding(x_service, svc_csr)
+        cur.wait_stream(side)
+        xs.record_stream(cur)
         return ops.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176
 
     def forward(self, data):
