@@ -129,7 +129,17 @@ class PointerNet(nn.Module):
             self._packed["dec_wfold"] = (d_ih @ w_e).float().contiguous().to(dev)
             self._packed["dec_bfold"] = (d_ih @ self.embedding2.bias.detach().double().cpu() + d_b).float().contiguous().to(dev)
             self._packed["dec_sfold"] = (d_ih @ self.decoder_start_input.detach().double().cpu() + d_b).float().contiguous().to(dev)
+            # largest |W_hh|: the fp16-operand precisions ("split", "f16") need it inside fp16's range
+            self._packed["whh_absmax"] = float(max(self.encoder.weight_hh_l0.detach().abs().max(),
+                                                   self.decoder.weight_hh_l0.detach().abs().max()))
         return self._packed
+
+    def check_precision(self, precision):
+        """fp16-operand modes hold W_hh as fp16 (pairs): refuse weights outside fp16's finite range."""
+        if precision != "f32":
+            m = self.packed()["whh_absmax"]
+            if not m < 6.0e4:
+                raise ops.GnnpnError(f"precision={precision!r}: max |W_hh| = {m:g} does not fit fp16 operands; use 'f32'")
 
     def encode_args(self, inputs, fold=None):
         """One entry of the ``nets`` list of ops.lstm_encode (+ the embedded tensor when the literal
@@ -276,6 +286,8 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32"):
     accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision)."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
+    la.check_precision(precision)
+    ha.check_precision(precision)
     enc_l, emb_l = la.encode_args(inputs, fold)
     enc_h, emb_h = ha.encode_args(inputs, fold)
     enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h], precision=precision)

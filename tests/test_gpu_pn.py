@@ -354,3 +354,18 @@ def test_split_precision_needs_the_cooperative_form(dev):
         two_level_greedy(low, high, x, precision="split")
     two_level_greedy(low, high, x)                     # and the failed call left no option behind
     ops.check_status(dev)
+
+
+def test_split_precision_refuses_weights_outside_fp16_range(dev):
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": 3, "n_per": 2, "seed_low": 1, "seed_high": 2}
+    low, high = build(cfg, dev)
+    with torch.no_grad():
+        high.actor.decoder.weight_hh_l0[5, 7] = 7.0e4
+    x = torch.rand(4, 6, 8).to(dev)
+    for precision in ("split", "f16"):
+        with pytest.raises(ops.GnnpnError):
+            two_level_greedy(low, high, x, precision=precision)
+    two_level_greedy(low, high, x)      # plain fp32 takes any finite weight
+    ops.check_status(dev)
