@@ -271,7 +271,8 @@ def main():
                 raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
     n_timed = args.steps
     if args.graph and not args.no_kernel_timers:
-        runner.reference_run(0)          # untimed: first eager launch of each kernel in this process
+        for _ in range(3):               # untimed: first eager launches of each kernel in this process, clocks settle
+            runner.reference_run(0)
         torch.cuda.synchronize()
         # An event pair measures GPU time between its two markers, so a host stall between them would be
         # booked as kernel time once the stream has run dry (a generation-2 Python GC pass over the
