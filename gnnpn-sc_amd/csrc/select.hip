@@ -111,14 +111,53 @@ __global__ __launch_bounds__(1024) void rank_rows_kernel(const float* __restrict
     for (int i = threadIdx.x; i < S; i += blockDim.x) out[i] = (int32_t)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffu));
 }
 
+// Rows of 16385..32768 services (BASELINE configs[4]: S = 20000): the 64-bit keys no longer fit the LDS, so the
+// same bitonic network runs on 32-bit service ids in LDS and forms each key from the (L2-resident) score row
+// when it compares.  Identical order by construction; only used on the artefact path.
+__global__ __launch_bounds__(1024) void rank_rows_indirect_kernel(const float* __restrict__ scores, int64_t ld_scores,
+                                                                  int32_t* __restrict__ ranking, int32_t S, int32_t P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int ids[];
+    const float* srow = scores + (int64_t)blockIdx.x * ld_scores;
+    auto key_of = [&](unsigned int i) { return i < (unsigned)S ? rank_key(srow[i], i) : 0ull; };
+    for (int i = threadIdx.x; i < P; i += blockDim.x) ids[i] = (unsigned)i;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));
+                const int p = i + j;
+                const bool desc = (i & k) == 0;
+                const unsigned int ia = ids[i], ib = ids[p];
+                if ((key_of(ia) < key_of(ib)) == desc) {
+                    ids[i] = ib;
+                    ids[p] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int32_t* out = ranking + (int64_t)blockIdx.x * S;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) out[i] = (int32_t)ids[i];
+}
+
 extern "C" int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
                                void* stream) {
     GNNPN_REQUIRE(scores && ranking, "rank_rows: null operand");
     GNNPN_REQUIRE(B >= 0 && S > 0 && ld_scores >= S, "rank_rows: bad shape");
-    if (S > 16384) GNNPN_FAIL(GNNPN_E_UNSUP, "rank_rows: S=%d exceeds the single-workgroup LDS sort (16384)", S);
+    if (S > 32768) GNNPN_FAIL(GNNPN_E_UNSUP, "rank_rows: S=%d exceeds the single-workgroup LDS sort (32768)", S);
     if (B == 0) return GNNPN_OK;
     int P = 2;
     while (P < S) P <<= 1;
+    if (S > 16384) {
+        const size_t lds_i = (size_t)P * sizeof(unsigned int);
+        hipError_t ei = hipFuncSetAttribute((const void*)rank_rows_indirect_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i);
+        if (ei != hipSuccess) GNNPN_FAIL(GNNPN_E_LAUNCH, "rank_rows: cannot reserve %zu B of LDS: %s", lds_i, hipGetErrorString(ei));
+        hipLaunchKernelGGL(rank_rows_indirect_kernel, dim3(B), dim3(1024), lds_i, (hipStream_t)stream, scores, ld_scores,
+                           ranking, S, P);
+        GNNPN_CHECK_LAUNCH("rank_rows");
+        return GNNPN_OK;
+    }
     const size_t lds = (size_t)P * sizeof(unsigned long long);
     hipError_t e = hipFuncSetAttribute((const void*)rank_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) GNNPN_FAIL(GNNPN_E_LAUNCH, "rank_rows: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

@@ -110,7 +110,8 @@ int gnnpn_select_candidates(const float* scores, int64_t ld_scores, const int32_
                             int32_t* out_ids, int32_t B, int32_t T, int32_t n_per, void* stream);
 
 /* Full descending ranking of every score row (ties: lowest id first): ranking [B,S] int32.
- * S <= 16384 (one LDS sort per row).  Replaces `_x.sort(dim=0, descending=True)` of src/models/trainML.py:62 (whose tie
+ * S <= 32768 (one LDS bitonic sort per row: 64-bit keys up to 16384, service ids with keys formed on the fly above).
+ * Replaces `_x.sort(dim=0, descending=True)` of src/models/trainML.py:62 (whose tie
  * order is undefined). */
 int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
                     void* stream);

@@ -260,7 +260,7 @@ def test_select_candidates_vs_oracle(dev):
     assert (ids.cpu()[(want[:, :, :4] == torch.tensor([0., 1., 1., 1.])).all(-1)] == -1).all()
 
 
-@pytest.mark.parametrize("B,S", [(3, 40), (4, 2507), (2, 16384)])
+@pytest.mark.parametrize("B,S", [(3, 40), (4, 2507), (2, 16384), (2, 16385), (3, 20000), (1, 32768)])
 def test_rank_rows(dev, B, S):
     ops = _ops()
     g = torch.Generator().manual_seed(S)
