@@ -9,8 +9,7 @@ extern "C" int gnnpn_abi_version(void) { return GNNPN_ABI_VERSION; }
 extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 
 // ---- run-time options (A/B switches for tests and benchmarks) ---------------------------------
-static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0, g_lstm_precision = 0;
-int gnnpn_option_lstm_precision() { return g_lstm_precision; }
+static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0;
 int gnnpn_option_lstm_ablate() { return g_lstm_ablate; }
 int gnnpn_option_lstm_impl() { return g_lstm_impl; }
 int gnnpn_option_decode_impl() { return g_decode_impl; }
@@ -24,11 +23,6 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "lstm_ablate")) {   // bit0 no MFMA, bit1 no transcendentals, bit2 no tag wait, bit3 no sweep, bit4 no publish
         g_lstm_ablate = value;
-        return GNNPN_OK;
-    }
-    if (!strcmp(name, "lstm_precision")) {   // encoder's recurrent product (cooperative form): 0 fp32, 1 fp16 operands, 2 fp16-split operands
-        GNNPN_REQUIRE(value >= 0 && value <= 2, "set_option: lstm_precision must be 0 (fp32), 1 (fp16) or 2 (fp16 split)");
-        g_lstm_precision = value;
         return GNNPN_OK;
     }
     if (!strcmp(name, "decode_impl")) {

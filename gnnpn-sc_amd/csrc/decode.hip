@@ -163,8 +163,9 @@ static void launch_decode(const float* embedded, const float* enc_out, const flo
 
 extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const float* inputs,
                                         float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
-                                        void* workspace, int64_t workspace_bytes, void* stream) {
+                                        int32_t precision, void* workspace, int64_t workspace_bytes, void* stream) {
     GNNPN_REQUIRE(nets && inputs, "pointer_decode: null input");
+    GNNPN_REQUIRE(precision == GNNPN_PREC_F32 || precision == GNNPN_PREC_SPLIT, "pointer_decode: precision must be GNNPN_PREC_F32 or GNNPN_PREC_SPLIT, got %d", precision);
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_DECODE_NETS, "pointer_decode: n_nets must be 1..%d",
                   GNNPN_MAX_DECODE_NETS);
     GNNPN_REQUIRE(B >= 0 && T > 0, "pointer_decode: bad shape");
@@ -205,16 +206,16 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         // pipelines two steps: 1.345 -> 1.313 ms/step).
         int rc;
         if (impl == 3) {
-            rc = gnnpn_launch_decode_coop2(args, n_nets, workspace, workspace_bytes, s);
-            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+            rc = gnnpn_launch_decode_coop2(args, n_nets, precision, workspace, workspace_bytes, s);
+            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, precision, workspace, workspace_bytes, s);
         } else {
-            rc = gnnpn_launch_decode_coop(args, n_nets, workspace, workspace_bytes, s);
+            rc = gnnpn_launch_decode_coop(args, n_nets, precision, workspace, workspace_bytes, s);
         }
         if (rc != GNNPN_OK) return rc;
         GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
         return GNNPN_OK;
     }
-    if (gnnpn_option_lstm_precision() == 2)
+    if (precision == GNNPN_PREC_SPLIT)
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand precision needs the cooperative form (H = 256)");
     for (int n = 0; n < n_nets; ++n) {   // streaming form: one net after the other (Low before High)
         const DecodeNet& d = args.net[n];

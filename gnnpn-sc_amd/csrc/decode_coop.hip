@@ -469,7 +469,7 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
 
 bool gnnpn_decode_coop_supported(int32_t H_, int32_t n_per) { return H_ == H && n_per <= KMAX; }
 
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
                              hipStream_t s) {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -501,7 +501,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate();
-    const bool split = gnnpn_option_lstm_precision() == 2;   // "split" precision: fp16 hi+lo operands in W_hh.h
+    const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
     if (split)

@@ -351,7 +351,7 @@ int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per) 
 
 // GNNPN_E_UNSUP (error text untouched) when this form does not fit the call: the caller then uses
 // decode_coop.hip
-int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
                               hipStream_t s) {
     for (int n = 0; n < n_nets; ++n)
         if (!args.net[n].xw_fold) return GNNPN_E_UNSUP;
@@ -380,7 +380,7 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, void* workspac
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate();
-    const bool split = gnnpn_option_lstm_precision() == 2;
+    const bool split = precision == GNNPN_PREC_SPLIT;
 #define GNNPN_DEC2(NP_)                                                                                          \
     do {                                                                                                         \
         if (split)                                                                                               \

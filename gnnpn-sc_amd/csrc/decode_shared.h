@@ -40,9 +40,9 @@ struct DecodeArgs {
 };
 
 bool gnnpn_decode_coop_supported(int32_t H, int32_t n_per);
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
                              hipStream_t s);
-int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
                               hipStream_t s);
 int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per);
 int gnnpn_option_decode_impl();

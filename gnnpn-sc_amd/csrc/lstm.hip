@@ -85,10 +85,12 @@ static int launch_encode(const LstmNets& nets, int n_nets, int32_t B, int32_t L,
 }
 
 extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, int32_t B, int32_t L, int32_t H,
-                                     int32_t F, void* workspace, int64_t workspace_bytes, void* stream) {
+                                     int32_t F, int32_t precision, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
     GNNPN_REQUIRE(in, "lstm_encode: null net array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
+    GNNPN_REQUIRE(precision >= GNNPN_PREC_F32 && precision <= GNNPN_PREC_SPLIT, "lstm_encode: unknown precision %d", precision);
     if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: hidden size %d not built (256, 32)", H);
     LstmNets nets{};
     bool any_fold = false;
@@ -116,6 +118,8 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl >= 2);
     if (!coop && any_fold)
         GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the streaming form needs precomputed pregates");
+    if (precision != GNNPN_PREC_F32 && (!coop || impl == 3))
+        GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: fp16-operand precisions need the cooperative form (H = 256, workspace)");
     if (coop) {
         // default: one recurrence per workgroup (lstm_coop.hip).  impl 3 selects the two-recurrences-per-
         // workgroup variant (lstm_coop2.hip): bit-identical, measured 1.25 vs 1.09 ms at QWS B=256 — the
@@ -127,7 +131,7 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
             if (rc == GNNPN_E_UNSUP)
                 GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the two-recurrence cooperative form does not fit this call");
         } else {
-            rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, workspace, workspace_bytes, s);
+            rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, precision, workspace, workspace_bytes, s);
         }
         if (rc != GNNPN_OK) return rc;
     } else if (H == 256) {

@@ -348,7 +348,7 @@ extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
     return a > b ? a : b;
 }
 
-int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,
                              int64_t workspace_bytes, hipStream_t s) {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -375,7 +375,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     for (int n = 0; n < n_nets; ++n)
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
-    const int prec = gnnpn_option_lstm_precision();   // 0 fp32, 1 fp16 operands, 2 fp16-split operands
+    const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
     const int abl = gnnpn_option_lstm_ablate();
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, \

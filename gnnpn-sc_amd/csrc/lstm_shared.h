@@ -17,11 +17,10 @@ struct LstmNets {
 };
 
 
-int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,
                              int64_t workspace_bytes, hipStream_t s);
 int gnnpn_launch_encode_coop2(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
                               int64_t workspace_bytes, hipStream_t s);
 int64_t gnnpn_encode_coop2_workspace_bytes();
 int gnnpn_option_lstm_impl();
-int gnnpn_option_lstm_precision();   // 0 fp32 (default, parity), 1 fp16 operands in the recurrent product (opt-in)
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

@@ -145,7 +145,7 @@ def set_option(name, value):
     _options[name] = int(value)
 
 
-# encoder operand precision of the recurrent product -> gnnpn_set_option("lstm_precision", .)
+# operand precision of the recurrent W_hh.h product -> GNNPN_PREC_* (include/gnnpn_hip.h)
 _PRECISIONS = {"f32": 0, "f16": 1, "split": 2}
 
 
@@ -221,15 +221,9 @@ def lstm_encode(nets, precision="f32"):
         raise GnnpnError(f"lstm_encode: unknown precision {precision!r}")
     if precision != "f32" and not coop:
         raise GnnpnError(f"lstm_encode: precision={precision!r} needs the cooperative form (H = 256)")
-    lib = _lib.load()
-    if precision != "f32":
-        check(lib.gnnpn_set_option(b"lstm_precision", _PRECISIONS[precision]), "gnnpn_set_option")
-    try:
-        check(lib.gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, dev_ptr(ws, torch.uint8, "workspace", True),
-                                        0 if ws is None else ws.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
-    finally:
-        if precision != "f32":
-            check(lib.gnnpn_set_option(b"lstm_precision", 0), "gnnpn_set_option")
+    check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, _PRECISIONS[precision],
+                                            dev_ptr(ws, torch.uint8, "workspace", True),
+                                            0 if ws is None else ws.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
     return enc, h_n, c_n
 
 
@@ -295,17 +289,11 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         a.actions = dev_ptr(out["actions"], F32, "actions").value
         a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
     ws = decode_workspace(dev, B, n_cat, n_per) if coop_supported(H, n_per, "decode_impl") else None
-    lib = _lib.load()
-    if precision == "split":
-        check(lib.gnnpn_set_option(b"lstm_precision", 2), "gnnpn_set_option")
-    try:
-        check(lib.gnnpn_pointer_decode_f32(
-            len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
-            dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
-            "gnnpn_pointer_decode_f32")
-    finally:
-        if precision == "split":
-            check(lib.gnnpn_set_option(b"lstm_precision", 0), "gnnpn_set_option")
+    check(_lib.load().gnnpn_pointer_decode_f32(
+        len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
+        _PRECISIONS["split"] if precision == "split" else 0,
+        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
+        "gnnpn_pointer_decode_f32")
     return outs
 
 

@@ -150,8 +150,17 @@ typedef struct {
     float* c_n;
 } gnnpn_encode_net_t;
 
+/* precision: operands of the recurrent W_hh.h product (accumulation, cell, outputs are fp32 in every mode)
+ *   GNNPN_PREC_F32   fp32 (the parity path)
+ *   GNNPN_PREC_F16   fp16 operands, encoder only: opt-in reduced precision (BASELINE configs[4])
+ *   GNNPN_PREC_SPLIT every operand as an fp16 pair (hi, lo*2^11), product = hi.hi + (hi.lo + lo.hi)/2^11 with fp32
+ *                    accumulation — measured as accurate as the fp32 chain against an fp64 LSTM
+ * F16/SPLIT need the cooperative form (H = 256 and a workspace): GNNPN_E_UNSUP otherwise. */
+#define GNNPN_PREC_F32 0
+#define GNNPN_PREC_F16 1
+#define GNNPN_PREC_SPLIT 2
 int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B, int32_t L, int32_t H,
-                          int32_t F, void* workspace, int64_t workspace_bytes, void* stream);
+                          int32_t F, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Size of the device workspace the cooperative encoder needs (status words + hand-off buffers).
  * With workspace == NULL gnnpn_lstm_encode_f32 uses the per-workgroup streaming form instead.
@@ -162,11 +171,6 @@ int64_t gnnpn_lstm_encode_workspace_bytes(void);
 /* Run-time switches (process-wide; they select among implementations of the SAME entry points):
  *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative, two recurrences per workgroup
  *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups)
- *   "lstm_precision" operands of the recurrent W_hh.h product of the cooperative kernels:
- *                    0 fp32 (default); 1 fp16 operands, encoder only (opt-in reduced precision);
- *                    2 split operands, encoder and decoder: every operand as an fp16 pair (hi, lo*2^11),
- *                      product = hi.hi + (hi.lo + lo.hi)/2^11 with fp32 accumulation — measured as accurate as
- *                      the fp32 chain against an fp64 LSTM
  *   "lstm_ablate"    diagnostics only (tools/): results are wrong when non-zero, except bit 7 = force the
  *                    placement-independent hand-off.
  * Unknown names / out-of-range values: GNNPN_E_ARG. */
@@ -223,9 +227,10 @@ typedef struct {
     int32_t reserved;
 } gnnpn_decode_net_t;
 
+/* precision: GNNPN_PREC_F32 or GNNPN_PREC_SPLIT (the decoder cell's W_hh.h product; cooperative, folded form). */
 int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const float* inputs,
                              float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
-                             void* workspace, int64_t workspace_bytes, void* stream);
+                             int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Workspace the cooperative decoder needs for this shape (status words, hand-off buffers, the
  * Low->High latent granules).  Word 0 after synchronisation: as for the encoder. */

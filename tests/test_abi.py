@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.gnnpn_linear_f32(None, 4, None, 4, None, None, None, 0, None, 4, 2, 2, 4, None)
     assert rc == -1 and b"null" in lib.gnnpn_last_error()
-    rc = lib.gnnpn_lstm_encode_f32(9, None, 1, 1, 256, 8, None, 0, None)
+    rc = lib.gnnpn_lstm_encode_f32(9, None, 1, 1, 256, 8, 0, None, 0, None)
     assert rc == -1 and b"n_nets" in lib.gnnpn_last_error()
     rc = lib.gnnpn_rank_rows(ctypes.c_void_p(16), 40000, ctypes.c_void_p(16), 1, 40000, None)
     assert rc == -2                                     # unsupported size is reported, not truncated

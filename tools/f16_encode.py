@@ -13,12 +13,12 @@ x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
 x[:, K:, 4:] = 0
 x = x.to(dev)
 def run(prec):
-    ops.set_option("lstm_precision", prec)
-    for _ in range(3): out = two_level_greedy(low, high, x)
+    prec = {0: "f32", 1: "f16", 2: "split"}[prec]
+    for _ in range(3): out = two_level_greedy(low, high, x, precision=prec)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): out = two_level_greedy(low, high, x)
+    for _ in range(10): out = two_level_greedy(low, high, x, precision=prec)
     e1.record(); torch.cuda.synchronize()
     return out, e0.elapsed_time(e1) / 10
 a, ta = run(0)
@@ -26,7 +26,6 @@ b, tb = run(1)
 a, ta2 = run(0)
 b, tb2 = run(1)
 print("repeat:", round(ta2, 3), round(tb2, 3))
-ops.set_option("lstm_precision", 0)
 ops.check_status(dev)
 same_low = (a["idx_low"] == b["idx_low"]).all(1).float().mean().item()
 same_high = (a["idx_high"] == b["idx_high"]).all(1).float().mean().item()
