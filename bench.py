@@ -160,8 +160,8 @@ def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "split"],
