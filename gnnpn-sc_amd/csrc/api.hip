@@ -9,7 +9,8 @@ extern "C" int gnnpn_abi_version(void) { return GNNPN_ABI_VERSION; }
 extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 
 // ---- run-time options (A/B switches for tests and benchmarks) ---------------------------------
-static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0;
+static int g_lstm_impl = 0, g_decode_impl = 0, g_lstm_ablate = 0, g_coop_lds_kb = 0;
+int gnnpn_option_coop_lds_kb() { return g_coop_lds_kb; }
 int gnnpn_option_lstm_ablate() { return g_lstm_ablate; }
 int gnnpn_option_lstm_impl() { return g_lstm_impl; }
 int gnnpn_option_decode_impl() { return g_decode_impl; }
@@ -23,6 +24,13 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "lstm_ablate")) {   // bit0 no MFMA, bit1 no transcendentals, bit2 no tag wait, bit3 no sweep, bit4 no publish
         g_lstm_ablate = value;
+        return GNNPN_OK;
+    }
+    if (!strcmp(name, "coop_lds_kb")) {   // LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative
+        // kernels launched from now on; 0 = just what they use.  Placement control for co-resident launches:
+        // with 100 KB on one stream and 56 KB on the other a CU takes one workgroup of each, never two of the first.
+        GNNPN_REQUIRE(value >= 0 && value <= 160, "set_option: coop_lds_kb must be 0..160");
+        g_coop_lds_kb = value;
         return GNNPN_OK;
     }
     if (!strcmp(name, "decode_impl")) {

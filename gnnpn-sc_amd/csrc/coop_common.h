@@ -38,6 +38,17 @@ __device__ __forceinline__ void granule_publish(u64* p, unsigned tag, float v, b
     else granule_store(p, tag, v);
 }
 
+// Host side: bytes of (unused) dynamic LDS that bring `func`'s footprint to the "coop_lds_kb" option.
+inline unsigned coop_lds_padding(const void* func, int target_kb) {
+    if (target_kb <= 0) return 0;
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, func) != hipSuccess) return 0;
+    const long dyn = (long)target_kb * 1024 - (long)a.sharedSizeBytes;
+    if (dyn <= 0) return 0;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return 0;
+    return (unsigned)dyn;
+}
+
 // Called by every thread of the workgroup.  Returns 1 (group on one XCD), 0 (not), -1 (a member did
 // not show up within the spin bound).  `flag` is one int of LDS.
 template <int G>

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
         return;
     }
     const bool same_xcd = same == 1 && !(ablate & 128);   // h and partial-dot granules stay inside the group
+    if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
         return;
     }
     const bool same_xcd = same == 1 && !(ablate & 128);
+    if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;
@@ -381,14 +382,17 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate();
     const bool split = precision == GNNPN_PREC_SPLIT;
+    const int lds_kb = gnnpn_option_coop_lds_kb();
 #define GNNPN_DEC2(NP_)                                                                                          \
     do {                                                                                                         \
         if (split)                                                                                               \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, \
-                               p_p, p_l, p_e, n_nets, groups_per_net, abl);                                      \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(groups * G), dim3(256),           \
+                               coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, true>, lds_kb), s, args, \
+                               p_h, p_p, p_l, p_e, n_nets, groups_per_net, abl);                                 \
         else                                                                                                     \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, \
-                               p_p, p_l, p_e, n_nets, groups_per_net, abl);                                      \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(groups * G), dim3(256),          \
+                               coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, false>, lds_kb), s, args, \
+                               p_h, p_p, p_l, p_e, n_nets, groups_per_net, abl);                                 \
     } while (0)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);

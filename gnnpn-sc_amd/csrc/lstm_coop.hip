@@ -377,8 +377,10 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
     const int abl = gnnpn_option_lstm_ablate();
+    const int lds_kb = gnnpn_option_coop_lds_kb();
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
-    hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256), 0, s, nets, p_x, \
+    hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256),              \
+                       coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
                        p_e, B, L, n_nets, groups_per_net, abl)
     if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
         if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");

@@ -10,6 +10,7 @@ the stages:
 Inputs are ``DeviceBatch``/``DeviceServices`` (packed once from the host structures of synth.py /
 loadData.py); outputs stay on the device.
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -160,12 +161,23 @@ class PipelinedRunner:
         self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
         self.streams = [torch.cuda.Stream() for _ in range(self.n_slots)]
         self.decode_impl = 3 if self.n_slots > 1 else 0
+        # Placement control for two slots: a CU holds two of the big (256-register) workgroups.  Left to the
+        # dispatcher, two workgroups of the SAME launch can land on one CU (and none on another); whichever kernel
+        # follows on that stream inherits the lopsided slots, so the imbalance persists (measured: 1.15 vs
+        # 1.27-1.42 ms/step, chosen at every restart).  Slot 0's cooperative kernels are padded to 100 KB of LDS
+        # and slot 1's to 56 KB: 100 + 56 fits a CU's 160 KB, 100 + 100 does not.
+        env = os.environ.get("GNNPN_SLOT_LDS_KB")
+        self.lds_kb = [int(v) for v in env.split(",")] if env else ([100, 56] if self.n_slots == 2 else [0] * self.n_slots)
         ops.set_option("decode_impl", self.decode_impl)
         try:
             self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
-            self.graphs = [pipe.capture(services, self.batches[s], slot=s) for s in range(self.n_slots)]
+            self.graphs = []
+            for s in range(self.n_slots):
+                ops.set_option("coop_lds_kb", self.lds_kb[s])
+                self.graphs.append(pipe.capture(services, self.batches[s], slot=s))
         finally:
             ops.set_option("decode_impl", 0)
+            ops.set_option("coop_lds_kb", 0)
         self.count = 0
 
     @staticmethod

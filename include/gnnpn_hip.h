@@ -171,6 +171,9 @@ int64_t gnnpn_lstm_encode_workspace_bytes(void);
 /* Run-time switches (process-wide; they select among implementations of the SAME entry points):
  *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative, two recurrences per workgroup
  *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups)
+ *   "coop_lds_kb"    LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernels
+ *                    launched from now on, 0 = none: placement control for two launches sharing the CUs
+ *                    (100 on one stream + 56 on the other: a CU takes one workgroup of each, never two of one)
  *   "lstm_ablate"    diagnostics only (tools/): results are wrong when non-zero, except bit 7 = force the
  *                    placement-independent hand-off.
  * Unknown names / out-of-range values: GNNPN_E_ARG. */

@@ -9,12 +9,12 @@ w = bench.WORKLOADS["qws"]
 table = synth.make_service_table(w["T"], w["S"], seed=0, degree=32)
 pb = synth.make_problem_batch(table, w["B"], seed=1, tasks_per_problem=w["n_t"])
 net, low, high = bench.build_models(w["T"], w["S"], w["K"], dev, w["n_gcn"])
-for prec in ("f32", "split"):
+for prec in os.environ.get("PRECS", "f32,split").split(","):
     pipe = ML2PNPipeline(net, low, high, w["K"], precision=prec)
     svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
     runner = PipelinedRunner(pipe, svc, batch, slots=2)
     n = 100
-    for mode in ("free", "lockstep", "free"):
+    for mode in os.environ.get("MODES", "free,lockstep,free").split(","):
         for _ in range(10): runner.submit()
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(), torch.cuda.Event()]
