@@ -13,14 +13,14 @@ cp(f"{O}/bench_normal.json", "r01_normal_b1024_bench.json")
 cp(f"{O}/bench_synth4.json", "r01_synth4_b512_bench.json")
 cp(f"{O}/aggregate_roofline.json", "r01_csr_aggregate_replicated_roofline.json")
 for d, name in (("prof_default", "r01_final_default_cmd_kernel_stats.csv"), ("prof_solo", "r01_final_solo_eager_kernel_stats.csv")):
-    f = glob.glob(f"{O}/{d}/*/*kernel_stats.csv")
-    if f: cp(f[0], name)
+    f = sorted(glob.glob(f"{O}/{d}/*/*kernel_stats.csv"), key=os.path.getmtime)   # newest run (older merges stay around)
+    if f: cp(f[-1], name)
 vals = collections.defaultdict(dict)
 for name in ("fetch", "write"):
-    f = glob.glob(f"{O}/pmc_{name}/*/*counter_collection.csv")
+    f = sorted(glob.glob(f"{O}/pmc_{name}/*/*counter_collection.csv"), key=os.path.getmtime)
     if not f: continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])): agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for r in csv.DictReader(open(f[-1])): agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(P, f"r01_final_pmc_{name}_size_summary.csv"), "w") as o:
         o.write("kernel,dispatches,mean_counter_value_KB\n")
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
