@@ -1,0 +1,48 @@
+"""Soak test of the two-slot pipeline: N steps with a different batch every step, every output compared with a
+single-stream run of the same batch (bit for bit), hand-off status checked at the end.  Usage: soak_pipeline.py [N] [precision]"""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnnpn_sc_amd import ops, synth
+from gnnpn_sc_amd.pipeline import ML2PNPipeline, DeviceServices, DeviceBatch, PipelinedRunner
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
+dev = torch.device("cuda:0")
+w = bench.WORKLOADS["qws"]
+table = synth.make_service_table(w["T"], w["S"], seed=0, degree=32)
+net, low, high = bench.build_models(w["T"], w["S"], w["K"], dev, w["n_gcn"])
+pipe = ML2PNPipeline(net, low, high, w["K"], precision=prec)
+svc = DeviceServices.from_table(table, dev)
+n_var = 12
+batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, w["B"], seed=100 + i, tasks_per_problem=w["n_t"]), dev)
+           for i in range(n_var)]
+runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+ops.set_option("decode_impl", runner.decode_impl)
+refs = [pipe.run(svc, b) for b in batches]           # single stream, same kernels
+ops.set_option("decode_impl", 0)
+torch.cuda.synchronize()
+keys = ("idx_low", "idx_high", "R", "actions", "win_low", "win_high_raw")
+bad, t0 = 0, time.time()
+pending = []                                          # (step, slot, variant, event)
+for i in range(N):
+    v = (i * 7 + i // 5) % n_var
+    out, s = runner.submit(batches[v])
+    ev = torch.cuda.Event(); ev.record(runner.stream(s))
+    snap = None
+    pending.append((i, s, v, ev, out))
+    if len(pending) == 2:                             # check the older step before its slot is reused
+        j, sj, vj, evj, oj = pending.pop(0)
+        evj.synchronize()
+        for k in keys:
+            if not torch.equal(oj[k], refs[vj][k]):
+                bad += 1
+                print(f"step {j} slot {sj} batch {vj}: {k} differs ({int((oj[k] != refs[vj][k]).sum())} elements)")
+                break
+for j, sj, vj, evj, oj in pending:
+    evj.synchronize()
+    for k in keys:
+        if not torch.equal(oj[k], refs[vj][k]):
+            bad += 1; print(f"step {j}: {k} differs"); break
+ops.check_status(dev)
+print(f"{N} steps ({prec}), {bad} mismatching, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
