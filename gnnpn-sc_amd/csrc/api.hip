@@ -18,7 +18,7 @@ int gnnpn_option_decode_impl() { return g_decode_impl; }
 extern "C" int gnnpn_set_option(const char* name, int value) {
     if (!name) GNNPN_FAIL(GNNPN_E_ARG, "set_option: null name");
     if (!strcmp(name, "lstm_impl")) {
-        GNNPN_REQUIRE(value >= 0 && value <= 3, "set_option: lstm_impl must be 0 (auto), 1 (streaming), 2 (cooperative) or 3 (cooperative, two recurrences per workgroup)");
+        GNNPN_REQUIRE(value >= 0 && value <= 2, "set_option: lstm_impl must be 0 (auto), 1 (streaming) or 2 (cooperative)");
         g_lstm_impl = value;
         return GNNPN_OK;
     }

@@ -114,25 +114,14 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     if (any_fold) GNNPN_REQUIRE(F == 8, "lstm_encode: in-kernel input projection is built for F = 8, got %d", F);
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int impl = gnnpn_option_lstm_impl();   // 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative x2
+    const int impl = gnnpn_option_lstm_impl();   // 0 auto, 1 streaming, 2 cooperative
     const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl >= 2);
     if (!coop && any_fold)
         GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the streaming form needs precomputed pregates");
-    if (precision != GNNPN_PREC_F32 && (!coop || impl == 3))
+    if (precision != GNNPN_PREC_F32 && !coop)
         GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: fp16-operand precisions need the cooperative form (H = 256, workspace)");
     if (coop) {
-        // default: one recurrence per workgroup (lstm_coop.hip).  impl 3 selects the two-recurrences-per-
-        // workgroup variant (lstm_coop2.hip): bit-identical, measured 1.25 vs 1.09 ms at QWS B=256 — the
-        // halves slow each other about as much as they overlap — and it cannot share the CUs with a second
-        // in-flight launch, so it is kept as a tested alternative, not the default.
-        int rc;
-        if (impl == 3) {
-            rc = gnnpn_launch_encode_coop2(nets, n_nets, B, L, workspace, workspace_bytes, s);
-            if (rc == GNNPN_E_UNSUP)
-                GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the two-recurrence cooperative form does not fit this call");
-        } else {
-            rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, precision, workspace, workspace_bytes, s);
-        }
+        const int rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, precision, workspace, workspace_bytes, s);
         if (rc != GNNPN_OK) return rc;
     } else if (H == 256) {
         launch_encode<256>(nets, n_nets, B, L, s);

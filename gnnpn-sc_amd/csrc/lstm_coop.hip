@@ -343,9 +343,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
 // workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
 // stamps, hello granules), then the exchange buffers
 extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
-    const int64_t a = COOP_STATUS_BYTES + (int64_t)64 * GROUP_GRANULES * sizeof(u64);   // up to 64 groups
-    const int64_t b = gnnpn_encode_coop2_workspace_bytes();
-    return a > b ? a : b;
+    return COOP_STATUS_BYTES + (int64_t)64 * GROUP_GRANULES * sizeof(u64);   // up to 64 groups
 }
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,

@@ -19,9 +19,6 @@ struct LstmNets {
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,
                              int64_t workspace_bytes, hipStream_t s);
-int gnnpn_launch_encode_coop2(const LstmNets& nets, int n_nets, int32_t B, int32_t L, void* workspace,
-                              int64_t workspace_bytes, hipStream_t s);
-int64_t gnnpn_encode_coop2_workspace_bytes();
 int gnnpn_option_coop_lds_kb();   // LDS footprint target of the cooperative kernels (placement control), 0 = none
 int gnnpn_option_lstm_impl();
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

@@ -169,7 +169,7 @@ int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B,
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
 /* Run-time switches (process-wide; they select among implementations of the SAME entry points):
- *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative, two recurrences per workgroup
+ *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups)
  *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups)
  *   "coop_lds_kb"    LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernels
  *                    launched from now on, 0 = none: placement control for two launches sharing the CUs

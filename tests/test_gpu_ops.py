@@ -170,7 +170,7 @@ def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
     try:
         ops.set_option("lstm_impl", 1)
         ref = ops.lstm_encode(args)
-        ops.set_option("lstm_impl", 3 if nets in (1, 2, 4) else 2)   # two recurrences per workgroup (opt-in variant)
+        ops.set_option("lstm_impl", 2)      # cooperative form forced
         out_a = ops.lstm_encode(args)
         ops.set_option("lstm_impl", 0)      # default cooperative form: one recurrence per workgroup, 8-CU groups
         out = ops.lstm_encode(args)
