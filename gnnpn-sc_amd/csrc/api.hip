@@ -34,7 +34,7 @@ extern "C" int gnnpn_set_option(const char* name, int value) {
         return GNNPN_OK;
     }
     if (!strcmp(name, "decode_impl")) {
-        GNNPN_REQUIRE(value >= 0 && value <= 3, "set_option: decode_impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups) or 3 (16-CU groups)");
+        GNNPN_REQUIRE(value >= 0 && value <= 4, "set_option: decode_impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups), 3 (16-CU groups) or 4 (8-CU groups, 256-register build)");
         g_decode_impl = value;
         return GNNPN_OK;
     }

@@ -97,24 +97,24 @@ __device__ __forceinline__ u64 phase_stamp() {
 // an LDS tile `src` (row c, stride LDH, element 4*kk + kq).  The A-fragments are fetched 16 k-steps
 // ahead of the MFMAs that use them: left to itself hipcc issues each ds_read right before the MFMAs
 // that need it and waits ~70 cycles per 4 MFMAs (measured 6.3k instead of 4.1k cycles per step).
-template <int LDH>
+template <int LDH, int CH = 16>   // CH: prefetch depth in k-steps (8 where registers are short: 2 x CH fragment registers)
 __device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq, const float (&w0)[64],
                                                 const float (&w1)[64], f32x4& acc0, f32x4& acc1) {
     const float* base = src + c * LDH + kq;
-    float a[2][16];
+    float a[2][CH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[0][i] = base[4 * i];
+    for (int i = 0; i < CH; ++i) a[0][i] = base[4 * i];
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        if (ch < 3) {
+    for (int ch = 0; ch < 64 / CH; ++ch) {
+        if (ch < 64 / CH - 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[(ch + 1) & 1][i] = base[4 * (16 * (ch + 1) + i)];
+            for (int i = 0; i < CH; ++i) a[(ch + 1) & 1][i] = base[4 * (CH * (ch + 1) + i)];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w0[16 * ch + i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w1[16 * ch + i], acc1, 0, 0, 0);
+        for (int i = 0; i < CH; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w0[CH * ch + i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w1[CH * ch + i], acc1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

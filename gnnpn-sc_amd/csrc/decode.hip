@@ -198,7 +198,7 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     args.K = n_per;
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int impl = gnnpn_option_decode_impl();   // 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 (16-CU groups)
+    const int impl = gnnpn_option_decode_impl();   // 0 auto, 1 streaming, 2 8-CU groups, 3 16-CU groups, 4 8-CU groups sized for 2 per CU
     if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl >= 2)) {
         // auto / 2: 8-member groups — fastest when the launch has the GPU to itself (0.32 ms at QWS B=256).
         // 3: 16-member groups — 0.52 ms alone, but 256 registers, i.e. it shares every SIMD with a wave of the
@@ -207,9 +207,11 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         int rc;
         if (impl == 3) {
             rc = gnnpn_launch_decode_coop2(args, n_nets, precision, workspace, workspace_bytes, s);
-            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, precision, workspace, workspace_bytes, s);
+            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, precision, false, workspace, workspace_bytes, s);
         } else {
-            rc = gnnpn_launch_decode_coop(args, n_nets, precision, workspace, workspace_bytes, s);
+            rc = gnnpn_launch_decode_coop(args, n_nets, precision, impl == 4, workspace, workspace_bytes, s);
+            if (rc == GNNPN_E_UNSUP && impl == 4)   // K > 8: the 16-member form is the other build that shares a CU
+                rc = gnnpn_launch_decode_coop2(args, n_nets, precision, workspace, workspace_bytes, s);
         }
         if (rc != GNNPN_OK) return rc;
         GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");

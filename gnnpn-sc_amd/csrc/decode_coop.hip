@@ -51,8 +51,10 @@ __device__ __forceinline__ int ror16(int v, int n) {
 
 // DIAG: diagnostic build with phase stamps (tools/stamp_decode.py); production carries none of it.
 // SPLIT: W_hh.h with fp16 hi+lo operands (coop_common.h); everything else as in the fp32 form
-template <bool FOLDX, bool DIAG, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
+// OCC: workgroups per CU the build is sized for — 1 (512 registers: fastest alone) or 2 (256 registers: shares the
+// CU with a workgroup of another launch, pipeline.PipelinedRunner)
+template <bool FOLDX, bool DIAG, bool SPLIT, int OCC>
+__global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, int n_nets,
                                                                      int groups_per_net, int ablate_arg) {
@@ -313,14 +315,17 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
             }
 
             // this step's window rows, own 32-unit slice: thread (row, cand) holds 32 floats
-            float4 ev[8];
-            const int prow = tid / K, pcand = tid - prow * K;
-            const bool pdot = tid < ROWS * K;
+            // (OCC == 2: two threads per (row, cand), 16 floats each — half the registers; K <= 8 there)
+            constexpr int EVH = OCC == 2 ? 2 : 1, EVN = 8 / EVH;
+            float4 ev[EVN];
+            const int ppair = tid / EVH, phalf = tid - ppair * EVH;
+            const int prow = ppair / K, pcand = ppair - prow * K;
+            const bool pdot = ppair < ROWS * K;
             if (pdot) {
                 const int b = b0 + prow;
-                const float* src = net.enc_out + ((int64_t)b * L + (int64_t)k * K + pcand) * H + member * UNITS;
+                const float* src = net.enc_out + ((int64_t)b * L + (int64_t)k * K + pcand) * H + member * UNITS + phalf * (4 * EVN);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < EVN; ++j)
                     ev[j] = b < B ? *reinterpret_cast<const float4*>(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
                 ah0 = acc[0];
                 ah1 = acc[1];
             } else {
-                mfma_chain_pair<LDH>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah0, ah1);
+                mfma_chain_pair<LDH, OCC == 2 ? 8 : 16>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah0, ah1);
             }
             if (stamps) {
                 asm volatile("" ::"v"(ah0[0]), "v"(ah1[0]));
@@ -427,17 +432,22 @@ __global__ __launch_bounds__(256, 1) void pointer_decode_coop_kernel(DecodeArgs 
             }
             __syncthreads();
             // ---- partial attention dots of the step-k window against the own h_k slice
-            if (pdot) {
+            {
                 float p = 0.0f;
+                if (pdot) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 hv = *reinterpret_cast<const float4*>(&hsl[prow][4 * j]);
-                    p = fmaf(ev[j].x, hv.x, p);
-                    p = fmaf(ev[j].y, hv.y, p);
-                    p = fmaf(ev[j].z, hv.z, p);
-                    p = fmaf(ev[j].w, hv.w, p);
+                    for (int j = 0; j < EVN; ++j) {
+                        const float4 hv = *reinterpret_cast<const float4*>(&hsl[prow][phalf * (4 * EVN) + 4 * j]);
+                        p = fmaf(ev[j].x, hv.x, p);
+                        p = fmaf(ev[j].y, hv.y, p);
+                        p = fmaf(ev[j].z, hv.z, p);
+                        p = fmaf(ev[j].w, hv.w, p);
+                    }
                 }
-                granule_publish(xp_g + (step & 1) * (G * ROWS * K) + ((size_t)prow * K + pcand) * G + member, step + 1, p, same_xcd);
+                if constexpr (EVH == 2)   // lanes 2p, 2p+1 hold the two halves of the slice: low half + high half
+                    p = __fadd_rn(p, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false)));
+                if (pdot && phalf == 0)
+                    granule_publish(xp_g + (step & 1) * (G * ROWS * K) + ((size_t)prow * K + pcand) * G + member, step + 1, p, same_xcd);
             }
             if (stamps) {
                 st[7] = phase_stamp();
@@ -470,7 +480,8 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
 
 bool gnnpn_decode_coop_supported(int32_t H_, int32_t n_per) { return H_ == H && n_per <= KMAX; }
 
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, void* workspace,
+                             int64_t workspace_bytes,
                              hipStream_t s) {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -505,17 +516,20 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
-    if (split)
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, true>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
-                           p_l, p_err, n_nets, groups_per_net, abl);
-    else if (fold && (abl & 32))
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, true, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
-                           p_l, p_err, n_nets, groups_per_net, abl);
-    else if (fold)
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
-                           p_l, p_err, n_nets, groups_per_net, abl);
-    else
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<false, false, false>), dim3(groups * G), dim3(256), 0, s, args, p_h, p_p,
-                           p_l, p_err, n_nets, groups_per_net, abl);
+    const int lds_kb = gnnpn_option_coop_lds_kb();
+#define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_)                                                                          \
+    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_>), dim3(groups * G), dim3(256),           \
+                       coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_>, lds_kb), s, \
+                       args, p_h, p_p, p_l, p_err, n_nets, groups_per_net, abl)
+    if (shared_cu && (!fold || (abl & 32)))
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side only");
+    if (shared_cu && args.K > 8) return GNNPN_E_UNSUP;   // two threads per (row, candidate): 2*16*K <= 256
+    if (split && shared_cu) GNNPN_DEC8(true, false, true, 2);
+    else if (split) GNNPN_DEC8(true, false, true, 1);
+    else if (shared_cu) GNNPN_DEC8(true, false, false, 2);
+    else if (fold && (abl & 32)) GNNPN_DEC8(true, true, false, 1);
+    else if (fold) GNNPN_DEC8(true, false, false, 1);
+    else GNNPN_DEC8(false, false, false, 1);
+#undef GNNPN_DEC8
     return GNNPN_OK;
 }

@@ -40,7 +40,8 @@ struct DecodeArgs {
 };
 
 bool gnnpn_decode_coop_supported(int32_t H, int32_t n_per);
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, void* workspace,
+                             int64_t workspace_bytes,
                              hipStream_t s);
 int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
                               hipStream_t s);

@@ -170,7 +170,8 @@ int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
 /* Run-time switches (process-wide; they select among implementations of the SAME entry points):
  *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups)
- *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups)
+ *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups),
+ *                    4 cooperative (8-CU groups, 256-register build that shares a CU with another launch)
  *   "coop_lds_kb"    LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernels
  *                    launched from now on, 0 = none: placement control for two launches sharing the CUs
  *                    (100 on one stream + 56 on the other: a CU takes one workgroup of each, never two of one)

@@ -226,7 +226,7 @@ def test_pipelined_runner_matches_single_stream(dev):
             got.append((out["idx_high"].clone(), out["R"].clone(), out["candidate_ids"].clone()))
     runner.synchronize()
     ops.check_status(dev)
-    ops.set_option("decode_impl", 3)                           # the decoder form the 2-slot runner uses
+    ops.set_option("decode_impl", runner.decode_impl)                           # the decoder form the 2-slot runner uses
     try:
         for b, (idx, R, ids) in zip(batches, got):
             ref = pipe.run(svc, b)

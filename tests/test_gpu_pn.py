@@ -141,6 +141,8 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
         ref = two_level_greedy(low, high, x)
         ops.set_option("decode_impl", 2)          # 8-CU groups
         out8 = two_level_greedy(low, high, x)
+        ops.set_option("decode_impl", 4)          # 8-CU groups, 256-register build (K > 8: falls back to the 16-CU form)
+        out4 = two_level_greedy(low, high, x)
         ops.set_option("decode_impl", 3)          # 16-CU groups (256 registers: co-resident with an encoder wave)
         out = two_level_greedy(low, high, x)
         out2 = two_level_greedy(low, high, x)
@@ -168,6 +170,11 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
           assert_index_parity(out8["idx_high"], ref["idx_high"], robust, "coop8/high", 0.8, x.cpu())).to(dev)
     assert float((out8["win_low"][s8] - ref["win_low"][s8]).abs().max()) < 1e-4
     assert float((out8["R"][s8] - ref["R"][s8]).abs().max()) <= R_ATOL
+    s4 = (assert_index_parity(out4["idx_low"], ref["idx_low"], robust, "coop8x2/low", 0.8, x.cpu()) &
+          assert_index_parity(out4["idx_high"], ref["idx_high"], robust, "coop8x2/high", 0.8, x.cpu())).to(dev)
+    assert float((out4["win_low"][s4] - ref["win_low"][s4]).abs().max()) < 1e-4
+    assert float((out4["win_high_raw"][s4] - ref["win_high_raw"][s4]).abs().max()) < 1e-4
+    assert float((out4["R"][s4] - ref["R"][s4]).abs().max()) <= R_ATOL
 
 
 @pytest.mark.parametrize("name", ["qws", "normal"])
@@ -323,7 +330,7 @@ def test_split_precision_ragged_shapes(dev, B, T, K):
     ref = two_level_greedy(low, high, x)
     outs = []
     try:
-        for impl in (2, 3, 3):
+        for impl in (2, 3, 3, 4):
             ops.set_option("decode_impl", impl)
             outs.append(two_level_greedy(low, high, x, precision="split"))
     finally:
@@ -334,7 +341,7 @@ def test_split_precision_ragged_shapes(dev, B, T, K):
     win_ref = torch.stack([ref["win_low"], ref["win_high_raw"] + ref["win_low"]]).cpu()
     m = opn.decision_margin(win_ref[0], x.cpu()), opn.decision_margin(win_ref[1], x.cpu())
     robust = (m[0] > 1e-4).all(1) & (m[1] > 1e-4).all(1)
-    for tag, out in (("split8", outs[0]), ("split16", outs[1])):
+    for tag, out in (("split8", outs[0]), ("split16", outs[1]), ("split8x2", outs[3])):
         same = assert_index_parity(out["idx_low"], ref["idx_low"], robust, tag + "/low", 0.8, x.cpu()) & \
             assert_index_parity(out["idx_high"], ref["idx_high"], robust, tag + "/high", 0.8, x.cpu())
         s = same.to(dev)

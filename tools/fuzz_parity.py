@@ -31,7 +31,7 @@ for c in range(n_cfg):
     ref = opn.two_level_greedy(opn.make_state_dict(256, sl), opn.make_state_dict(256, sh), x, T, K)
     robust = robust_problems(ref["margin_low"], ref["margin_high"])
     for prec in ("f32", "split"):
-        for impl in (2, 3):
+        for impl in (2, 3, 4):
             ops.set_option("decode_impl", impl)
             try:
                 out = two_level_greedy(low, high, x.to(dev), precision=prec)
@@ -48,5 +48,5 @@ for c in range(n_cfg):
             finally:
                 ops.set_option("decode_impl", 0)
     print(f"cfg {c}: B={B} T={T} K={K} robust {int(robust.sum())}/{B} ok", flush=True)
-print(f"{n_cfg} configs x 4 variants, {fails} failures, {time.time() - t0:.0f} s")
+print(f"{n_cfg} configs x 6 variants, {fails} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)

@@ -11,7 +11,7 @@ g = torch.Generator().manual_seed(0)
 x = torch.rand(B, T * K, 8, generator=g).to(dev)
 import gnnpn_sc_amd.ops as O
 orig = O.pointer_decode
-for impl in (0, 3, 2, 3):
+for impl in (0, 3, 2, 4, 3, 4):
     ops.set_option("decode_impl", impl)
     for _ in range(3): two_level_greedy(low, high, x)
     torch.cuda.synchronize()
