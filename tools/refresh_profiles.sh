@@ -11,8 +11,8 @@ timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --precision f16 --no-cpu-baseline > $O/bench_f16.json 2> /dev/null
 timeout 300 python bench.py --precision split --no-cpu-baseline > $O/bench_split.json 2> /dev/null
 timeout 200 python tools/split_encode.py > $O/split_accuracy.txt 2> /dev/null
-timeout 300 python bench.py --workload normal --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_normal.json 2> /dev/null
-timeout 300 python bench.py --workload synth4 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_synth4.json 2> /dev/null
+timeout 300 python bench.py --workload normal --steps 20 --warmup 4 --no-cpu-baseline > $O/bench_normal.json 2> /dev/null
+timeout 300 python bench.py --workload synth4 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_synth4.json 2> /dev/null
 timeout 200 python tools/bench_aggregate.py > $O/aggregate_roofline.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-split-line > $O/prof_default.log 2>&1
