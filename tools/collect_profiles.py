@@ -8,7 +8,6 @@ def cp(src, dst):
 cp(f"{O}/bench_default.json", "r01_final_qws_b256_bench.json")
 cp(f"{O}/bench_f16.json", "r01_optin_fp16_encoder_qws_b256_bench.json")
 cp(f"{O}/bench_split.json", "r01_optin_split_operands_qws_b256_bench.json")
-cp(f"{O}/split_accuracy.txt", "r01_split_operands_accuracy.txt")
 cp(f"{O}/bench_normal.json", "r01_normal_b1024_bench.json")
 cp(f"{O}/bench_synth4.json", "r01_synth4_b512_bench.json")
 cp(f"{O}/aggregate_roofline.json", "r01_csr_aggregate_replicated_roofline.json")

@@ -8,6 +8,13 @@ from bench import build_models
 dev = torch.device("cuda:0")
 T, K, B = 47, 5, 256
 net, low, high = build_models(T, 2507, K, dev)
+scale = float(os.environ.get("WHH_SCALE", "1"))          # stress: larger recurrent weights (saturating gates)
+if scale != 1:
+    with torch.no_grad():
+        for m in (low, high):
+            m.actor.encoder.weight_hh_l0.mul_(scale); m.actor.decoder.weight_hh_l0.mul_(scale)
+            m.actor.encoder.weight_ih_l0.mul_(scale)
+    print("W_hh, W_ih scaled by", scale)
 g = torch.Generator().manual_seed(0)
 x = torch.rand(B, T * K, 8, generator=g)
 x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
