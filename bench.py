@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ML+2PN inference throughput on MI355X (BASELINE.json metric: service-composition problems/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload qws|normal|synth4] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload qws|normal|synth4|synth5] [--batch B] [--precision f32|split|f16]
 
 A "step" = one pass of the whole hot path over one batch of B synthetic problems that is already
 resident in HBM: GNN scores -> per-category top-K feasible candidates -> Low/High pointer-network
@@ -14,6 +14,10 @@ Extra objects on the line:
   kernels      : every timed kernel of the step (avg ms, algorithmic bytes/flops, fraction of peak)
   cpu_baseline : the CPU oracle (oracle/, a torch-CPU port of the reference algorithm) timed on this
                  box's host cores over a bounded sample of the same workload (rank 0, N=1 only)
+  split_operands : a second measurement of the same workload with precision="split" (the recurrent W_hh.h
+                 products from fp16 hi+lo operand pairs, fp32 accumulate) and its agreement with the f32 results;
+                 reported beside `value`, never as `value`
+Defaults: --gpus 1 --steps 100 --warmup 10 --workload qws (a few seconds of GPU time + ~10 s of CPU baseline).
 """
 import argparse
 import gc
