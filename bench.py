@@ -154,7 +154,16 @@ def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or passes >= 16:
             break
-    return {"value": round(n * passes / el, 2), "unit": "problems/s", "cores": cores, "kind": "port",
+    # the same chain on ONE thread (SURVEY.md section 8d asks for both), over a smaller sample
+    single = None
+    if cores > 1:
+        torch.set_num_threads(1)
+        n1 = min(B, 32)
+        t1 = time.perf_counter()
+        one_pass(n1)
+        single = {"value": round(n1 / (time.perf_counter() - t1), 2), "cores": 1, "sample": f"one pass over the first {n1} problems"}
+        torch.set_num_threads(cores)
+    return {"value": round(n * passes / el, 2), "unit": "problems/s", "cores": cores, "kind": "port", "single_thread": single,
             "sample": f"{passes} pass(es) over the first {n} problems of the same batch through oracle/ (torch-CPU "
                       f"fp32 port of the reference algorithm: GNN forward, stable ranking, candidate reduction, "
                       f"Low+High greedy decode with full-L attention, reward); torch {torch.__version__}, "
