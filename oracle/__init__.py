@@ -21,4 +21,8 @@ the *reference itself* imported in the build container:
   are third-party, un-vendored and not installed in the image, so the conv
   arithmetic follows their published algorithm as restated in
   ``tests/golden/pyg_standin.py``.            : glue PINNED, conv "parity unpinned"
+* ``woa.py``   <- ``/root/reference/src/baselines/WOA.py`` ``ESWOA`` (the
+  step after the path; groundwork for a later round — no product code uses it yet): real class run
+  with numpy's global generator routed to an explicit draw stream
+  (``tests/golden/make_golden_woa.py``)                      : PINNED
 """

@@ -119,3 +119,36 @@ def test_hand_graph():
 def test_rank_is_stable_lowest_index_first():
     s = torch.tensor([[0.5, 0.9, 0.5, 0.9, 0.1]])
     assert oml.rank_services(s).tolist() == [[1, 3, 0, 2, 4]]
+
+
+def test_woa_oracle_reproduces_reference():
+    """oracle/woa.py against the reference's own ESWOA runs (tests/golden/make_golden_woa.py): same draw count,
+    same best-fitness history, same final selection — including the runs in which the reference's list aliasing
+    and negative list positions change the outcome."""
+    import copy
+    from oracle import woa as owoa
+    with open(os.path.join(GOLDEN, "woa_cases.json")) as f:
+        cases = json.load(f)
+    assert {c["name"] for c in cases} >= {"tiny", "no_solution", "foreign_pick", "violated", "qws_like", "normal_like"}
+    for c in cases:
+        got = owoa.eswoa([[tuple(s) for s in cat] for cat in c["services"]], c["constraints"], copy.deepcopy(c["solution"]),
+                         c["pop_size"], c["max_iter"], owoa.DrawStream(c["seed"]))
+        want = c["expected"]
+        assert got["draws"] == want["draws"], c["name"]
+        assert got["history"] == want["history"], c["name"]
+        assert got["best_fitness"] == want["best_fitness"], c["name"]
+        assert [list(r[:4]) for r in got["best_rows"]] == want["best_rows"], c["name"]
+        assert [int(v) for v in got["best_pos"]] == want["best_pos"], c["name"]
+        assert all(b <= a for a, b in zip(got["history"], got["history"][1:])), "best fitness never gets worse"
+
+
+def test_woa_objective_known_answers():
+    from oracle import woa as owoa
+    rows = [(0.2, 0.9, 0.95, 0.98), (0.4, 0.5, 0.97, 0.99), (0.0, 1.0, 1.0, 1.0)]       # last: dummy row
+    v, o = owoa.objective(rows, [[[0.9, 1.0]], [[0.99, 1.0]]])
+    assert v == 1                                       # 0.95*0.97 = 0.9215 inside, 0.98*0.99 = 0.9702 below 0.99
+    assert o == pytest.approx((0.6 / 2 + 1 - 0.5) / 2, abs=1e-15)
+    s = owoa.DrawStream(7)
+    u = [s.uniform() for _ in range(1000)]
+    assert 0.0 <= min(u) and max(u) < 1.0 and abs(sum(u) / 1000 - 0.5) < 0.05 and s.count == 1000
+    assert [owoa.DrawStream(7).below(10) for _ in range(3)] == [int(u[0] * 10)] * 3     # pure function of (seed, k)
