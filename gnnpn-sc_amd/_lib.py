@@ -38,6 +38,7 @@ _SIGNATURES = {
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
+    "gnnpn_eswoa_f64": (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, _P, _P, _P]),
     "gnnpn_debug_cell_activations": (c_int, [_P, _P, _P, c_int64, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -327,3 +327,27 @@ def debug_cell_activations(x):
                                                    dev_ptr(th, F32, "th"), x.numel(), stream_ptr()),
           "gnnpn_debug_cell_activations")
     return sig, th
+
+
+def eswoa(cand_ptr, len_init, cand, bounds, start_pos, pop, max_iter, seeds, n_cat):
+    """ES-WOA fine-tuning of P problems in one launch (gnnpn_eswoa_f64; reference src/baselines/WOA.py:8-162).
+    cand_ptr [P*T+1] i32, len_init [P*T] i32, cand [n,4] f64, bounds [P,4] f64, start_pos [P*T] i32 (first entry of a
+    problem < 0: no seed solution), seeds [P] int64 (bit pattern of the uint64 seed).  Returns (best_fitness [P] f64,
+    best_pos [P,T] i32, history [P,max_iter] f64, draws [P] i64)."""
+    dev = cand.device
+    T = int(n_cat)
+    P = (cand_ptr.numel() - 1) // T
+    I64 = torch.int64
+    best_fit = torch.empty(P, dtype=torch.float64, device=dev)
+    best_pos = torch.empty(P, T, dtype=I32, device=dev)
+    history = torch.empty(P, max(int(max_iter), 1), dtype=torch.float64, device=dev)
+    draws = torch.empty(P, dtype=I64, device=dev)
+    per_problem = cand_ptr[T::T] - cand_ptr[:-1:T] if P else cand_ptr[:0]
+    max_cand = int(per_problem.max().item()) if P else 1
+    check(_lib.load().gnnpn_eswoa_f64(P, T, dev_ptr(cand_ptr, I32, "cand_ptr"), dev_ptr(len_init, I32, "len_init"),
+                                      dev_ptr(cand, torch.float64, "cand"), dev_ptr(bounds, torch.float64, "bounds"),
+                                      dev_ptr(start_pos, I32, "start_pos"), int(pop), int(max_iter),
+                                      dev_ptr(seeds, I64, "seeds"), max_cand, dev_ptr(best_fit, torch.float64, "best_fitness"),
+                                      dev_ptr(best_pos, I32, "best_pos"), dev_ptr(history, torch.float64, "history"),
+                                      dev_ptr(draws, I64, "draws"), stream_ptr()), "gnnpn_eswoa_f64")
+    return best_fit, best_pos, history[:, :int(max_iter)], draws

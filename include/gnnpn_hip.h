@@ -263,6 +263,26 @@ int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, i
  * evaluated on an array so that tests can measure them against the CPU's libm-grade functions. */
 int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t n, void* stream);
 
+/* ES-WOA fine-tuning of P compositions in one launch (one wavefront per problem).  Replaces `ESWOA.__init__` +
+ * `ESWOA.start` of src/baselines/WOA.py:8-162 (the step after the ML+2PN path); the caller
+ * (gnnpn-sc_amd/WOA.py) does the reference's host-side preparation: 5-decimal rounding of the QoS tuples (:13-26) and
+ * appending a pick that is not among its category's candidates (:62-69).
+ *   cand_ptr [P*T+1] : candidate rows of (problem p, category j) are cand[cand_ptr[p*T+j] .. cand_ptr[p*T+j+1])
+ *   len_init [P*T]   : candidate counts BEFORE the append (the initial population is drawn from those, :51-52)
+ *   cand     [n,4]   : q0..q3 (float64, as the reference computes)
+ *   bounds   [P,4]   : lo/hi of the two product constraints
+ *   start_pos [P*T]  : position of the seed solution's pick in each category, or start_pos[p*T] < 0: no seed (:70-74)
+ *   seeds    [P]     : draw k of a problem is splitmix64(seed + k * 0x9E3779B97F4A7C15) >> 11, scaled to [0,1)
+ *                      (the reference uses numpy's global generator; see oracle/woa.py)
+ *   max_cand         : the largest cand_ptr[(p+1)*T] - cand_ptr[p*T] (sizes the LDS)
+ * Outputs: best_fitness [P], best_pos [P*T] (may be negative: Python list positions), history [P*max_iter] (best
+ * fitness after every iteration, WOA.py:128,161), draws [P] (stream positions consumed).
+ * GNNPN_E_UNSUP: T outside 1..64, or a problem that does not fit a CU's LDS. */
+int gnnpn_eswoa_f64(int32_t P, int32_t T, const int32_t* cand_ptr, const int32_t* len_init, const double* cand,
+                    const double* bounds, const int32_t* start_pos, int32_t pop, int32_t max_iter, const uint64_t* seeds,
+                    int32_t max_cand, double* best_fitness, int32_t* best_pos, double* history, int64_t* draws,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

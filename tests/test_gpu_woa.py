@@ -1,0 +1,71 @@
+"""-m gpu: the ES-WOA fine-tuner (gnnpn_eswoa_f64 through gnnpn_sc_amd.WOA) against the golden runs of the reference's
+own ``ESWOA`` class (tests/golden/woa_cases.json, tests/golden/make_golden_woa.py) and against the oracle run live."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import woa as owoa
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    with open(os.path.join(GOLDEN, "woa_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["tiny", "no_solution", "foreign_pick", "violated", "qws_like", "normal_like"])
+def test_eswoa_golden(dev, name):
+    """Bit-exact: same draw count, same best-fitness history (float64), same final positions and rows as the reference."""
+    from gnnpn_sc_amd import WOA
+    c = next(x for x in _cases() if x["name"] == name)
+    m = WOA.ESWOA([[tuple(s) for s in cat] for cat in c["services"]], c["constraints"], copy.deepcopy(c["solution"]),
+                  popSize=c["pop_size"], MAX_Iter=c["max_iter"], seed=c["seed"], device=dev)
+    q, rows = m.start()
+    want = c["expected"]
+    assert q == want["best_fitness"]
+    assert m.bestFitnesses == want["history"]
+    assert [int(v) for v in m.bestPops] == want["best_pos"]
+    assert [list(r) for r in rows] == want["best_rows"]
+
+
+def test_eswoa_batch_vs_live_oracle(dev):
+    """Many problems in one launch (different seeds, seeded and unseeded starts) against oracle/woa.py run live."""
+    from gnnpn_sc_amd import WOA
+    g = np.random.default_rng(3)
+    T, problems, seeds = 13, [], []
+    for p in range(24):
+        services = [[tuple(float(v) for v in np.r_[g.random(2), 0.9 + 0.1 * g.random(2)]) for _ in range(int(g.integers(1, 8)))]
+                    for _ in range(T)]
+        lo = 0.9 ** T * float(g.choice([0.6, 1.2]))
+        cons = [[[lo, 1.0]], [[lo, 1.0]]]
+        sol = None if p % 5 == 4 else [list(cat[int(g.integers(0, len(cat)))]) for cat in services]
+        if sol is not None and p % 3 == 0:
+            sol[p % T] = [float(v) for v in np.r_[g.random(2), 0.9 + 0.1 * g.random(2)]]     # foreign pick
+        problems.append((services, cons, sol))
+        seeds.append(1000 + p)
+    got = WOA.fine_tune(problems, popSize=30, MAX_Iter=40, seeds=seeds, device=dev)
+    for p, (services, cons, sol) in enumerate(problems):
+        want = owoa.eswoa(services, cons, copy.deepcopy(sol), 30, 40, owoa.DrawStream(seeds[p]))
+        assert got[p]["draws"] == want["draws"], p
+        assert got[p]["bestFitnesses"] == want["history"], p
+        assert got[p]["bestFitness"] == want["best_fitness"], p
+        assert [int(v) for v in got[p]["bestPops"]] == [int(v) for v in want["best_pos"]], p
+        assert [tuple(r) for r in got[p]["bestSolutions"]] == [tuple(r[:4]) for r in want["best_rows"]], p
+
+
+def test_eswoa_rejects_what_it_does_not_implement(dev):
+    from gnnpn_sc_amd import WOA, ops
+    services = [[(0.5, 0.5, 0.95, 0.95)] for _ in range(65)]
+    with pytest.raises(ops.GnnpnError):                       # more categories than lanes
+        WOA.fine_tune([(services, [[[0.0, 1.0]], [[0.0, 1.0]]], None)], popSize=4, MAX_Iter=2, seeds=[1], device=dev)
+    with pytest.raises(ops.GnnpnError):                       # two pairs for one product constraint
+        WOA.fine_tune([(services[:3], [[[0.0, 1.0], [0.1, 1.0]], [[0.0, 1.0]]], None)], popSize=4, MAX_Iter=2, seeds=[1], device=dev)
+    with pytest.raises(ops.GnnpnError):                       # host tensors: no CPU path
+        ops.eswoa(torch.zeros(4, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), torch.zeros(3, 4, dtype=torch.float64),
+                  torch.zeros(1, 4, dtype=torch.float64), torch.zeros(3, dtype=torch.int32), 4, 2, torch.zeros(1, dtype=torch.int64), 3)
