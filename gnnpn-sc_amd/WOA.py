@@ -59,15 +59,21 @@ def fine_tune(problems, popSize=100, MAX_Iter=500, seeds=None, device=None, patc
     problems = list(problems)
     if not problems:
         return []
+    if seeds is None:
+        seeds = np.frombuffer(os.urandom(8 * len(problems)), dtype=np.uint64)
+    seeds = np.asarray(seeds, dtype=np.uint64).reshape(len(problems))
+    sizes = [len(s) for s, _c, _sol in problems]
+    if len(set(sizes)) > 1:                                  # one launch per distinct number of categories
+        out = [None] * len(problems)
+        for T in sorted(set(sizes)):
+            idx = [i for i, n in enumerate(sizes) if n == T]
+            for i, r in zip(idx, fine_tune([problems[i] for i in idx], popSize, MAX_Iter, seeds[idx], device, patches)):
+                out[i] = r
+        return out
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     prep = [_prepare(s, c, sol, patches) for s, c, sol in problems]
     T = len(prep[0][0])
-    if any(len(p[0]) != T for p in prep):
-        raise GnnpnError("fine_tune: all problems must have the same number of categories")
     P = len(prep)
-    if seeds is None:
-        seeds = np.frombuffer(os.urandom(8 * P), dtype=np.uint64)
-    seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
     ptr, flat, len0, start, bounds = [0], [], [], [], []
     for cats, l0, st, _rows, b in prep:
         for j, cat in enumerate(cats):
@@ -106,3 +112,62 @@ class ESWOA:
         self.bestFitness, self.bestSolutions, self.bestPops = r["bestFitness"], r["bestSolutions"], r["bestPops"]
         self.bestFitnesses = r["bestFitnesses"]
         return self.bestFitness, self.bestSolutions
+
+
+class WOA:
+    """The driver of WOA.py:165-310 for the mode the ML+2PN pipeline feeds (``ML2PNWOATest``, environment.ini
+    ``[<ds>-WOA]``): pointer-network actions -> per-problem seed solutions -> ``loadDataOther`` candidate lists -> ES-WOA
+    on every test problem (here: all of them in one launch per workflow size) -> ``./solutions/WOA/<ds>/ML+2PN+WOA.txt``.
+    The other three modes (ES-WOA from scratch, ML+ES-WOA, ML+WOA) are baselines outside the path: NotImplementedError.
+    ``seed``: problem number ``idx`` runs on stream ``seed + idx`` (None: fresh seeds, the reference's behaviour).
+    The reference sizes its solution table for exactly 1000 test problems (:194); any number works here."""
+
+    def __init__(self, dataset, serCategory, MLESWOAtest, ML2PNWOATest, MLWOATest, ESWOAtest, serviceNumber, reduct, epoch,
+                 MAX_Iter, popSize, seed=None, device=None):
+        self.dataset, self.serCategory = dataset + "/", serCategory
+        self.MLESWOAtest, self.ML2PNWOATest, self.MLWOATest, self.ESWOAtest = MLESWOAtest, ML2PNWOATest, MLWOATest, ESWOAtest
+        self.serviceNumber, self.reduct, self.epoch, self.MAX_Iter, self.popSize = serviceNumber, reduct, epoch, MAX_Iter, popSize
+        self.seed, self.device = seed, device
+        self.times, self.qosNum, self.train, self.sSetList = 0, 4, False, None
+
+    def start(self):
+        import json
+        import time
+
+        from .loadData import loadDataOther
+        if not self.ML2PNWOATest or self.MLESWOAtest or self.MLWOATest or self.ESWOAtest:
+            raise NotImplementedError("WOA: only the ML2PNWOATest mode (fine-tuning the ML+2PN solution) is on the path")
+        ds = self.dataset[:-1]
+        src = (f"./solutions/PNHigh/{self.dataset}/allActions{self.epoch}.txt" if self.epoch >= 0
+               else f"./solutions/pretrained/{ds}-PNHigh.txt")                                   # :187-192
+        with open(src) as f:
+            allActions = json.load(f)
+        n_test = len(allActions[0]) if allActions else 0
+        solutions, self.sSetList = [], []
+        for b in range(n_test):                                                                # :194-208
+            rows = [allActions[c][b][: self.qosNum] for c in range(len(allActions))]
+            rows = [r for r in rows if sum(r) != 3]                                            # dummy action of an absent category
+            solutions.append(rows)
+            self.sSetList.append({tuple(round(v, 5) for v in r) for r in rows})
+        features, constraintsList, minCostList = loadDataOther(ds, self.reduct, sSetList=self.sSetList, train=self.train)
+        first = len(minCostList) // 4 * 3
+        n = min(len(features), len(solutions))
+        problems = [(features[i], constraintsList[i], solutions[i] if solutions[i] else None) for i in range(n)]
+        seeds = None if self.seed is None else [(self.seed + first + i) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+        t0 = time.time()
+        results = fine_tune(problems, self.popSize, self.MAX_Iter, seeds, self.device)
+        per_problem = (time.time() - t0) / max(n, 1)
+        out = {"quality": [], "time": [], "averageQ": 0, "averageT": 0}
+        self.bestFitnesses = [[r["bestFitnesses"][i] for r in results] for i in range(self.MAX_Iter)]   # :264, 283-284
+        for i, r in enumerate(results):                                                        # :286-292
+            out["quality"].append(minCostList[first + i] / r["bestFitness"])
+            out["time"].append(per_problem)
+            out["averageQ"] = sum(out["quality"]) / (self.times + 1)
+            out["averageT"] = sum(out["time"]) / (self.times + 1)
+            print(first + i, out["averageQ"], out["averageT"])
+            self.times += 1
+        os.makedirs(f"./solutions/WOA/{self.dataset}", exist_ok=True)
+        with open(f"./solutions/WOA/{self.dataset}/ML+2PN+WOA.txt", "w") as f:                 # :294-296
+            json.dump(out, f)
+        self.results = results
+        return out

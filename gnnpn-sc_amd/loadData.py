@@ -145,3 +145,85 @@ def tables_from_dataset(ds, first=0, last=None):
     pb = ProblemBatch(np.asarray(xs, dtype=np.float32), np.concatenate(eis_w, 1) if eis_w else np.zeros((2, 0), np.int64),
                       np.asarray(batch, dtype=np.int64), np.stack(local), np.stack(present), np.stack(glob))
     return table, pb
+
+
+def addS(PriS, serviceFeatures, constraints, serviceIndex, ser2idxdiv, ser2idxmod, reduct=False, sSet=None):
+    """Candidate lists of one problem for the WOA fine-tuner — loadData.py:155-202, same arguments and result.
+
+    Walks the services in ``PriS`` order and keeps, per category, those inside the problem's local bounds.  With a
+    truthy ``reduct`` (a response-time threshold) each category keeps a small front instead: a newcomer replaces the
+    first front member it beats on both q0 (lower) and q1 (higher) while that member's q1 is below the threshold, unless
+    that member is one of the pointer network's picks (``sSet``, 5-decimal tuples), and is appended when it replaced
+    nothing and either is such a pick itself or straddles the threshold (q1 > reduct > q0).  The front starts from the
+    sentinel (1, 0, 1, 1), which occupies slot 0 until something replaces it — the kept list is empty until then
+    (:183-186).  Returns the kept lists of the categories in ``serviceIndex`` (the problem's task nodes, in node order)."""
+    n_slots = 50                                                       # :156: capacity is hard-coded in the reference
+    kept = [[] for _ in range(n_slots)]
+    front = [[[1], [0], [1], [1]] for _ in range(n_slots)]             # per category: columns q0, q1, cost, quality
+    for s in PriS:
+        cat = ser2idxdiv[s]
+        row = serviceFeatures[str(cat + 1)][ser2idxmod[s]]
+        entry = (row[-4], row[-3], row[-2], row[-1])
+        q0, q1, cost, quality = entry
+        bounds = constraints[cat + 1]
+        if not (bounds[0] <= cost <= bounds[1] and bounds[2] <= quality <= bounds[3]):
+            continue
+        if not reduct:
+            kept[cat].append(entry)
+            continue
+        cols, replaced = front[cat], False
+        for x in range(len(cols[0])):
+            member = tuple(round(cols[c][x], 5) for c in range(4))
+            if sSet and member in sSet:
+                continue
+            if q0 < cols[0][x] and q1 > cols[1][x] and cols[1][x] < reduct:
+                for c in range(4):
+                    cols[c][x] = entry[c]
+                if not kept[cat]:
+                    kept[cat].append(entry)
+                else:
+                    kept[cat][x] = entry
+                replaced = True
+                break
+            if (q0 > cols[0][x] and q1 < cols[1][x]) or q1 > reduct > q0:
+                break
+        if not replaced and ((sSet and tuple(round(v, 5) for v in entry) in sSet) or q1 > reduct > q0):
+            for c in range(4):
+                cols[c].append(entry[c])
+            kept[cat].append(entry)
+    return [kept[c] for c in serviceIndex]
+
+
+def loadDataOther(dataset="", reduct=False, sSetList=None, train=False):
+    """-> (newServiceFeatures, constraintsList, minCostList) — loadData.py:205-276: per problem of the test quarter (or of
+    the whole set with ``train``) the candidate lists of ``addS`` with empty categories dropped, and the two global
+    product constraints as ``[[[lo0, hi0]], [[lo1, hi1]]]``."""
+    d = f"./data/{dataset}/" if dataset != "" else "./data/"
+    nodefeatures = _read(d + "nodefeatures.data")
+    serviceFeature = _read(d + "serviceFeature.data")
+    minCostList = _read(d + "minCostList.data")
+    n_cat = len(serviceFeature)
+    ser2idxdiv, ser2idxmod = [], []
+    for key in serviceFeature:                                         # file order, :221-224
+        ser2idxdiv += [int(key) - 1] * len(serviceFeature[key])
+        ser2idxmod += list(range(len(serviceFeature[key])))
+    n_train = len(nodefeatures) // 4 * 3
+    first = 0 if train else n_train
+    every_service = list(range(len(ser2idxdiv)))
+    features, constraintsList = [], []
+    for number, nodes in enumerate(nodefeatures[first:], start=first):
+        constraints = {c: [0] * 8 for c in range(1, n_cat + 1)}        # [local lo/hi x2 | global lo/hi x2]
+        for node in nodes:
+            pair = node[-5:-3] + node[-2:]
+            if node[0] == 1:                                           # the request node: global constraints
+                for c in constraints:
+                    constraints[c][-4:] = pair
+            else:
+                constraints[node[:-6].index(1)][-8:-4] = pair
+        serviceIndex = [node[:-6].index(1) - 1 for node in nodes][1:]  # :251-257
+        sSet = sSetList[number - n_train] if sSetList and number >= n_train else None
+        lists = addS(every_service, serviceFeature, constraints, serviceIndex, ser2idxdiv, ser2idxmod, reduct, sSet)
+        features.append([lst for lst in lists if len(lst) > 0])
+        any_cat = constraints[next(iter(constraints))]                 # :268-272: the first key's global pair
+        constraintsList.append([[any_cat[-4:-2]], [any_cat[-2:]]])
+    return features, constraintsList, minCostList

@@ -8,7 +8,10 @@
                                          # ./solutions/pretrained/<ds>-{ML.pt,PNLow.model,PNHigh.model}
                                          # weights), then score them
 
-Every other approach of the reference (training, WOA, GA/DQN baselines) is out of scope and
+    python main.py QWS WOA [epoch]       # ES-WOA fine-tuning of the ML+2PN solution on the GPU (reference main.py:86-104,
+                                         # mode ML2PNWOATest of [<ds>-WOA]); --seed N makes the run reproducible
+
+Every other approach of the reference (training, the other WOA modes, GA/DQN baselines) is out of scope and
 answers with the reference's own message.
 """
 import configparser
@@ -43,13 +46,27 @@ def main(argv):
         return 1
     dataset, approach = argv[1], argv[2]
     ds = {"QWS": "QWS", "qws": "QWS", "Normal": "Normal"}.get(dataset)
-    if ds is None or approach != "ML+2PN":
+    if ds is None or approach not in ("ML+2PN", "WOA"):
         print("Please check the parameters!")                       # reference main.py:231
         return 1
     here = os.path.dirname(os.path.abspath(__file__))
     cfg = configparser.RawConfigParser()
     cfg.optionxform = str
     cfg.read([os.path.join(here, "environment.ini"), "environment.ini"])
+    if approach == "WOA":                                           # reference main.py:86-104
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from gnnpn_sc_amd import WOA
+        sec = cfg[f"{ds}-WOA"]
+        args = argv[3:]
+        seed = int(args[args.index("--seed") + 1]) if "--seed" in args else None
+        pos = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] != "--seed")]
+        epoch = int(pos[0]) if pos else int(sec["epoch"])
+        reduct = float(sec["reduct"]) if ds == "Normal" else int(sec["reduct"])
+        WOA.WOA(ds, int(sec["serCategory"]), int(sec["MLESWOAtest"]), int(sec["ML2PNWOATest"]), int(sec["MLWOATest"]),
+                int(sec["ESWOAtest"]), int(sec["serviceNumber"]), reduct, epoch, int(sec["MAX_Iter"]), int(sec["popSize"]),
+                seed=seed).start()
+        return 0
     sec = cfg[f"{ds}-ML+2PN"]
     flags = [a for a in argv[3:] if a.startswith("--")]
     pos = [a for a in argv[3:] if not a.startswith("--")]

@@ -69,3 +69,43 @@ def test_eswoa_rejects_what_it_does_not_implement(dev):
     with pytest.raises(ops.GnnpnError):                       # host tensors: no CPU path
         ops.eswoa(torch.zeros(4, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), torch.zeros(3, 4, dtype=torch.float64),
                   torch.zeros(1, 4, dtype=torch.float64), torch.zeros(3, dtype=torch.int32), 4, 2, torch.zeros(1, dtype=torch.int64), 3)
+
+
+def test_woa_driver_end_to_end(dev, tmp_path, monkeypatch):
+    """``WOA(...).start()`` in its ML2PNWOATest mode from the artefact files to ``ML+2PN+WOA.txt``: the 1000 qualities
+    the reference itself produced (per-problem streams, both `reduct` settings), to the last bit."""
+    from test_host_logic import _woa_driver_setup
+    from gnnpn_sc_amd import WOA
+    monkeypatch.chdir(tmp_path)
+    fx, _actions, _n_train = _woa_driver_setup(str(tmp_path))
+    p = fx["params"]
+    for reduct in (0, 0.55):
+        drv = WOA.WOA("QWS", p["T"], 0, 1, 0, 0, 4, reduct, -1, p["MAX_Iter"], p["popSize"], seed=p["base_seed"], device=dev)
+        out = drv.start()
+        with open("./solutions/WOA/QWS//ML+2PN+WOA.txt") as f:
+            written = json.load(f)
+        want = fx["modes"][str(reduct)]
+        assert written["quality"] == out["quality"] == want["quality"]
+        assert out["averageQ"] == want["averageQ"]
+    with pytest.raises(NotImplementedError):
+        WOA.WOA("QWS", p["T"], 1, 0, 0, 0, 4, 0, -1, 4, 4).start()
+
+
+def test_main_cli_woa(dev, tmp_path, monkeypatch):
+    """``python main.py QWS WOA --seed N`` (reference main.py:86-94) drives the same run as the class."""
+    import contextlib
+    import io
+    from test_host_logic import _woa_driver_setup
+    monkeypatch.chdir(tmp_path)
+    fx, _a, _n = _woa_driver_setup(str(tmp_path))
+    p = fx["params"]
+    (tmp_path / "environment.ini").write_text(
+        f"[QWS-WOA]\nserCategory = {p['T']}\nMLESWOAtest = 0\nML2PNWOATest = 1\nMLWOATest = 0\nESWOAtest = 0\n"
+        f"serviceNumber = 4\nreduct = 0\nepoch = -1\nMAX_Iter = {p['MAX_Iter']}\npopSize = {p['popSize']}\n")
+    import main as cli
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["main.py", "QWS", "WOA", "--seed", str(p["base_seed"])]) == 0
+    with open("./solutions/WOA/QWS//ML+2PN+WOA.txt") as f:
+        assert json.load(f)["quality"] == fx["modes"]["0"]["quality"]
+    assert len(buf.getvalue().strip().splitlines()) == 1000            # one progress line per problem, as the reference prints

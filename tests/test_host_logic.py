@@ -75,7 +75,7 @@ def test_check_and_cli_match_reference(fx, workdir):
     assert buf.getvalue() == fx["check"]["printed"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        assert cli.main(["main.py", "QWS", "WOA"]) == 1
+        assert cli.main(["main.py", "QWS", "DAAGA"]) == 1
     assert buf.getvalue().strip() == "Please check the parameters!"       # reference main.py:231
 
 
@@ -183,3 +183,53 @@ def test_batch_shard_is_a_partition():
         assert int(p.seg_ptr[0]) == 0 and int(p.seg_ptr[-1]) == p.x.shape[0]
         assert int(p.wf_csr.rowptr[-1]) == p.wf_csr.col.numel()
         assert p.wf_csr.col.numel() == 0 or (int(p.wf_csr.col.min()) >= 0 and int(p.wf_csr.col.max()) < p.x.shape[0])
+
+
+def _woa_driver_setup(tmp):
+    """Rebuild the data set and the PNHigh actions file of tests/golden/woa_driver.json under ``tmp`` (cwd)."""
+    import gnnpn_sc_amd.synth as synth
+    import gnnpn_sc_amd.loadData as mine
+    with open(os.path.join(GOLDEN, "woa_driver.json")) as f:
+        fx = json.load(f)
+    p = fx["params"]
+    ds = synth.make_dataset(p["T"], p["S"], p["P"], seed=p["seed"], tasks_per_problem=p["tasks_per_problem"],
+                            lo_range=tuple(p["lo_range"]))
+    synth.write_dataset(tmp, "QWS", ds)
+    os.makedirs(os.path.join(tmp, "solutions", "pretrained"))
+    n_train = p["P"] // 4 * 3
+    lists0, _, _ = mine.loadDataOther("QWS", False)
+    actions = [[[0.0, 1.0, 1.0, 1.0, 0, 0, 0, 0] for _ in range(p["P"] - n_train)] for _ in range(p["T"])]
+    for b, nodes in enumerate(ds["nodefeatures"][n_train:]):
+        cats = [n[:-6].index(1) - 1 for n in nodes][1:]
+        for l, c in enumerate(cats):
+            k = fx["picks"][b][l]
+            q = fx["foreign"][f"{b},{l}"] if k < 0 else list(lists0[b][l][k])
+            actions[c][b] = q + [0, 0, 0, 0]
+    with open(os.path.join(tmp, "solutions", "pretrained", "QWS-PNHigh.txt"), "w") as f:
+        json.dump(actions, f)
+    return fx, actions, n_train
+
+
+def test_load_data_other_and_adds_match_reference(tmp_path, monkeypatch):
+    """loadDataOther / addS (loadData.py:155-276) in both `reduct` settings of environment.ini against the digests of the
+    reference's own output (tests/golden/make_golden_woa.py), and the oracle's qualities on a sample of the problems."""
+    import hashlib
+    import copy
+    import gnnpn_sc_amd.loadData as mine
+    from oracle import woa as owoa
+    monkeypatch.chdir(tmp_path)
+    fx, actions, n_train = _woa_driver_setup(str(tmp_path))
+    p = fx["params"]
+    n_test = p["P"] - n_train
+    sols = [[actions[c][b][:4] for c in range(p["T"]) if sum(actions[c][b][:4]) != 3] for b in range(n_test)]
+    ssets = [{tuple(round(v, 5) for v in r) for r in rows} for rows in sols]
+    for reduct in (0, 0.55):
+        want = fx["modes"][str(reduct)]
+        lists, cons, mins = mine.loadDataOther("QWS", reduct, sSetList=ssets, train=False)
+        assert hashlib.sha256(json.dumps([lists, cons]).encode()).hexdigest() == want["lists_sha256"]
+        assert json.loads(json.dumps(lists[:3])) == want["lists_head"] and cons[:3] == want["constraints_head"]
+        assert [sum(len(l) for l in q) for q in lists] == want["kept_per_problem"]
+        for b in range(0, n_test, 9):                            # every 9th problem through the oracle
+            r = owoa.eswoa(lists[b], cons[b], copy.deepcopy(sols[b]), p["popSize"], p["MAX_Iter"],
+                           owoa.DrawStream(p["base_seed"] + n_train + b))
+            assert mins[n_train + b] / r["best_fitness"] == want["quality"][b], (reduct, b)
