@@ -389,6 +389,12 @@ def main():
         line["split_operands"] = split_line
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, table, pb, net, low, high)
+    # RCCL writes a version banner to the C stdout buffer, which would otherwise come out at exit, AFTER this line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
     print(json.dumps(line), flush=True)
     gdist.destroy(2 if force_dist else world)
 
