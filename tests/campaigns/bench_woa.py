@@ -2,7 +2,7 @@
 vs the CPU oracle on a few of them.  Usage: bench_woa.py [n_problems] [max_iter]"""
 import sys, os, time, copy
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gnnpn_sc_amd import WOA, ops
 from oracle import woa as owoa                       # CPU baseline / checker only
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -3,7 +3,7 @@ random shapes, including constraint ranges that leave categories without a feasi
 Usage: fuzz_front.py [n_configs] [seed]"""
 import sys, os, random, time
 import numpy as np, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from oracle import ml as oml, data as odata, pn as opn      # checker use only
 import gnnpn_sc_amd.synth as synth

@@ -1,7 +1,7 @@
 """Fuzz campaign: random shapes / seeds, HIP two-level decode (all precisions and decoder forms) against the CPU
 oracle run live, judged by the parity rule of tests/parity.py.  Usage: fuzz_parity.py [n_configs] [seed]"""
 import sys, os, random, time, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from oracle import pn as opn                      # checker use only
 from parity import LOGIT_ATOL, R_ATOL, assert_index_parity, robust_problems

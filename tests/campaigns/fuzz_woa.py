@@ -3,7 +3,7 @@ category (1..20), population, iterations, seeded / unseeded / foreign picks, tig
 Usage: fuzz_woa.py [n_configs] [seed]"""
 import sys, os, copy, random, time
 import numpy as np, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from gnnpn_sc_amd import WOA
 from oracle import woa as owoa                      # checker only

@@ -14,7 +14,7 @@ LOGIT_ATOL = 2e-4   # |C*tanh(dot)| differences (C = 10)
 # QoS score tolerance of BASELINE.json's north_star, 1e-5: scores are rounded to 5 decimals (modelPN.py:61), so two
 # results whose unrounded values straddle a rounding boundary differ by exactly one unit, 1e-5 — which as a
 # difference of two fp32 numbers of magnitude <= 3 (violate <= 2, objFunc <= 1) reads 1e-5 +- ulp(3) = 1e-5 +- 2.4e-7
-# (tools/fuzz_parity.py found 2.81652 vs 2.81653 -> 1.00136e-5).
+# (tests/campaigns/fuzz_parity.py found 2.81652 vs 2.81653 -> 1.00136e-5).
 R_ATOL = 1e-5 + 2 * 2.4e-7
 
 
