@@ -53,7 +53,7 @@ __device__ __forceinline__ int ror16(int v, int n) {
 // SPLIT: W_hh.h with fp16 hi+lo operands (coop_common.h); everything else as in the fp32 form
 // OCC: workgroups per CU the build is sized for — 1 (512 registers: fastest alone) or 2 (256 registers: shares the
 // CU with a workgroup of another launch, pipeline.PipelinedRunner)
-template <bool FOLDX, bool DIAG, bool SPLIT, int OCC>
+template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 : 1)>
 __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, int n_nets,
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 
             // this step's window rows, own 32-unit slice: thread (row, cand) holds 32 floats
             // (OCC == 2: two threads per (row, cand), 16 floats each — half the registers; K <= 8 there)
-            constexpr int EVH = OCC == 2 ? 2 : 1, EVN = 8 / EVH;
+            constexpr int EVH = EVH_, EVN = 8 / EVH;   // EVH = 2 needs 2*16*K <= 256 threads, i.e. K <= 8
             float4 ev[EVN];
             const int ppair = tid / EVH, phalf = tid - ppair * EVH;
             const int prow = ppair / K, pcand = ppair - prow * K;
@@ -517,19 +517,23 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     if (split && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
     const int lds_kb = gnnpn_option_coop_lds_kb();
-#define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_)                                                                          \
-    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_>), dim3(groups * G), dim3(256),           \
-                       coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_>, lds_kb), s, \
-                       args, p_h, p_p, p_l, p_err, n_nets, groups_per_net, abl)
+#define GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, EVH_)                                                                   \
+    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(groups * G), dim3(256),     \
+                       coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
+                       s, args, p_h, p_p, p_l, p_err, n_nets, groups_per_net, abl)
+#define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
     if (shared_cu && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side only");
-    if (shared_cu && args.K > 8) return GNNPN_E_UNSUP;   // two threads per (row, candidate): 2*16*K <= 256
-    if (split && shared_cu) GNNPN_DEC8(true, false, true, 2);
+    const bool wide_k = args.K > 8;                       // two threads per (row, candidate) need 2*16*K <= 256
+    if (split && shared_cu && wide_k) GNNPN_DEC8X(true, false, true, 2, 1);
+    else if (split && shared_cu) GNNPN_DEC8(true, false, true, 2);
     else if (split) GNNPN_DEC8(true, false, true, 1);
+    else if (shared_cu && wide_k) GNNPN_DEC8X(true, false, false, 2, 1);
     else if (shared_cu) GNNPN_DEC8(true, false, false, 2);
     else if (fold && (abl & 32)) GNNPN_DEC8(true, true, false, 1);
     else if (fold) GNNPN_DEC8(true, false, false, 1);
     else GNNPN_DEC8(false, false, false, 1);
 #undef GNNPN_DEC8
+#undef GNNPN_DEC8X
     return GNNPN_OK;
 }

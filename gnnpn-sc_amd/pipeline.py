@@ -160,8 +160,7 @@ class PipelinedRunner:
     def __init__(self, pipe, services, example_batch, slots=2):
         self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
         self.streams = [torch.cuda.Stream() for _ in range(self.n_slots)]
-        # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4;
-        # falls back to the 16-member form for K > 8).  Measured at QWS B=256 against the 16-member form (3):
+        # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
         # 228 k vs 221 k problems/s in fp32, 353 k vs 316 k with the split precision.
         shared = 4
         self.decode_impl = int(os.environ.get("GNNPN_PIPE_DECODE_IMPL", shared if self.n_slots > 1 else 0))
