@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     const u64* src_l = xl + ((size_t)tile * T + (k - 1)) * ROWS * K + wave * 4 * K;
                     const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all members
                     const int n_l = 4 * K;
-                    unsigned vh[16], vp[8], vl = 0;
+                    constexpr int NPJ = EVH_ == 2 ? 4 : 8;   // partial-dot granules per lane: G*4*K / 64, K <= 8 in the EVH_ = 2 builds
+                    unsigned vh[16], vp[NPJ], vl = 0;
                     bool ok = false;
                     for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
                         bool good = true;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                             good &= (unsigned)(x >> 32) == tag;
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
+                        for (int j = 0; j < NPJ; ++j) {
                             if (lane + 64 * j < n_p) {
                                 const u64 x = granule_load(src_p + lane + 64 * j);
                                 vp[j] = (unsigned)x;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                             hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < NPJ; ++j) {
                         if (lane + 64 * j < n_p) part_lin[wave][lane + 64 * j] = __uint_as_float(vp[j]);
                     }
                     if (lane < n_l) {
