@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
 """ML+2PN inference throughput on MI355X (BASELINE.json metric: service-composition problems/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload qws|normal|synth4|synth5] [--batch B] [--precision f32|split|f16]
+    python bench.py --gpus N --steps K --warmup W [--workload qws|normal|synth4|synth5] [--batch B]
+                    [--precision f32|split|f16] [--scaling weak|strong] [--global-batch G]
 
 A "step" = one pass of the whole hot path over one batch of B synthetic problems that is already
 resident in HBM: GNN scores -> per-category top-K feasible candidates -> Low/High pointer-network
 encode + greedy decode -> QoS reward (+ at N>1 the single all-gather of the selected indices).
-One process per GPU; at N>1 every rank owns its own B problems (weak scaling, no data-path
-collective besides that all-gather).  Rank 0 prints ONE JSON line.
+One process per GPU.  Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks come from the environment; launched plainly as `python bench.py --gpus N` (N > 1) it starts its own N rank
+processes BEFORE anything touches a GPU and exits with their status.  Rank 0 prints ONE JSON line.
+  --scaling weak   (default) every rank owns its own B problems per step: global batch = N * B
+  --scaling strong the global batch is fixed (--global-batch, default the workload's: 4096 for synth4 = BASELINE
+                   configs[3] "batch=4096 sharded over 8") and sharded contiguously: rank r runs G/N problems per step
+No data-path collective besides the one all-gather of the selected indices.
+The timed region (exactly K steps between barrier + synchronize on both sides, MAX over ranks) is REPEATED until at
+least 1 s has been measured; `value` / `ms_per_step` are the median round, `timing` carries min / median / max.
+Steps rotate over --batches (default 4) distinct resident batches per rank.
 
 Extra objects on the line:
   roofline     : the dominant kernel by time, priced against the bound that applies to it
@@ -42,7 +51,7 @@ WORKLOADS = {
                 desc="QWS shape: T=47 K=5 L=235 S=2507(assumed) H=256, batch=256 (BASELINE configs[1])"),
     "normal": dict(T=50, K=10, S=5000, B=1024, n_t=10, n_gcn=4,
                    desc="Normal shape: T=50 K=10 L=500 S=5000(assumed) H=256, batch=1024 (configs[2])"),
-    "synth4": dict(T=1000, K=5, S=5000, B=512, n_t=1000, n_gcn=2,
+    "synth4": dict(T=1000, K=5, S=5000, B=512, n_t=1000, n_gcn=2, G=4096,
                    desc="synthetic 1000-task/5000-candidate, batch=512 per GPU (configs[3] = 4096 over 8)"),
     "synth5": dict(T=2000, K=10, S=20000, B=64, n_t=2000, n_gcn=2,
                    desc="synthetic 2000-task/20000-candidate, batch=64 per GPU (configs[4]; its 'fp16 encoder MFMA path' "
@@ -68,10 +77,12 @@ def algorithmic_cost(name, w, B):
     L = T * K
     if name == "lstm_encode":       # both nets in one launch: recurrent matmul flops
         return dict(bound="mfma", work=2 * B * L * 2 * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
-    if name == "pointer_decode":    # BOTH nets in one launch; per net: every enc_out row once (L*H*4), the
-        # picked embedded row + state per step, outputs   (SURVEY §8d "PN decode, one problem, one net")
-        byt = 2 * B * (L * H * 4 + T * (H * 4 + 2 * H * 4) + T * (8 * 4 + K * 4 + 8 + 32))
+    if name == "pointer_decode":    # BOTH nets in one launch; per net and problem exactly SURVEY.md section 8d's "PN decode,
+        # one problem, one net": every enc_out row once (L*H*4) + per-step state T*(2*H*4) + outputs T*(8 + K*4)
+        byt = 2 * B * (L * H * 4 + T * (2 * H * 4) + T * (8 + K * 4))
         return dict(bound="hbm", work=byt, unit="GB/s", peak=PEAK_HBM_GBS)
+    if name == "request_branch":    # fused GIN branch: reads the node rows + CSR once, writes [B,128]; weights are L2-resident
+        return dict(bound="hbm", work=w["n_nodes"] * 7 * 4 + w["n_edges"] * 4 + B * 128 * 4, unit="GB/s", peak=PEAK_HBM_GBS)
     if name == "pregates_gemm":     # [B*L,256] x [256,1024] per net
         return dict(bound="mfma", work=2 * B * L * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
     if name == "csr_aggregate_gcn":  # 2*S*C*4 + E*(4+4) + (S+1)*4, C=256
@@ -170,13 +181,70 @@ def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
                       f"{cores} threads of {os.cpu_count()} host CPUs, {el:.1f} s"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) and relay their status.
+    Runs BEFORE this process touches a GPU (torch.cuda.device_count() does not initialise one on this image) and never
+    replaces a process image: the children are ordinary subprocesses, the parent only waits."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n}: this node has {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
+def rank_batches(synth, table, w, rank, world, scaling, n_batches):
+    """The resident synthetic batches of one rank (host side).  weak: B problems per rank and batch, seeds differ by
+    rank.  strong: batch j is ONE global set of G problems made of 8 (or `world`) seeded chunks, of which this rank
+    owns a contiguous run — the same global set at every N, so N=1 and N=8 work on identical problems."""
+    out = []
+    if scaling == "weak":
+        for j in range(n_batches):
+            out.append(synth.make_problem_batch(table, w["B"], seed=1 + rank + 97 * j, tasks_per_problem=w["n_t"]))
+        return out
+    import numpy as np
+    n_chunks = 8 if 8 % world == 0 else world
+    G = w["G"]
+    if G % n_chunks:
+        raise SystemExit(f"--global-batch {G} must be a multiple of {n_chunks}")
+    per = n_chunks // world
+    for j in range(n_batches):
+        parts = [synth.make_problem_batch(table, G // n_chunks, seed=1 + 97 * j + 1009 * c, tasks_per_problem=w["n_t"])
+                 for c in range(rank * per, (rank + 1) * per)]
+        nodes = np.cumsum([0] + [p.x.shape[0] for p in parts])
+        probs = np.cumsum([0] + [p.n_problems for p in parts])
+        out.append(synth.ProblemBatch(
+            np.concatenate([p.x for p in parts]), np.concatenate([p.edge_index + nodes[i] for i, p in enumerate(parts)], 1),
+            np.concatenate([p.batch + probs[i] for i, p in enumerate(parts)]),
+            np.concatenate([p.local_bounds for p in parts]), np.concatenate([p.present for p in parts]),
+            np.concatenate([p.global_bounds for p in parts])))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="qws", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU and step (default: the workload's; weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: problems per step over ALL GPUs "
+                    "(default: the workload's G, else its per-GPU batch)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps rotate over")
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step timed region until this many seconds")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "split"],
                     help="f16: opt-in fp16-operand encoder (BASELINE configs[4]); NOT the headline dtype — the line "
                          "then carries the agreement with the f32 path")
@@ -192,11 +260,13 @@ def main():
                     help="independent steps (batches) in flight on separate HIP streams (needs --graph 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                                 # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ML+2PN hot path has no CPU implementation")
     dev = torch.device("cuda", local_rank)
@@ -204,23 +274,34 @@ def main():
 
     import gnnpn_sc_amd.synth as synth
     from gnnpn_sc_amd import dist as gdist
-    from gnnpn_sc_amd import modelPN, ops
-    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
 
     force_dist = os.environ.get("GNNPN_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         gdist.init_process_group("nccl", dev)
 
     w = dict(WORKLOADS[args.workload])
     if args.batch:
         w["B"] = args.batch
+    if args.scaling == "strong":
+        w["G"] = args.global_batch or w.get("G", w["B"])
+        if w["G"] % world:
+            raise SystemExit(f"--global-batch {w['G']} is not divisible by {world} GPUs")
+        w["B"] = w["G"] // world
     T, K, S, B = w["T"], w["K"], w["S"], w["B"]
     table = synth.make_service_table(T, S, seed=0, degree=32)
     w["E"] = int(table.edge_index.shape[1]) + S            # + self loops
-    pb = synth.make_problem_batch(table, B, seed=1 + rank, tasks_per_problem=w["n_t"])
+    host_batches = rank_batches(synth, table, w, rank, world, args.scaling, max(1, args.batches))
+    pb = host_batches[0]
+    w["n_nodes"], w["n_edges"] = int(pb.x.shape[0]), int(pb.edge_index.shape[1])
     net, low, high = build_models(T, S, K, dev, w["n_gcn"])
     pipe = ML2PNPipeline(net, low, high, K, precision=args.precision)
-    svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(b, dev) for b in host_batches]
+    batch = batches[0]
+    del host_batches[1:]
 
     timers = KernelTimers()
     if not args.no_kernel_timers:
@@ -228,49 +309,76 @@ def main():
         timers.wrap(ops, "pointer_decode", "pointer_decode")
         timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
         timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
+        if hasattr(ops, "request_branch"):
+            timers.wrap(ops, "request_branch", "request_branch")
 
     # Steps are independent batches.  Default: pipeline.PipelinedRunner — `inflight` slots, each one
-    # captured HIP graph of the whole pass with its own stream, outputs and hand-off workspaces; step i
-    # runs on slot i % inflight, so the latency-bound recurrent kernels of one step overlap the next
-    # step's kernels.  Events cannot be read back from a replayed graph, and event pairs between the
-    # kernels of an eager timed region cost ~25 % throughput, so the per-kernel durations come from a
+    # captured HIP graph of the whole pass with its own stream, static inputs/outputs and hand-off workspaces; step i
+    # copies resident batch i % n_batches into slot i % inflight's static inputs (device-to-device, on the slot's
+    # stream, inside the timed region) and replays the slot's graph, so the latency-bound recurrent kernels of one
+    # step overlap the next step's kernels.  Events cannot be read back from a replayed graph, and event pairs between
+    # the kernels of an eager timed region cost ~25 % throughput, so the per-kernel durations come from a
     # separate eager pass on one stream right after the timed region; --graph 0 (eager, one stream)
     # records them inside the timed region instead.
-    from gnnpn_sc_amd.pipeline import PipelinedRunner
     n_slots = max(1, args.inflight) if args.graph else 1
     runner = PipelinedRunner(pipe, svc, batch, slots=n_slots) if args.graph else None
+    last = {}                                                   # slot -> index of the batch its outputs belong to
 
     def step(i, runner=runner):
+        j = i % len(batches)
         if runner is not None:
-            out, s = runner.submit()
+            out, s = runner.submit(batches[j])
             stream = runner.stream(s)
+            last[(id(runner), s)] = j
         else:
-            out, stream = pipe.run(svc, batch), torch.cuda.current_stream()
+            out, stream = pipe.run(svc, batches[j]), torch.cuda.current_stream()
         step.last = out
-        if world > 1 or force_dist:
+        if use_dist:
             with torch.cuda.stream(stream):
                 return gdist.all_gather_indices(out["idx_high"]), out["R"]
         return out["idx_high"], out["R"]
+
+    def timed_rounds(run_step):
+        """The contract's timed region — barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks —
+        repeated until --min-time seconds have been measured (every rank sees the same maxima, so they stop together)."""
+        rounds, total, i0, res = [], 0.0, args.warmup, None
+        while True:
+            torch.cuda.synchronize()
+            gdist.barrier(world)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                res = run_step(i0 + i)
+            torch.cuda.synchronize()
+            gdist.barrier(world)
+            dt = gdist.max_over_ranks(time.perf_counter() - t0, dev, world)
+            rounds.append(dt)
+            total += dt
+            i0 += args.steps
+            if total >= args.min_time or len(rounds) >= 1000:
+                return rounds, res
+
+    def summarise(rounds):
+        r = sorted(rounds)
+        med = r[len(r) // 2] if len(r) % 2 else 0.5 * (r[len(r) // 2 - 1] + r[len(r) // 2])
+        return med, {"rounds": len(r), "steps_per_round": args.steps,
+                     "round_ms": {"min": round(r[0] * 1e3, 4), "median": round(med * 1e3, 4), "max": round(r[-1] * 1e3, 4)},
+                     "spread_pct": round((r[-1] - r[0]) / med * 100, 2)}
 
     gc.collect()
     gc.disable()                     # no collector pauses inside the timed region or the timing pass
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    gdist.barrier(world)
-    torch.cuda.synchronize()
     timers.enabled = not args.graph
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        idx, R = step(i)
-    torch.cuda.synchronize()
-    gdist.barrier(world)
-    elapsed = time.perf_counter() - t0
+    rounds, (idx, R) = timed_rounds(step)
     timers.enabled = False
-    elapsed = gdist.max_over_ranks(elapsed, dev, world)
-    ops.check_status(dev)            # a timed-out hand-off would have invalidated the run
-    # self-check: the (overlapped) results equal a single-stream run of the same kernels on the same batch
-    ref = runner.reference_run(0) if runner is not None else pipe.run(svc, batch)
+    elapsed, timing = summarise(rounds)
+    if runner is not None:
+        runner.synchronize(check=True)   # sticky status of every launch of the timed region: a timed-out hand-off voids the run
+    ops.check_status(dev)
+    # self-check: every slot's (overlapped) result equals a single-stream run of the same kernels on the same batch
+    decode_impl = runner.decode_impl if runner is not None else 0
+    ref = pipe.run(svc, batch, decode_impl=decode_impl)
     torch.cuda.synchronize()
     agreement = None
     if args.precision != "f32":       # agreement of the reduced-precision mode with the f32 path: same batch,
@@ -283,7 +391,8 @@ def main():
     if runner is not None:
         for s in range(n_slots):
             o = runner.graphs[s].outputs
-            if not (torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])):
+            rj = pipe.run(svc, batches[last[(id(runner), s)]], decode_impl=decode_impl)
+            if not (torch.equal(o["idx_high"], rj["idx_high"]) and torch.equal(o["R"], rj["R"])):
                 raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
     n_timed = args.steps
     if args.graph and not args.no_kernel_timers:
@@ -315,31 +424,25 @@ def main():
         gc.disable()
         for i in range(args.warmup):
             step(i, runner_s)
-        torch.cuda.synchronize()
-        gdist.barrier(world)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, runner_s)
-        torch.cuda.synchronize()
-        gdist.barrier(world)
-        el_s = gdist.max_over_ranks(time.perf_counter() - t0, dev, world)
+        rounds_s, _ = timed_rounds(lambda i: step(i, runner_s))
         gc.enable()
-        ops.check_status(dev)
+        el_s, timing_s = summarise(rounds_s)
+        runner_s.synchronize(check=True)
         out_s = runner_s.graphs[0].outputs
-        same = (out_s["actions"] == ref["actions"]).all(-1)
+        ref_s = pipe.run(svc, batches[last[(id(runner_s), 0)]], decode_impl=decode_impl)
+        same = (out_s["actions"] == ref_s["actions"]).all(-1)
         split_line = {"precision": "W_hh.h of encoder and decoder from fp16 hi+lo operand pairs, fp32 accumulate; rest f32",
                       "value": round(world * B * args.steps / el_s, 2), "unit": "problems/s",
-                      "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                      "ms_per_step": round(el_s / args.steps * 1e3, 4), "timing": timing_s,
                       "agreement_vs_f32": {"problems_with_identical_selection": round(float(same.all(1).float().mean()), 4),
                                            "identical_decisions": round(float(same.float().mean()), 5),
-                                           "max_abs_R_diff": round(float((out_s["R"] - ref["R"]).abs().max()), 6)}}
+                                           "max_abs_R_diff": round(float((out_s["R"] - ref_s["R"]).abs().max()), 6)}}
         del runner_s
 
     if rank != 0:
         gdist.destroy(world)
         return
-    if (world > 1 or force_dist) and tuple(idx.shape) != (world * B, T):
+    if use_dist and tuple(idx.shape) != (world * B, T):
         raise SystemExit(f"all-gather returned {tuple(idx.shape)}, expected {(world * B, T)}")
     value = world * B * args.steps / elapsed
     kernels = []
@@ -350,14 +453,13 @@ def main():
                         "bound": c["bound"], "achieved": round(achieved, 3), "peak": c["peak"], "unit": c["unit"],
                         "frac": round(achieved / c["peak"], 5)})
     # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
-    # profiles/r01_pmc_traffic.json, FETCH_SIZE doubled as the gfx950 guide prescribes; only quoted
-    # when this run is the workload those passes measured.
+    # profiles/r02_pmc_traffic.json, FETCH_SIZE doubled as the gfx950 guide prescribes; only quoted
+    # when this run is a workload / batch those passes measured.
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if args.workload == "qws" and B == 256:
-            traffic = {k: v["traffic"] for k, v in pmc["kernels"].items()}
+        traffic = {k: v["traffic"] for k, v in pmc.get(f"{args.workload}_b{B}", {}).get("kernels", {}).items()}
     except (OSError, ValueError, KeyError):
         pass
     for k in kernels:
@@ -370,16 +472,19 @@ def main():
     line = {
         "metric": "service-composition problems/sec (ML+2PN inference)", "value": round(value, 2),
         "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 encoder operands / f32 rest",
                                        "split": "f32 with the encoder's W_hh.h product as fp16 hi+lo split operands (fp32 accumulate) / f32 rest"}[args.precision],
-        "data": "synthetic",
+        "data": "synthetic", "timing": timing,
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
+                   "resident_batches": len(batches),
                    "launch": (f"{'hipGraph replay' if args.graph else 'eager'}, {n_slots} independent step(s) "
                               f"in flight on separate HIP streams"),
                    "kernel_timing": ("HIP events in a separate single-stream pass" if args.graph else
                                      "HIP events inside the timed region (durations include overlap with the "
                                      "other in-flight step)"),
+                   "service_embedding": "problem-independent GCN branch evaluated once per (weights, service table), "
+                                        "outside the step (SURVEY.md section 7)",
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}"},
         "roofline": roof, "kernels": kernels,
     }

@@ -72,6 +72,7 @@ def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=
     svc = DeviceServices.from_table(table, dev)
     rankings, actions = [], [[] for _ in range(T)]
     n_train = P // 4 * 3
+    from . import ops
     for lo in range(0, P, batch_size):
         hi = min(P, lo + batch_size)
         _, pb = ld.tables_from_dataset(ds, lo, hi)
@@ -79,6 +80,7 @@ def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=
         out = pipe.run(svc, batch)
         rankings += pipe.rankings(svc, batch).cpu().tolist()
         act = out["actions"].cpu().numpy().astype(np.float64)            # [b,T,8]
+        ops.check_status(dev)     # a timed-out inter-workgroup hand-off must never reach an artefact file
         for b in range(hi - lo):
             if lo + b >= n_train:
                 for t in range(T):

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -29,11 +29,11 @@ _SIGNATURES = {
     "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "gnnpn_rank_rows": (c_int, [_P, c_int64, _P, c_int32, c_int32, _P]),
     "gnnpn_precision_at_k": (c_int, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int32, _P, _P]),
-    "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P]),
+    "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                         _P, c_int64, _P]),
+                                         _P, _P, c_int64, _P]),
     "gnnpn_pointer_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
@@ -49,6 +49,12 @@ class DecodeNet(ctypes.Structure):
                                   "bhh", "latent_win", "emb_w", "emb_b", "xw_fold", "xb_fold", "start_fold", "idx", "win_logits", "pick_prob", "actions",
                                   "queries")] + \
                [("latent_from", c_int32), ("reserved", c_int32)]
+
+
+class LaunchOpts(ctypes.Structure):
+    """gnnpn_launch_opts_t of include/gnnpn_hip.h (per-call implementation choice / placement / sticky status)."""
+    _fields_ = [("impl", c_int32), ("lds_kb", c_int32), ("write_through", c_int32), ("reserved", c_int32),
+                ("sticky_status", _P)]
 
 
 class EncodeNet(ctypes.Structure):

@@ -14,6 +14,13 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
                        __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
 }
 
+// A failed bounded wait: the launch's own status word (zeroed by every launch) and the caller's sticky word
+// (never cleared by the library), see gnnpn_launch_opts_t.sticky_status.
+__device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsigned code) {
+    atomicOr(err, code);
+    if (sticky) atomicOr(sticky, code);
+}
+
 // ---- same-XCD fast path --------------------------------------------------------------------------
 // The CUs of one XCD share its L2, so a granule stored WITHOUT sc bits (it stays in that L2) is found
 // there by a same-XCD reader's sc1 (L1-bypassing) load ~0.2 us sooner than a write-through store that

@@ -56,8 +56,8 @@ __device__ __forceinline__ int ror16(int v, int n) {
 template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 : 1)>
 __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
-                                                                     unsigned* __restrict__ err, int n_nets,
-                                                                     int groups_per_net, int ablate_arg) {
+                                                                     unsigned* __restrict__ err, unsigned* __restrict__ sticky,
+                                                                     int n_nets, int groups_per_net, int ablate_arg) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     __shared__ int xcd_flag;
     const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
     if (same < 0) {
-        if (tid == 0) atomicOr(err, 4u);
+        if (tid == 0) coop_raise(err, sticky, 4u);
         return;
     }
     const bool same_xcd = same == 1 && !(ablate & 128);   // h and partial-dot granules stay inside the group
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
         }
         if (abort_flag) break;
     }
-    if (abort_flag && tid == 0) atomicOr(err, 2u);
+    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
 }
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
@@ -481,9 +481,8 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
 
 bool gnnpn_decode_coop_supported(int32_t H_, int32_t n_per) { return H_ == H && n_per <= KMAX; }
 
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, void* workspace,
-                             int64_t workspace_bytes,
-                             hipStream_t s) {
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, const CoopOpts& opts,
+                             void* workspace, int64_t workspace_bytes, hipStream_t s) {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -513,15 +512,16 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    const int abl = gnnpn_option_lstm_ablate();
+    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    unsigned* p_s = opts.sticky;
     const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
-    const int lds_kb = gnnpn_option_coop_lds_kb();
+    const int lds_kb = opts.lds_kb;
 #define GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, EVH_)                                                                   \
     hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(groups * G), dim3(256),     \
                        coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
-                       s, args, p_h, p_p, p_l, p_err, n_nets, groups_per_net, abl)
+                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, abl)
 #define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
     if (shared_cu && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side only");

@@ -40,8 +40,8 @@ __device__ __forceinline__ float ror16v(float v, int n) { return __int_as_float(
 template <int NP, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                       u64* __restrict__ xp, u64* __restrict__ xl,
-                                                                      unsigned* __restrict__ err, int n_nets,
-                                                                      int groups_per_net, int ablate) {
+                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
+                                                                      int n_nets, int groups_per_net, int ablate) {
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
     if (tid == 0) abort_flag = 0;
     const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
     if (same < 0) {
-        if (tid == 0) atomicOr(err, 4u);
+        if (tid == 0) coop_raise(err, sticky, 4u);
         return;
     }
     const bool same_xcd = same == 1 && !(ablate & 128);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
         }
         if (abort_flag) break;
     }
-    if (abort_flag && tid == 0) atomicOr(err, 2u);
+    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
 }
 
 int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
@@ -352,8 +352,8 @@ int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per) 
 
 // GNNPN_E_UNSUP (error text untouched) when this form does not fit the call: the caller then uses
 // decode_coop.hip
-int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
-                              hipStream_t s) {
+int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, const CoopOpts& opts, void* workspace,
+                              int64_t workspace_bytes, hipStream_t s) {
     for (int n = 0; n < n_nets; ++n)
         if (!args.net[n].xw_fold) return GNNPN_E_UNSUP;
     if (args.K > KMAX) return GNNPN_E_UNSUP;
@@ -380,19 +380,20 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
-    const int abl = gnnpn_option_lstm_ablate();
+    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    unsigned* p_s = opts.sticky;
     const bool split = precision == GNNPN_PREC_SPLIT;
-    const int lds_kb = gnnpn_option_coop_lds_kb();
+    const int lds_kb = opts.lds_kb;
 #define GNNPN_DEC2(NP_)                                                                                          \
     do {                                                                                                         \
         if (split)                                                                                               \
             hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(groups * G), dim3(256),           \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, true>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, n_nets, groups_per_net, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, abl);                                 \
         else                                                                                                     \
             hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(groups * G), dim3(256),          \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, false>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, n_nets, groups_per_net, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, abl);                                 \
     } while (0)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);

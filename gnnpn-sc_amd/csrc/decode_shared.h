@@ -1,6 +1,7 @@
 // Argument blocks shared by the two decoder implementations (decode.hip, decode_coop.hip).
 #pragma once
 #include "common.h"
+#include "lstm_shared.h"   // CoopOpts
 
 // device-side view of gnnpn_decode_net_t (same field order; see include/gnnpn_hip.h)
 struct DecodeNet {
@@ -40,10 +41,8 @@ struct DecodeArgs {
 };
 
 bool gnnpn_decode_coop_supported(int32_t H, int32_t n_per);
-int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, void* workspace,
-                             int64_t workspace_bytes,
-                             hipStream_t s);
-int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, void* workspace, int64_t workspace_bytes,
-                              hipStream_t s);
+int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, const CoopOpts& opts,
+                             void* workspace, int64_t workspace_bytes, hipStream_t s);
+int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, const CoopOpts& opts, void* workspace,
+                              int64_t workspace_bytes, hipStream_t s);
 int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per);
-int gnnpn_option_decode_impl();

@@ -85,8 +85,8 @@ static int launch_encode(const LstmNets& nets, int n_nets, int32_t B, int32_t L,
 }
 
 extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, int32_t B, int32_t L, int32_t H,
-                                     int32_t F, int32_t precision, void* workspace, int64_t workspace_bytes,
-                                     void* stream) {
+                                     int32_t F, int32_t precision, const gnnpn_launch_opts_t* opts_in, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
     GNNPN_REQUIRE(in, "lstm_encode: null net array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
@@ -114,14 +114,17 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     if (any_fold) GNNPN_REQUIRE(F == 8, "lstm_encode: in-kernel input projection is built for F = 8, got %d", F);
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int impl = gnnpn_option_lstm_impl();   // 0 auto, 1 streaming, 2 cooperative
+    const CoopOpts opts = coop_opts(opts_in);
+    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 2, "lstm_encode: opts.impl must be 0 (auto), 1 (streaming) or 2 (cooperative)");
+    GNNPN_REQUIRE(opts.lds_kb >= 0 && opts.lds_kb <= 160, "lstm_encode: opts.lds_kb must be 0..160");
+    const int impl = opts.impl;
     const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl >= 2);
     if (!coop && any_fold)
         GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the streaming form needs precomputed pregates");
     if (precision != GNNPN_PREC_F32 && !coop)
         GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: fp16-operand precisions need the cooperative form (H = 256, workspace)");
     if (coop) {
-        const int rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, precision, workspace, workspace_bytes, s);
+        const int rc = gnnpn_launch_encode_coop(nets, n_nets, B, L, precision, opts, workspace, workspace_bytes, s);
         if (rc != GNNPN_OK) return rc;
     } else if (H == 256) {
         launch_encode<256>(nets, n_nets, B, L, s);

@@ -96,9 +96,10 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentine
 // accumulation-order noise — at about a fifth of the fp32-MFMA issue time.  Opt-in; see DESIGN.md.
 template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
-                                                                  unsigned* __restrict__ err, int32_t B, int32_t L,
-                                                                  int n_nets, int groups_per_net, int ablate_arg) {
-    const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 (force the write-through hand-off) is a tested mode
+                                                                  unsigned* __restrict__ err, unsigned* __restrict__ sticky,
+                                                                  int32_t B, int32_t L, int n_nets, int groups_per_net,
+                                                                  int ablate_arg) {
+    const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi tile + lo tile (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     __shared__ int xcd_flag;
     const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
     if (same < 0) {
-        if (threadIdx.x == 0) atomicOr(err, 4u);
+        if (threadIdx.x == 0) coop_raise(err, sticky, 4u);
         return;
     }
     const bool same_xcd = same == 1 && !(ablate & 128);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
         }
         first_tile = false;
     }
-    if (abort_flag && threadIdx.x == 0) atomicOr(err, 1u);
+    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u);
 }
 
 // workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
@@ -346,8 +347,8 @@ extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
     return COOP_STATUS_BYTES + (int64_t)64 * GROUP_GRANULES * sizeof(u64);   // up to 64 groups
 }
 
-int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,
-                             int64_t workspace_bytes, hipStream_t s) {
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, const CoopOpts& opts,
+                             void* workspace, int64_t workspace_bytes, hipStream_t s) {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -374,12 +375,13 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
-    const int abl = gnnpn_option_lstm_ablate();
-    const int lds_kb = gnnpn_option_coop_lds_kb();
+    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    const int lds_kb = opts.lds_kb;
+    unsigned* p_s = opts.sticky;
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
-                       p_e, B, L, n_nets, groups_per_net, abl)
+                       p_e, p_s, B, L, n_nets, groups_per_net, abl)
     if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
         if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
         GNNPN_ENC(0, false, true);

@@ -17,8 +17,23 @@ struct LstmNets {
 };
 
 
-int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, void* workspace,
-                             int64_t workspace_bytes, hipStream_t s);
-int gnnpn_option_coop_lds_kb();   // LDS footprint target of the cooperative kernels (placement control), 0 = none
-int gnnpn_option_lstm_impl();
+// per-call launch options, resolved from gnnpn_launch_opts_t (NULL = defaults)
+struct CoopOpts {
+    int impl = 0, lds_kb = 0;
+    bool write_through = false;
+    unsigned* sticky = nullptr;
+};
+inline CoopOpts coop_opts(const gnnpn_launch_opts_t* o) {
+    CoopOpts c;
+    if (o) {
+        c.impl = o->impl;
+        c.lds_kb = o->lds_kb;
+        c.write_through = o->write_through != 0;
+        c.sticky = o->sticky_status;
+    }
+    return c;
+}
+
+int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, const CoopOpts& opts,
+                             void* workspace, int64_t workspace_bytes, hipStream_t s);
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

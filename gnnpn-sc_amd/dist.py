@@ -13,6 +13,13 @@ import torch.distributed as td
 def init_process_group(backend, device=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:    # a lone process asking for a group: world of one
+        import socket
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     if not td.is_initialized():
         kw = {}
         if backend == "nccl" and device is not None:

@@ -6,6 +6,7 @@ actions accumulated as ``allActions[T][nTest][8]`` (the artefact ``ML2PN.check``
 """
 import torch
 
+from . import ops
 from .modelPN import two_level_greedy
 
 
@@ -40,6 +41,7 @@ def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device=
         inputs = torch.stack(items).to(dev)
         out = two_level_greedy(low_model, model, inputs)
         act = out["actions"].cpu().numpy()
+        ops.check_status(dev)     # a timed-out inter-workgroup hand-off must never reach the caller's artefacts
         for a in range(serCategory):
             all_actions[a] += act[:, a, :].tolist()
         val_tour.append(float(out["R"].mean().item()))

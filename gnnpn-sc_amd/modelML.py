@@ -19,7 +19,7 @@ import os
 import torch
 from torch import nn
 
-from . import graph, ops
+from . import custom_ops, graph, ops   # noqa: F401  (custom_ops registers torch.ops.gnnpn.*)
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
@@ -164,36 +164,41 @@ class Net(nn.Module):
         """Workflow branch (modelML.py:133-143,165-166): x [N,7], CSR of the batched workflow graphs,
         graph segment pointer -> [B, hidden]."""
         p = self.prepared(x.device)
-        h = ops.embed_concat(x, p["node_table"])                                               # :134-137
+        h = torch.ops.gnnpn.embed_concat(x, p["node_table"])                                               # :134-137
         for lp in p["gin"]:                                                                     # :139-142
-            agg = ops.csr_aggregate(wf_csr.rowptr, wf_csr.col, None, h, self_coef=lp["eps"])
-            t = ops.linear(agg, lp["w0"], lp["b0"], lp["a1"], lp["s1"], ACT_RELU)
-            h = ops.linear(t, lp["w3"], lp["b3"], lp["a2"], lp["s2"], ACT_RELU)
-        h = ops.linear(h, *p["nodeLin"])                                                        # :165
-        return ops.segment_mean(seg_ptr, h)                                                     # :166
+            agg = torch.ops.gnnpn.csr_aggregate(wf_csr.rowptr, wf_csr.col, None, h, self_coef=lp["eps"])
+            t = torch.ops.gnnpn.linear(agg, lp["w0"], lp["b0"], lp["a1"], lp["s1"], ACT_RELU)
+            h = torch.ops.gnnpn.linear(t, lp["w3"], lp["b3"], lp["a2"], lp["s2"], ACT_RELU)
+        h = torch.ops.gnnpn.linear(h, *p["nodeLin"])                                                        # :165
+        return torch.ops.gnnpn.segment_mean(seg_ptr, h)                                                     # :166
 
     @torch.no_grad()
     def service_embedding(self, x_service, svc_csr):
         """Service branch (modelML.py:145-156,164): x_service [S,5], self-loop-complete CSR with RAW
         edge weights -> [S, hidden]."""
         p = self.prepared(x_service.device)
-        xs = ops.embed_concat(x_service, p["service_table"])                                    # :146-149
-        norm = ops.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
+        xs = torch.ops.gnnpn.embed_concat(x_service, p["service_table"])                                    # :146-149
+        norm = torch.ops.gnnpn.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
         for lp in p["gcn"]:                                                                     # :152-155
-            xw = ops.linear(xs, lp["wt"])                                                       # transform first
-            xs = ops.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
+            xw = torch.ops.gnnpn.linear(xs, lp["wt"])                                                       # transform first
+            xs = torch.ops.gnnpn.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
                                    shift=lp["s"], act=ACT_RELU)
-        return ops.linear(xs, *p["serviceLin"])                                                 # :164
+        return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                                 # :164
 
     @torch.no_grad()
-    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr):
+    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr, service_emb=None):
         """The two branches are independent until the score product: the service branch (GCN) is forked onto
         a side stream and joined before the GEMM, so ~20 small launch-latency-bound kernels run two abreast
-        (fork/join is stream-capturable: inside a HIP graph it becomes two parallel branches)."""
+        (fork/join is stream-capturable: inside a HIP graph it becomes two parallel branches).
+        ``service_emb`` [S, hidden]: the service branch's result computed earlier (it depends on the weights and the
+        service table only — pipeline.ML2PNPipeline caches it per (weights, table)); the branch is then skipped."""
+        if service_emb is not None:
+            xr = self.request_embedding(x, wf_csr, seg_ptr)
+            return torch.ops.gnnpn.linear(xr, service_emb, act=ACT_SIGMOID)                                 # :173-176
         if not self.parallel_branches:
             xr = self.request_embedding(x, wf_csr, seg_ptr)
             xs = self.service_embedding(x_service, svc_csr)
-            return ops.linear(xr, xs, act=ACT_SIGMOID)                                          # :173-176
+            return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                          # :173-176
         cur = torch.cuda.current_stream(x.device)
         side = self._side_streams.get(x.device)
         if side is None:
@@ -204,7 +209,7 @@ class Net(nn.Module):
         xr = self.request_embedding(x, wf_csr, seg_ptr)
         cur.wait_stream(side)
         xs.record_stream(cur)
-        return ops.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176
+        return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176
 
     def forward(self, data):
         """Net.forward (modelML.py:131-176) on a PyG-style ``data`` object with attributes x,

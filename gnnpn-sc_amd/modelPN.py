@@ -16,7 +16,7 @@ import math
 import torch
 from torch import nn
 
-from . import ops
+from . import custom_ops, ops
 
 # Fold embedding2 (modelPN.py:190) and the encoder LSTM's input projection into ONE [4H, 8] matrix
 # evaluated inside the recurrent kernel (W_ih.(W_e x + b_e) + b_ih = (W_ih W_e) x + (W_ih b_e + b_ih)):
@@ -53,7 +53,7 @@ class LatentWindows:
             return [self[i] for i in range(*k.indices(len(self)))]
         if k < 0:
             k += len(self)
-        return ops.attention_logits(self._enc_out, self._queries, k, self.idx, self._tanh_c, self._use_tanh)
+        return torch.ops.gnnpn.attention_logits(self._enc_out, self._queries, k, self.idx, self._tanh_c, self._use_tanh)
 
     def __iter__(self):
         return (self[k] for k in range(len(self)))
@@ -151,8 +151,8 @@ class PointerNet(nn.Module):
         if fold:
             return {"inputs": inputs, "w_in": w["enc_wfold"], "b_in": w["enc_bfold"], "whh": w["enc_whh"],
                     "bhh": w["enc_bhh"]}, None
-        embedded = ops.linear(inputs.reshape(B * L, F), w["emb_w"], w["emb_b"])
-        pregates = ops.linear(embedded, w["enc_wih"], w["enc_bih"])
+        embedded = torch.ops.gnnpn.linear(inputs.reshape(B * L, F), w["emb_w"], w["emb_b"])
+        pregates = torch.ops.gnnpn.linear(embedded, w["enc_wih"], w["enc_bih"])
         H = self.hidden_size
         return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
             embedded.view(B, L, H)
@@ -174,8 +174,8 @@ class PointerNet(nn.Module):
         """Encode + greedy decode; returns the decode dict of ops.pointer_decode plus enc_out."""
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
-        enc, h_n, c_n = ops.lstm_encode([enc_args])
-        out = ops.pointer_decode(
+        enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
+        out = custom_ops.pointer_decode(
             [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
                               _window_tensor(latent, self.serCategory, self.serNumber), fold=fold)],
             inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
@@ -225,8 +225,8 @@ def calc(services, constraints, sCategory):
     for i in range(consNum):
         act[0, 0, qosNum + 2 * i], act[0, 0, qosNum + 2 * i + 1] = constraints[i][0][-2], constraints[i][0][-1]
     dev = torch.device("cuda")
-    violate = int(ops.qos_reward(act.to(dev), "Low").item())
-    total = float(ops.qos_reward(act.to(dev), "High").item())
+    violate = int(torch.ops.gnnpn.qos_reward(act.to(dev), 0).item())
+    total = float(torch.ops.gnnpn.qos_reward(act.to(dev), 1).item())
     return violate, total - violate, []
 
 
@@ -237,7 +237,7 @@ def reward(sample_solution, optSolutions, sCategory, USE_CUDA=False, level="Low"
     if embedding_size != 0:
         raise NotImplementedError("embedding_size != 0 is outside the ML+2PN inference configuration")
     actions = torch.stack(list(sample_solution), dim=1).contiguous()
-    R = ops.qos_reward(actions, level)
+    R = torch.ops.gnnpn.qos_reward(actions, 0 if level == "Low" else 1)
     if verbose:
         lst = R.tolist()
         print(f"{level}, {sum(1 for v in lst if v >= 1)}, {sum(lst) / max(len(lst), 1)}: ", lst)
@@ -276,26 +276,35 @@ class CombinatorialRL(nn.Module):
 
 
 @torch.no_grad()
-def two_level_greedy(low, high, inputs, fold=None, precision="f32"):
+def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=0, lds_kb=0, write_through=False, ws=None):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
     action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
     win_high_raw + win_low (modelPN.py:216).
     precision: "f32" (default) | "split" (fp16 hi+lo operands in both W_hh.h products, fp32 accumulate: measured as
-    accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision)."""
+    accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
+    decode_impl / lds_kb / write_through / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,
+    ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
+    # the two decoders run in ONE launch with one (C, use_tanh, window shape): the reference applies each PointerNet's
+    # own (modelPN.py:119-122), so nets that differ there cannot take this fused path
+    for name in ("C", "use_tanh", "serNumber", "serCategory", "hidden_size", "seq_len"):
+        if getattr(la, name) != getattr(ha, name):
+            raise ops.GnnpnError(f"two_level_greedy: Low and High nets differ in {name} ({getattr(la, name)!r} vs "
+                                 f"{getattr(ha, name)!r}); decode them with separate CombinatorialRL.forward calls")
     la.check_precision(precision)
     ha.check_precision(precision)
     enc_l, emb_l = la.encode_args(inputs, fold)
     enc_h, emb_h = ha.encode_args(inputs, fold)
-    enc, h_n, c_n = ops.lstm_encode([enc_l, enc_h], precision=precision)
+    enc, h_n, c_n = custom_ops.lstm_encode([enc_l, enc_h], precision=precision, lds_kb=lds_kb, write_through=write_through, ws=ws)
     del enc_l, enc_h
-    dl, dh = ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
+    dl, dh = custom_ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
                                  ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold)],
                                 inputs, la.serCategory, la.serNumber, la.C, la.use_tanh,
-                                precision="split" if precision == "split" else "f32")
-    R = ops.qos_reward(dh["actions"], high.level)
+                                precision="split" if precision == "split" else "f32", impl=decode_impl, lds_kb=lds_kb,
+                                write_through=write_through, ws=ws)
+    R = torch.ops.gnnpn.qos_reward(dh["actions"], 0 if high.level == "Low" else 1)
     return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
             "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -127,57 +127,113 @@ def pack_lstm_weight(w):
     return w.reshape(4, H, H // 4, 4).permute(2, 0, 1, 3).contiguous()
 
 
-_workspaces = {}
-_options = {}
-_slot = 0
-
-
-def set_workspace_slot(slot):
-    """Cooperative kernels of launches that may be in flight at the same time (two pipelined steps on
-    two streams) must not share hand-off buffers: select the workspace set used by subsequent calls."""
-    global _slot
-    _slot = int(slot)
-
-
-def set_option(name, value):
-    """Run-time A/B switches of the library (gnnpn_set_option), e.g. ("lstm_impl", 1)."""
-    check(_lib.load().gnnpn_set_option(name.encode(), int(value)), "gnnpn_set_option")
-    _options[name] = int(value)
-
-
 # operand precision of the recurrent W_hh.h product -> GNNPN_PREC_* (include/gnnpn_hip.h)
 _PRECISIONS = {"f32": 0, "f16": 1, "split": 2}
 
 
-def encode_workspace(device):
-    """Per-device workspace of the cooperative encoder (status word + hand-off buffers)."""
-    key = (device.type, device.index, "encode", _slot)
-    if key not in _workspaces:
-        n = int(_lib.load().gnnpn_lstm_encode_workspace_bytes())
-        _workspaces[key] = torch.zeros(n, dtype=torch.uint8, device=device)
-    return _workspaces[key]
+class Workspaces:
+    """Hand-off workspaces + the sticky status word of the cooperative recurrent kernels, for ONE stream of launches.
 
+    Launches that may be in flight at the same time (two pipelined steps on two streams) must not share hand-off
+    buffers: each gets its own ``Workspaces`` (``PipelinedRunner`` owns one per slot).  A buffer is never freed or
+    replaced once handed out — a captured HIP graph may have baked its address in — so growing keeps the old tensor
+    alive; while ``frozen`` (set by whoever captured a graph over it) growing raises instead.
+    ``status`` is gnnpn_launch_opts_t.sticky_status: every cooperative launch ORs its failure code (a bounded
+    inter-workgroup wait timed out: outputs invalid) into it and nothing but ``check()`` clears it, so one host read
+    covers every launch since the last check."""
 
-def check_status(device):
-    """Synchronise and raise if a bounded inter-workgroup wait of the cooperative kernels timed
-    out (their outputs would be invalid).  Called by tests / bench after a run, never inside it."""
-    torch.cuda.synchronize(device)
-    for key, ws in _workspaces.items():
-        if key[:2] != (device.type, device.index):
-            continue
-        word = int(ws[:4].view(torch.int32).item())
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.id = -1                      # index in the process-wide registry (custom_ops pass it as an int)
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._encode = None
+        self._decode = None
+        self._retired = []
+        self.frozen = False
+
+    def encode(self):
+        if self._encode is None:
+            n = int(_lib.load().gnnpn_lstm_encode_workspace_bytes())
+            self._encode = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        return self._encode
+
+    def decode(self, B, T, n_per):
+        need = int(_lib.load().gnnpn_pointer_decode_workspace_bytes(B, T, n_per))
+        ws = self._decode
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                if self.frozen:
+                    raise GnnpnError(f"decode workspace of {ws.numel()} B is captured in a HIP graph and cannot grow to "
+                                     f"{need} B: use a separate Workspaces for the larger shape")
+                self._retired.append(ws)
+            ws = self._decode = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def check(self, what="cooperative kernel"):
+        """Synchronise the device and raise if any launch since the last check reported a failed hand-off."""
+        torch.cuda.synchronize(self.device)
+        word = int(self.status[0].item())
         if word != 0:
-            raise GnnpnError(f"cooperative kernel reported status {word:#x}: an inter-workgroup hand-off "
-                             "timed out (outputs invalid)")
+            self.status.zero_()
+            raise GnnpnError(f"{what}: status {word:#x} — an inter-workgroup hand-off timed out in at least one launch "
+                             "since the last check (its outputs are invalid)")
 
 
-def coop_supported(H, n_per=1, option=None):
+_default_ws = {}
+_all_ws = []
+
+
+def new_workspaces(device):
+    w = Workspaces(device)
+    w.id = len(_all_ws)
+    _all_ws.append(w)
+    return w
+
+
+def workspaces_by_id(ws_id):
+    return _all_ws[ws_id]
+
+
+def workspaces(device, ws=None):
+    """``ws`` itself, or the process-wide default ``Workspaces`` of ``device`` (single-stream use)."""
+    if ws is not None:
+        return ws
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _default_ws:
+        _default_ws[key] = new_workspaces(torch.device(*key))
+    return _default_ws[key]
+
+
+def set_option(name, value):
+    """Diagnostics switch of the library (gnnpn_set_option): only "lstm_ablate" (tools/).  Implementation choice,
+    placement and hand-off form are per-call arguments (``impl``, ``lds_kb``, ``write_through``)."""
+    check(_lib.load().gnnpn_set_option(name.encode(), int(value)), "gnnpn_set_option")
+
+
+def check_status(device=None):
+    """Synchronise and raise if a bounded inter-workgroup wait of ANY cooperative launch since the last check timed out
+    (the sticky status word of every Workspaces of this process, optionally of one device only)."""
+    want = None if device is None else torch.device(device)
+    for w in list(_all_ws):
+        if want is None or w.device.type == want.type and (want.index is None or w.device.index == want.index):
+            w.check()
+
+
+def _launch_opts(ws, impl, lds_kb, write_through):
+    o = _lib.LaunchOpts()
+    o.impl, o.lds_kb, o.write_through = int(impl), int(lds_kb), int(bool(write_through))
+    o.sticky_status = ws.status.data_ptr() if ws is not None else None
+    return o
+
+
+def coop_supported(H, n_per=1, impl=0):
     """Shapes the cooperative recurrent kernels are built for (else: per-workgroup streaming);
-    ``option`` names the A/B switch that can force the streaming form."""
-    return H == 256 and n_per <= 16 and _options.get(option, 0) != 1
+    ``impl`` 1 forces the streaming form."""
+    return H == 256 and n_per <= 16 and impl != 1
 
 
-def lstm_encode(nets, precision="f32"):
+def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None):
     """Run the encoder recurrence of len(nets) nets in ONE launch (gnnpn_lstm_encode_f32).
 
     precision="f16" (opt-in, cooperative form only): W_hh and h_{t-1} enter the recurrent product as
@@ -188,13 +244,15 @@ def lstm_encode(nets, precision="f32"):
     w_in [4H,8] + b_in [4H] (input projection evaluated inside the cooperative kernel; for shapes
     without a cooperative kernel the projection is materialised first with gnnpn_linear_f32 —
     the same k-ordered fma chain + bias, so the same bits).
+    impl: 0 auto, 1 per-workgroup streaming, 2 cooperative; lds_kb / write_through / ws: gnnpn_launch_opts_t and the
+    ``Workspaces`` to use (default: the device's shared one).
     -> (enc_out list [B,L,H], h_n list [B,H], c_n list [B,H])."""
     n = len(nets)
     H = nets[0]["bhh"].numel() // 4
     first = nets[0]["pregates"] if nets[0].get("pregates") is not None else nets[0]["inputs"]
     B, L = first.shape[0], first.shape[1]
     dev = first.device
-    coop = coop_supported(H, option="lstm_impl")
+    coop = coop_supported(H, impl=impl)
     arr = (_lib.EncodeNet * n)()
     enc, h_n, c_n, keep = [], [], [], []
     for i, d in enumerate(nets):
@@ -216,29 +274,21 @@ def lstm_encode(nets, precision="f32"):
         a.whh_packed = dev_ptr(d["whh"], F32, f"nets[{i}].whh").value
         a.bhh = dev_ptr(d["bhh"], F32, f"nets[{i}].bhh").value
         a.enc_out, a.h_n, a.c_n = (dev_ptr(t, F32, "out").value for t in (e, hn, cn))
-    ws = encode_workspace(dev) if coop else None
+    wsp = workspaces(dev, ws) if coop else None
+    buf = wsp.encode() if coop else None
     if precision not in _PRECISIONS:
         raise GnnpnError(f"lstm_encode: unknown precision {precision!r}")
     if precision != "f32" and not coop:
         raise GnnpnError(f"lstm_encode: precision={precision!r} needs the cooperative form (H = 256)")
-    check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, _PRECISIONS[precision],
-                                            dev_ptr(ws, torch.uint8, "workspace", True),
-                                            0 if ws is None else ws.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
+    opts = _launch_opts(wsp, impl, lds_kb, write_through)
+    check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, _PRECISIONS[precision], _lib.ctypes.byref(opts),
+                                            dev_ptr(buf, torch.uint8, "workspace", True),
+                                            0 if buf is None else buf.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
     return enc, h_n, c_n
 
 
-def decode_workspace(device, B, T, n_per):
-    """Per-device workspace of the cooperative decoder, grown on demand."""
-    key = (device.type, device.index, "decode", _slot)
-    need = int(_lib.load().gnnpn_pointer_decode_workspace_bytes(B, T, n_per))
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
-
-
-def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32"):
+def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32",
+                   impl=0, lds_kb=0, write_through=False, ws=None):
     """Greedy decode of 1 or 2 pointer networks in ONE call (gnnpn_pointer_decode_f32).
 
     nets: list of dicts with keys enc_out, h0, c0, start, wih, whh, bih, bhh, EITHER embedded [B,L,H]
@@ -247,7 +297,9 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
     Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
     queries [B,T,H] | None.
     precision="split": the W_hh.h product with fp16 hi+lo operands (cooperative, folded form only); "f16" is an
-    encoder-only mode and leaves the decoder in fp32."""
+    encoder-only mode and leaves the decoder in fp32.
+    impl: 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 (16-CU groups), 4 (8-CU groups, 256-register build for two
+    workgroups per CU); lds_kb / write_through / ws as for lstm_encode."""
     B, L, H = nets[0]["enc_out"].shape
     if precision not in _PRECISIONS:
         raise GnnpnError(f"pointer_decode: unknown precision {precision!r}")
@@ -267,7 +319,7 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         for name, key in (("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"), ("start", "start"),
                           ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"), ("bhh", "bhh")):
             setattr(a, name, dev_ptr(d[key], F32, f"nets[{i}].{key}").value)
-        coop = coop_supported(H, n_per, "decode_impl")
+        coop = coop_supported(H, n_per, impl)
         if d.get("xw_fold") is not None and coop:                          # folded input side (cooperative form)
             a.xw_fold = dev_ptr(d["xw_fold"], F32, f"nets[{i}].xw_fold").value
             a.xb_fold = dev_ptr(d["xb_fold"], F32, f"nets[{i}].xb_fold").value
@@ -288,11 +340,14 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value
         a.actions = dev_ptr(out["actions"], F32, "actions").value
         a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
-    ws = decode_workspace(dev, B, n_cat, n_per) if coop_supported(H, n_per, "decode_impl") else None
+    coop = coop_supported(H, n_per, impl)
+    wsp = workspaces(dev, ws) if coop else None
+    buf = wsp.decode(B, n_cat, n_per) if coop else None
+    opts = _launch_opts(wsp, impl, lds_kb, write_through)
     check(_lib.load().gnnpn_pointer_decode_f32(
         len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
-        _PRECISIONS["split"] if precision == "split" else 0,
-        dev_ptr(ws, torch.uint8, "workspace", True), 0 if ws is None else ws.numel(), stream_ptr()),
+        _PRECISIONS["split"] if precision == "split" else 0, _lib.ctypes.byref(opts),
+        dev_ptr(buf, torch.uint8, "workspace", True), 0 if buf is None else buf.numel(), stream_ptr()),
         "gnnpn_pointer_decode_f32")
     return outs
 

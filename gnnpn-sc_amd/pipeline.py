@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import graph, ops
+from . import custom_ops, graph, ops   # noqa: F401  (custom_ops registers torch.ops.gnnpn.*)
 from .modelPN import two_level_greedy
 
 
@@ -27,6 +27,7 @@ class DeviceServices:
     csr: graph.CSR               # self-loop-complete destination-major CSR, raw weights
     cat_ptr: torch.Tensor        # i32 [T+1]
     qos: torch.Tensor            # f64 [S,4]
+    emb_cache: tuple = None      # (prepared-weights object, [S,hidden] service embedding): see ML2PNPipeline.service_embedding
 
     @staticmethod
     def from_table(table, device):
@@ -84,64 +85,79 @@ class ML2PNPipeline:
     def __init__(self, net, low, high, n_per, precision="f32"):
         self.net, self.low, self.high, self.n_per = net, low, high, n_per
         self.precision = precision       # "f16": opt-in fp16-operand encoder (not parity-exact)
+        self.cache_service_embedding = True   # False: re-evaluate the GCN branch in every pass (round-1 behaviour)
+
+    @torch.no_grad()
+    def service_embedding(self, services):
+        """The GCN (service) branch of Net.forward (modelML.py:145-156,164): a function of the weights and the service
+        table ONLY, so it is evaluated once per (weights, table) and kept on the table ("compute
+        the service embedding once per model and cache it") instead of once per batch.  Loading / moving the weights
+        gives a new prepared-weights object and so invalidates the entry."""
+        prep = self.net.prepared(services.x_service.device)
+        c = services.emb_cache
+        if c is None or c[0] is not prep:
+            c = services.emb_cache = (prep, self.net.service_embedding(services.x_service, services.csr))
+        return c[1]
 
     @torch.no_grad()
     def scores(self, services, batch):
         """TrainML.test's forward (trainML.py:56-58)."""
-        return self.net.scores(batch.x, batch.wf_csr, batch.seg_ptr, services.x_service, services.csr)
+        return self.net.scores(batch.x, batch.wf_csr, batch.seg_ptr, services.x_service, services.csr,
+                               service_emb=self.service_embedding(services) if self.cache_service_embedding else None)
 
     @torch.no_grad()
     def candidates(self, services, batch, scores):
         """sort + loadDataPN + SCDataset, fused (trainML.py:62; loadData.py:101-149; trainPNHigh.py:23-31)."""
-        return ops.select_candidates(scores, services.cat_ptr, services.qos, batch.local_bounds, batch.present,
-                                     batch.global_bounds, self.n_per)
+        return torch.ops.gnnpn.segment_topk_feasible(scores, services.cat_ptr, services.qos, batch.local_bounds,
+                                                     batch.present, batch.global_bounds, self.n_per)
 
     @torch.no_grad()
-    def run(self, services, batch):
+    def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None):
+        """One pass.  decode_impl / lds_kb / ws: launch options of the recurrent kernels (modelPN.two_level_greedy)."""
         scores = self.scores(services, batch)
         rows, ids = self.candidates(services, batch, scores)
-        out = two_level_greedy(self.low, self.high, rows, precision=self.precision)
+        out = two_level_greedy(self.low, self.high, rows, precision=self.precision, decode_impl=decode_impl,
+                               lds_kb=lds_kb, ws=ws)
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
-    def capture(self, services, batch, warmup=2, slot=0):
+    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None):
         """Record one whole pass over (services, batch) into a HIP graph and return a callable that
         replays it on the CURRENT stream (one launch per step instead of ~25).  The returned dict's
-        tensors are the graph's static outputs: they are overwritten by every replay.  ``slot``
-        selects a private set of cooperative-kernel workspaces, so that graphs of different slots
-        may be in flight at the same time on different streams (independent batches pipelined)."""
-        ops.set_workspace_slot(slot)
-        try:
-            stream = torch.cuda.Stream()
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                for _ in range(warmup):          # allocate workspaces / pack weights outside the capture
-                    self.run(services, batch)
-            torch.cuda.current_stream().wait_stream(stream)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.run(services, batch)
-        finally:
-            ops.set_workspace_slot(0)
+        tensors are the graph's static outputs: they are overwritten by every replay.  ``ws`` is the
+        private ``ops.Workspaces`` of this graph (default: a new one), so that graphs may be in flight
+        at the same time on different streams (independent batches pipelined); it is frozen — the graph
+        holds its addresses — and lives as long as the returned callable."""
+        ws = ops.new_workspaces(batch.x.device) if ws is None else ws
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for _ in range(warmup):          # allocate workspaces / pack weights outside the capture
+                self.run(services, batch, decode_impl, lds_kb, ws)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.run(services, batch, decode_impl, lds_kb, ws)
+        ws.frozen = True
 
         def replay():
             graph.replay()
             return out
-        replay.graph, replay.outputs = graph, out
+        replay.graph, replay.outputs, replay.workspaces = graph, out, ws
         return replay
 
     @torch.no_grad()
     def rankings(self, services, batch):
         """The artefact TrainML.test writes (trainML.py:62-68,148-149): full ranking per problem."""
-        return ops.rank_rows(self.scores(services, batch))
+        return torch.ops.gnnpn.rank_rows(self.scores(services, batch))
 
     @torch.no_grad()
     def test(self, services, batch, labels):
         """TrainML.test (trainML.py:49-72): (idxList = full ranking per problem, [P@1, P@5]).
         ``labels`` [B,S] 0/1 (float32 device tensor).  Rankings stay on the device (int32 [B,S])."""
         ranking = self.rankings(services, batch)
-        pk = ops.precision_at_k(ranking, labels.float().contiguous(), (1, 5))
+        pk = torch.ops.gnnpn.precision_at_k(ranking, labels.float().contiguous(), [1, 5])
         return ranking, [float(v) for v in pk.mean(0).tolist()]
 
 
@@ -171,16 +187,10 @@ class PipelinedRunner:
         # and slot 1's to 56 KB: 100 + 56 fits a CU's 160 KB, 100 + 100 does not.
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
         self.lds_kb = [int(v) for v in env.split(",")] if env else ([100, 56] if self.n_slots == 2 else [0] * self.n_slots)
-        ops.set_option("decode_impl", self.decode_impl)
-        try:
-            self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
-            self.graphs = []
-            for s in range(self.n_slots):
-                ops.set_option("coop_lds_kb", self.lds_kb[s])
-                self.graphs.append(pipe.capture(services, self.batches[s], slot=s))
-        finally:
-            ops.set_option("decode_impl", 0)
-            ops.set_option("coop_lds_kb", 0)
+        self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
+        self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(self.n_slots)]
+        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
+                                    ws=self.workspaces[s]) for s in range(self.n_slots)]
         self.count = 0
 
     @staticmethod
@@ -211,12 +221,13 @@ class PipelinedRunner:
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
-        ops.set_option("decode_impl", self.decode_impl)
-        try:
-            return self.pipe.run(self.services, self.batches[slot])
-        finally:
-            ops.set_option("decode_impl", 0)
+        return self.pipe.run(self.services, self.batches[slot], decode_impl=self.decode_impl)
 
-    def synchronize(self):
+    def synchronize(self, check=True):
+        """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a
+        failed inter-workgroup hand-off (its outputs would be garbage) — the sticky status words of the slots."""
         for st in self.streams:
             st.synchronize()
+        if check:
+            for w in self.workspaces:
+                w.check("PipelinedRunner")

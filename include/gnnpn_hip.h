@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 1
+#define GNNPN_ABI_VERSION 2
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -159,24 +159,43 @@ typedef struct {
 #define GNNPN_PREC_F32 0
 #define GNNPN_PREC_F16 1
 #define GNNPN_PREC_SPLIT 2
+
+/* Per-call launch options of the two recurrent entry points (NULL = all defaults).  They select among
+ * implementations of the SAME arithmetic; nothing here is process-wide state.
+ *   impl            encoder: 0 auto, 1 per-workgroup streaming, 2 cooperative (8-CU groups)
+ *                   decoder: 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups),
+ *                            4 cooperative (8-CU groups, 256-register build that shares a CU with another launch)
+ *   lds_kb          LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernel, 0 = none:
+ *                   placement control for two launches sharing the CUs (100 on one stream + 56 on the other: a CU
+ *                   takes one workgroup of each, never two of one)
+ *   write_through   non-zero: always publish hand-off granules with agent-scope (sc1) stores instead of keeping them in
+ *                   the XCD's L2 when a group has verified at run time that it sits on one XCD (same results)
+ *   sticky_status   device uint32 or NULL: every failure code a cooperative kernel raises (bounded inter-workgroup
+ *                   wait timed out: outputs invalid) is OR-ed into it as well as into word 0 of the workspace.  The
+ *                   library never clears it — word 0 of the workspace is zeroed by every launch — so one host read
+ *                   after any number of launches tells whether ANY of them failed. */
+typedef struct {
+    int32_t impl;
+    int32_t lds_kb;
+    int32_t write_through;
+    int32_t reserved;
+    uint32_t* sticky_status;
+} gnnpn_launch_opts_t;
+
 int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B, int32_t L, int32_t H,
-                          int32_t F, int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+                          int32_t F, int32_t precision, const gnnpn_launch_opts_t* opts, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* Size of the device workspace the cooperative encoder needs (status words + hand-off buffers).
  * With workspace == NULL gnnpn_lstm_encode_f32 uses the per-workgroup streaming form instead.
  * After the stream has been synchronised, word 0 of the workspace (uint32) is non-zero iff a
- * bounded inter-workgroup wait timed out (outputs are then invalid). */
+ * bounded inter-workgroup wait of the LAST launch on it timed out (outputs are then invalid);
+ * gnnpn_launch_opts_t.sticky_status accumulates over launches. */
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
-/* Run-time switches (process-wide; they select among implementations of the SAME entry points):
- *   "lstm_impl"      0 auto, 1 streaming, 2 cooperative (8-CU groups)
- *   "decode_impl"    0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups),
- *                    4 cooperative (8-CU groups, 256-register build that shares a CU with another launch)
- *   "coop_lds_kb"    LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernels
- *                    launched from now on, 0 = none: placement control for two launches sharing the CUs
- *                    (100 on one stream + 56 on the other: a CU takes one workgroup of each, never two of one)
- *   "lstm_ablate"    diagnostics only (tools/): results are wrong when non-zero, except bit 7 = force the
- *                    placement-independent hand-off.
+/* Diagnostics switch (process-wide; tools/ only):
+ *   "lstm_ablate"    phase stamps / ablations of the cooperative kernels; results are WRONG when non-zero.
+ * Implementation choice and placement control are per-call arguments (gnnpn_launch_opts_t), not options.
  * Unknown names / out-of-range values: GNNPN_E_ARG. */
 int gnnpn_set_option(const char* name, int value);
 
@@ -234,7 +253,8 @@ typedef struct {
 /* precision: GNNPN_PREC_F32 or GNNPN_PREC_SPLIT (the decoder cell's W_hh.h product; cooperative, folded form). */
 int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const float* inputs,
                              float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
-                             int32_t precision, void* workspace, int64_t workspace_bytes, void* stream);
+                             int32_t precision, const gnnpn_launch_opts_t* opts, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 
 /* Workspace the cooperative decoder needs for this shape (status words, hand-off buffers, the
  * Low->High latent granules).  Word 0 after synchronisation: as for the encoder. */

@@ -32,9 +32,8 @@ for c in range(n_cfg):
     robust = robust_problems(ref["margin_low"], ref["margin_high"])
     for prec in ("f32", "split"):
         for impl in (2, 3, 4):
-            ops.set_option("decode_impl", impl)
             try:
-                out = two_level_greedy(low, high, x.to(dev), precision=prec)
+                out = two_level_greedy(low, high, x.to(dev), precision=prec, decode_impl=impl)
                 ops.check_status(dev)
                 s = assert_index_parity(out["idx_high"], ref["idx_high"], robust, "high", 0.0, x) & \
                     assert_index_parity(out["idx_low"], ref["idx_low"], robust, "low", 0.0, x)
@@ -45,8 +44,6 @@ for c in range(n_cfg):
             except Exception as e:                # noqa: BLE001
                 fails += 1
                 print(f"FAIL B={B} T={T} K={K} seeds=({sl},{sh},{sx}) precision={prec} decode_impl={impl}: {e}")
-            finally:
-                ops.set_option("decode_impl", 0)
     print(f"cfg {c}: B={B} T={T} K={K} robust {int(robust.sum())}/{B} ok", flush=True)
 print(f"{n_cfg} configs x 6 variants, {fails} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)

@@ -38,6 +38,7 @@ from oracle import data as odata            # noqa: E402
 from oracle import ml as oml                # noqa: E402
 from oracle import pn as opn                # noqa: E402
 import pyg_standin                          # noqa: E402
+from pn_inputs import pn_inputs             # noqa: E402,F401
 
 
 def import_reference():
@@ -55,22 +56,6 @@ def import_reference():
     from src.models import modelPN, modelML
     from src import loadData, ML2PN
     return modelPN, modelML, loadData, ML2PN
-
-
-def pn_inputs(B, T, K, seed, dummy_every=0):
-    """QWS-shaped PN input [B, T*K, 8]: q0,q1~U(0,1), q2,q3~U(.9,1); rows < K carry the request's
-    global constraints in cols 4..7 (loadData.py:130-133); optional dummy rows [0,1,1,1]."""
-    rng = np.random.default_rng(seed)
-    x = np.zeros((B, T * K, 8), np.float32)
-    x[:, :, 0:2] = rng.random((B, T * K, 2), dtype=np.float32)
-    x[:, :, 2:4] = 0.9 + 0.1 * rng.random((B, T * K, 2), dtype=np.float32)
-    lo = np.float32(0.9) ** np.float32(T) * np.float32(1.6)
-    x[:, :K, 4:8] = np.array([lo, 1.0, lo, 1.0], np.float32)
-    if dummy_every:
-        for c in range(0, T, dummy_every):
-            if c:
-                x[:, c * K:(c + 1) * K, 0:4] = np.array([0, 1, 1, 1], np.float32)
-    return torch.from_numpy(x)
 
 
 def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0, weight_scale=1.0):

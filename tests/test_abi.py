@@ -26,7 +26,7 @@ def test_build_and_load():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gnnpn_hip.h but not exported"
     lib.gnnpn_abi_version.restype = ctypes.c_int
-    assert lib.gnnpn_abi_version() == 1
+    assert lib.gnnpn_abi_version() == 2
 
 
 def test_binding_covers_header():
@@ -41,8 +41,10 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.gnnpn_linear_f32(None, 4, None, 4, None, None, None, 0, None, 4, 2, 2, 4, None)
     assert rc == -1 and b"null" in lib.gnnpn_last_error()
-    rc = lib.gnnpn_lstm_encode_f32(9, None, 1, 1, 256, 8, 0, None, 0, None)
+    rc = lib.gnnpn_lstm_encode_f32(9, None, 1, 1, 256, 8, 0, None, None, 0, None)
     assert rc == -1 and b"n_nets" in lib.gnnpn_last_error()
+    assert lib.gnnpn_set_option(b"decode_impl", 3) == -1        # implementation choice is a per-call argument now
+    assert b"gnnpn_launch_opts_t" in lib.gnnpn_last_error()
     rc = lib.gnnpn_rank_rows(ctypes.c_void_p(16), 40000, ctypes.c_void_p(16), 1, 40000, None)
     assert rc == -2                                     # unsupported size is reported, not truncated
 

@@ -167,19 +167,11 @@ def test_lstm_encode_cooperative_equals_streaming(dev, B, L, nets):
     whh = [ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
     bhh = [((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev) for _ in range(nets)]
     args = [{"pregates": pre[n], "whh": whh[n], "bhh": bhh[n]} for n in range(nets)]
-    try:
-        ops.set_option("lstm_impl", 1)
-        ref = ops.lstm_encode(args)
-        ops.set_option("lstm_impl", 2)      # cooperative form forced
-        out_a = ops.lstm_encode(args)
-        ops.set_option("lstm_impl", 0)      # default cooperative form: one recurrence per workgroup, 8-CU groups
-        out = ops.lstm_encode(args)
-        out2 = ops.lstm_encode(args)       # back-to-back launches reuse the hand-off buffers
-        ops.set_option("lstm_ablate", 128)  # force the placement-independent (write-through) hand-off
-        out3 = ops.lstm_encode(args)
-    finally:
-        ops.set_option("lstm_impl", 0)
-        ops.set_option("lstm_ablate", 0)
+    ref = ops.lstm_encode(args, impl=1)
+    out_a = ops.lstm_encode(args, impl=2)   # cooperative form forced
+    out = ops.lstm_encode(args)             # default cooperative form: one recurrence per workgroup, 8-CU groups
+    out2 = ops.lstm_encode(args)            # back-to-back launches reuse the hand-off buffers
+    out3 = ops.lstm_encode(args, write_through=True)   # the placement-independent (agent-scope write-through) hand-off
     ops.check_status(dev)
     for n in range(nets):
         for a, b, c, d, e in zip(ref, out, out2, out3, out_a):

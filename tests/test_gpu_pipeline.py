@@ -226,12 +226,33 @@ def test_pipelined_runner_matches_single_stream(dev):
             got.append((out["idx_high"].clone(), out["R"].clone(), out["candidate_ids"].clone()))
     runner.synchronize()
     ops.check_status(dev)
-    ops.set_option("decode_impl", runner.decode_impl)                           # the decoder form the 2-slot runner uses
-    try:
-        for b, (idx, R, ids) in zip(batches, got):
-            ref = pipe.run(svc, b)
-            assert torch.equal(ids, ref["candidate_ids"]) and torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
-    finally:
-        ops.set_option("decode_impl", 0)
+    for b, (idx, R, ids) in zip(batches, got):
+        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)                  # the decoder form the 2-slot runner uses
+        assert torch.equal(ids, ref["candidate_ids"]) and torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
     with pytest.raises(ops.GnnpnError):
         runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
+
+
+def test_all_gather_indices_rccl_world1(dev):
+    """The one collective of the path on its real backend (backend "nccl" is RCCL on ROCm), world size 1: the equal-shard
+    and the ragged form of dist.all_gather_indices on device tensors.  (World 2 runs on CPU with gloo, test_host_logic.)"""
+    import os
+    import socket
+    import torch.distributed as td
+    from gnnpn_sc_amd import dist as gdist
+    if td.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        rank, world = gdist.init_process_group("nccl", dev)
+        assert (rank, world) == (0, 1)
+        idx = torch.arange(4 * 47, dtype=torch.int32, device=dev).view(4, 47)
+        assert torch.equal(gdist.all_gather_indices(idx), idx)
+        assert torch.equal(gdist.all_gather_indices(idx, sizes=[4]), idx)
+        assert gdist.max_over_ranks(1.5, dev, 2) == 1.5          # the all-reduce(MAX) bench.py uses, forced through RCCL
+    finally:
+        if td.is_initialized():
+            td.destroy_process_group()

@@ -136,21 +136,12 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
     x[:, K:, 4:] = 0
     x = x.to(dev)
-    try:
-        ops.set_option("decode_impl", 1)
-        ref = two_level_greedy(low, high, x)
-        ops.set_option("decode_impl", 2)          # 8-CU groups
-        out8 = two_level_greedy(low, high, x)
-        ops.set_option("decode_impl", 4)          # 8-CU groups, 256-register build (K > 8: falls back to the 16-CU form)
-        out4 = two_level_greedy(low, high, x)
-        ops.set_option("decode_impl", 3)          # 16-CU groups (256 registers: co-resident with an encoder wave)
-        out = two_level_greedy(low, high, x)
-        out2 = two_level_greedy(low, high, x)
-        ops.set_option("lstm_ablate", 128)      # force the placement-independent (write-through) hand-off
-        out3 = two_level_greedy(low, high, x)
-    finally:
-        ops.set_option("decode_impl", 0)
-        ops.set_option("lstm_ablate", 0)
+    ref = two_level_greedy(low, high, x, decode_impl=1)
+    out8 = two_level_greedy(low, high, x, decode_impl=2)    # 8-CU groups
+    out4 = two_level_greedy(low, high, x, decode_impl=4)    # 8-CU groups, 256-register build (K > 8: falls back to the 16-CU form)
+    out = two_level_greedy(low, high, x, decode_impl=3)     # 16-CU groups (256 registers: co-resident with an encoder wave)
+    out2 = two_level_greedy(low, high, x, decode_impl=3)
+    out3 = two_level_greedy(low, high, x, decode_impl=3, write_through=True)   # the placement-independent hand-off
     ops.check_status(dev)
     for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions", "action_probs"):
         assert torch.equal(out[k], out2[k]), k                    # deterministic across launches
@@ -217,23 +208,19 @@ def test_saturated_logits_first_max_wins(dev):
         nets.append(m.to(dev).eval())
     x = torch.from_numpy(fx["inputs"]).to(dev)
     ties_checked = 0
-    try:
-        for impl in (1, 2, 3):
-            ops.set_option("decode_impl", impl)
-            out = two_level_greedy(nets[0], nets[1], x, fold=False)    # literal two-stage order: closest to the fixture
-            got_low, win = out["idx_low"].cpu().numpy(), out["win_low"].cpu().numpy()
-            for b in range(x.shape[0]):
-                for t in range(T):
-                    if (got_low[b, :t] != fx["idx_low"][b, :t]).any():
-                        break                                           # history diverged: later steps not comparable
-                    w_ref, w_got = fx["win_low"][b, t], win[b, t]
-                    top = w_ref.max()
-                    if (w_ref == top).sum() >= 2 and (w_got == w_got.max()).sum() >= 2 and \
-                            np.array_equal(w_got == w_got.max(), w_ref == top):
-                        assert got_low[b, t] == fx["idx_low"][b, t] == t * K + int(np.argmax(w_ref == top))
-                        ties_checked += 1
-    finally:
-        ops.set_option("decode_impl", 0)
+    for impl in (1, 2, 3):
+        out = two_level_greedy(nets[0], nets[1], x, fold=False, decode_impl=impl)   # literal two-stage order: closest to the fixture
+        got_low, win = out["idx_low"].cpu().numpy(), out["win_low"].cpu().numpy()
+        for b in range(x.shape[0]):
+            for t in range(T):
+                if (got_low[b, :t] != fx["idx_low"][b, :t]).any():
+                    break                                           # history diverged: later steps not comparable
+                w_ref, w_got = fx["win_low"][b, t], win[b, t]
+                top = w_ref.max()
+                if (w_ref == top).sum() >= 2 and (w_got == w_got.max()).sum() >= 2 and \
+                        np.array_equal(w_got == w_got.max(), w_ref == top):
+                    assert got_low[b, t] == fx["idx_low"][b, t] == t * K + int(np.argmax(w_ref == top))
+                    ties_checked += 1
     assert ties_checked >= 3, f"only {ties_checked} exact ties were comparable"
 
 
@@ -328,13 +315,7 @@ def test_split_precision_ragged_shapes(dev, B, T, K):
     x[:, K:, 4:] = 0
     x = x.to(dev)
     ref = two_level_greedy(low, high, x)
-    outs = []
-    try:
-        for impl in (2, 3, 3, 4):
-            ops.set_option("decode_impl", impl)
-            outs.append(two_level_greedy(low, high, x, precision="split"))
-    finally:
-        ops.set_option("decode_impl", 0)
+    outs = [two_level_greedy(low, high, x, precision="split", decode_impl=impl) for impl in (2, 3, 3, 4)]
     ops.check_status(dev)
     for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions"):
         assert torch.equal(outs[1][k], outs[2][k]), k

@@ -152,3 +152,24 @@ def test_woa_objective_known_answers():
     u = [s.uniform() for _ in range(1000)]
     assert 0.0 <= min(u) and max(u) < 1.0 and abs(sum(u) / 1000 - 0.5) < 0.05 and s.count == 1000
     assert [owoa.DrawStream(7).below(10) for _ in range(3)] == [int(u[0] * 10)] * 3     # pure function of (seed, k)
+
+
+@pytest.mark.parametrize("name", ["qws512", "normal1024"])
+def test_pn_oracle_reproduces_reference_at_baseline_shape(name):
+    """The BASELINE-size fixtures (tests/golden/make_golden_big.py: the real modelPN.py at QWS / Normal shape, inputs
+    and weights regenerated from seeds): the oracle on the first chunk of 128 problems, whatever the thread count —
+    identical picks up to the first fragile decision of every problem (tests/parity.py::prefix_parity)."""
+    from parity import assert_R_parity, prefix_parity
+    from pn_inputs import pn_inputs_chunked
+    fx = golden(f"pn_big_{name}.npz")
+    T, K, n = int(fx["n_cat"]), int(fx["n_per"]), 128 if name == "qws512" else 32
+    x = pn_inputs_chunked(int(fx["B"]), T, K, int(fx["seed_inputs"]), int(fx["chunk"]))[:n]
+    out = opn.two_level_greedy(opn.make_state_dict(256, int(fx["seed_low"])), opn.make_state_dict(256, int(fx["seed_high"])),
+                               x, T, K)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], {k: fx[k][:n] for k in ("idx_low", "idx_high", "margin_low", "margin_high")},
+                        name, x)
+    assert rec["robust_identical"] == rec["robust_problems"] > 0
+    assert_R_parity(out["R"], fx["R"][:n], name, rec["same_mask"])
+    nw = min(n, fx["win_low"].shape[0])
+    m = rec["same_mask"][:nw]
+    assert np.allclose(out["win_low"].numpy()[:nw][m], fx["win_low"][:nw][m], rtol=0, atol=2e-5)

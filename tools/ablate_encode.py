@@ -43,7 +43,7 @@ ops.set_option("lstm_ablate", 0)
 # phase stamps (diagnostic build path: lstm_ablate bit 5)
 ops.set_option("lstm_ablate", 32)
 ops.lstm_encode(nets); torch.cuda.synchronize()
-ws = ops.encode_workspace(dev)
+ws = ops.workspaces(dev).encode()
 prof = ws[32:32 + 56].view(torch.int64).cpu().tolist()
 n = max(prof[5], 1)
 print("flush + input prefetch part of the MFMA phase:", round(prof[6] / n))
@@ -54,7 +54,12 @@ ops.set_option("lstm_ablate", 0)
 
 ops.set_option("lstm_ablate", 0)
 ops.lstm_encode(nets); torch.cuda.synchronize()
-ws = ops.encode_workspace(dev)
+ws = ops.workspaces(dev).encode()
 print("status", int(ws[:4].view(torch.int32).item()), "workgroups on the same-XCD fast path:", int(ws[4:8].view(torch.int32).item()))
-timeit("write-through hand-off forced", 128)
-ops.set_option("lstm_ablate", 0)
+for _ in range(3): ops.lstm_encode(nets, write_through=True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): ops.lstm_encode(nets, write_through=True)
+e1.record(); torch.cuda.synchronize()
+print(f"write-through hand-off forced: {e0.elapsed_time(e1) / 10:.3f} ms")

@@ -17,9 +17,7 @@ n_var = 12
 batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, w["B"], seed=100 + i, tasks_per_problem=w["n_t"]), dev)
            for i in range(n_var)]
 runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
-ops.set_option("decode_impl", runner.decode_impl)
-refs = [pipe.run(svc, b) for b in batches]           # single stream, same kernels
-ops.set_option("decode_impl", 0)
+refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]           # single stream, same kernels
 torch.cuda.synchronize()
 keys = ("idx_low", "idx_high", "R", "actions", "win_low", "win_high_raw")
 bad, t0 = 0, time.time()

@@ -12,7 +12,7 @@ x = torch.rand(B, T * K, 8, generator=g).to(dev)
 for _ in range(3): two_level_greedy(low, high, x)
 ops.set_option("lstm_ablate", 32)
 two_level_greedy(low, high, x); torch.cuda.synchronize()
-ws = ops.decode_workspace(dev, B, T, K)
+ws = ops.workspaces(dev).decode(B, T, K)
 prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
 n = max(prof[7], 1)
 names = ["sweep+fill", "logits/argmax (3 barriers)", "W_hh.h MFMA", "x embed->LDS", "W_ih.x MFMA", "cell+publish h", "partial dots"]
