@@ -85,14 +85,23 @@ def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=
             if lo + b >= n_train:
                 for t in range(T):
                     actions[t].append(act[b, t].tolist())
+    return write_artifacts(dataset, epoch, rankings, actions)
+
+
+def artifact_paths(dataset, epoch):
+    """Where ``loadDataPN`` / ``check`` look (loadData.py:84-89, ML2PN.py:25-28): epoch -1 -> ./solutions/pretrained/."""
     if epoch == -1:
-        os.makedirs("./solutions/pretrained", exist_ok=True)
-        p_rank, p_act = f"./solutions/pretrained/{dataset}-ML.txt", f"./solutions/pretrained/{dataset}-PNHigh.txt"
-    else:
-        os.makedirs(f"./solutions/ML/{dataset}", exist_ok=True)
-        os.makedirs(f"./solutions/PNHigh/{dataset}", exist_ok=True)
-        p_rank = f"./solutions/ML/{dataset}/testServices-epoch{epoch}.txt"
-        p_act = f"./solutions/PNHigh/{dataset}/allActions{epoch}.txt"
+        return f"./solutions/pretrained/{dataset}-ML.txt", f"./solutions/pretrained/{dataset}-PNHigh.txt"
+    return f"./solutions/ML/{dataset}/testServices-epoch{epoch}.txt", f"./solutions/PNHigh/{dataset}/allActions{epoch}.txt"
+
+
+def write_artifacts(dataset, epoch, rankings, actions):
+    """The two artefacts of an ML+2PN run in the reference's formats: rankings [P][S] ints as TrainML.start dumps them
+    (trainML.py:146-149) and the High-level actions [T][nTest][8] floats as the PNHigh eval block dumps them
+    (trainPNHigh.py:133-144)."""
+    p_rank, p_act = artifact_paths(dataset, epoch)
+    for p in (p_rank, p_act):
+        os.makedirs(os.path.dirname(p), exist_ok=True)
     with open(p_rank, "w") as f:
         json.dump(rankings, f)
     with open(p_act, "w") as f:

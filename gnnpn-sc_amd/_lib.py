@@ -26,6 +26,8 @@ _SIGNATURES = {
                                         c_int32, _P]),
     "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,
+                                         _P, _P, _P, _P]),
     "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "gnnpn_rank_rows": (c_int, [_P, c_int64, _P, c_int32, c_int32, _P]),
     "gnnpn_precision_at_k": (c_int, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int32, _P, _P]),
@@ -55,6 +57,12 @@ class LaunchOpts(ctypes.Structure):
     """gnnpn_launch_opts_t of include/gnnpn_hip.h (per-call implementation choice / placement / sticky status)."""
     _fields_ = [("impl", c_int32), ("lds_kb", c_int32), ("write_through", c_int32), ("reserved", c_int32),
                 ("sticky_status", _P)]
+
+
+class GinLayer(ctypes.Structure):
+    """gnnpn_gin_layer_t of include/gnnpn_hip.h."""
+    _fields_ = [(n, _P) for n in ("w0_packed", "b0", "bn1_scale", "bn1_shift", "w3_packed", "b3", "bn2_scale", "bn2_shift",
+                                  "eps")]
 
 
 class EncodeNet(ctypes.Structure):

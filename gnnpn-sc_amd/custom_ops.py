@@ -5,6 +5,7 @@ calling an operator with host tensors fails in the dispatcher ("Could not run 'g
 'CPU' backend"), and a missing library raises ``GnnpnError`` — never a silent fallback.
 
     torch.ops.gnnpn.linear / embed_concat / csr_aggregate / gcn_norm / segment_mean
+    torch.ops.gnnpn.request_branch             (the whole GIN branch of small workflow graphs in one launch)
     torch.ops.gnnpn.segment_topk_feasible      (candidate reduction: sort + loadDataPN + SCDataset)
     torch.ops.gnnpn.rank_rows / precision_at_k
     torch.ops.gnnpn.lstm_encode                (n nets in one launch)
@@ -46,6 +47,14 @@ _op("csr_aggregate(Tensor rowptr, Tensor col, Tensor? w, Tensor x, Tensor? self_
     "Tensor? scale=None, Tensor? shift=None, int act=0) -> Tensor",
     lambda rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0:
     ops.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act))
+def _request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layer_tensors, lin_w_packed, lin_b, hidden):
+    keys = ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")
+    layers = [dict(zip(keys, layer_tensors[i:i + len(keys)])) for i in range(0, len(layer_tensors), len(keys))]
+    return ops.request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layers, lin_w_packed, lin_b, hidden)
+
+
+_op("request_branch(Tensor x, Tensor table, Tensor rowptr, Tensor col, Tensor seg_ptr, int max_nodes, "
+    "Tensor[] layer_tensors, Tensor lin_w_packed, Tensor lin_b, int hidden) -> Tensor", _request_branch)
 _op("gcn_norm(Tensor rowptr, Tensor col, Tensor w_raw) -> Tensor", ops.gcn_norm)
 _op("segment_mean(Tensor segptr, Tensor x) -> Tensor", ops.segment_mean)
 _op("segment_topk_feasible(Tensor scores, Tensor cat_ptr, Tensor qos, Tensor local_bounds, Tensor present, "

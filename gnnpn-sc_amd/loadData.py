@@ -142,6 +142,9 @@ def tables_from_dataset(ds, first=0, last=None):
         local.append(lo)
         present.append(pr)
         glob.append(gl)
+    if not nodes_all:          # the service table alone (first == last)
+        return table, ProblemBatch(np.zeros((0, 7), np.float32), np.zeros((2, 0), np.int64), np.zeros(0, np.int64),
+                                   np.zeros((0, T, 4)), np.zeros((0, T), np.uint8), np.zeros((0, 4)))
     pb = ProblemBatch(np.asarray(xs, dtype=np.float32), np.concatenate(eis_w, 1) if eis_w else np.zeros((2, 0), np.int64),
                       np.asarray(batch, dtype=np.int64), np.stack(local), np.stack(present), np.stack(glob))
     return table, pb

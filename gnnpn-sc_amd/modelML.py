@@ -9,10 +9,10 @@ libgnnpn_hip.so:
   GCN  (service graph)  : gcn_norm -> linear (X.W, transform first) -> csr_aggregate(+bias,BN,ReLU)
   head                  : linear, segment_mean, linear(score) + sigmoid
 
-Service-branch semantics: the service embedding is problem independent
-and is computed ONCE per forward from the first ``outChannels`` rows of ``data.x_service`` — the
-reference's B-fold replication inside a PyG batch (modelML.py:145-156,167-172) averages B copies
-of the same thing.
+Service-branch semantics: ``Net.forward(data)`` does what the reference's forward does on
+whatever the batched ``data`` holds (GCN over all copies, mean over copies: modelML.py:145-156,167-172); the device
+pipeline (``pipeline.ML2PNPipeline``) evaluates the branch on ONE copy of the table — the problem-independent
+embedding — once per (weights, table).
 """
 import os
 
@@ -107,6 +107,7 @@ class Net(nn.Module):
         self.noServicesLins = nn.ModuleList(                                       # :108-115 (state_dict parity)
             nn.Linear(c + self.qosNumber if i == 0 else 2 * h, 2 * h) for i in range(numLayersGCN))
         self._prep = None
+        self.fuse_request_branch = os.environ.get("GNNPN_LAYERED_GIN") != "1"   # one-launch GIN branch for small workflow graphs
         self.parallel_branches = os.environ.get("GNNPN_SERIAL_BRANCHES") != "1"   # scores(): GCN branch on a side stream
         self._side_streams = {}
 
@@ -149,21 +150,37 @@ class Net(nn.Module):
             p["gin"].append({"eps": f(conv.eps), "w0": f(conv.nn[0].weight), "b0": f(conv.nn[0].bias),
                              "a1": a1.to(device), "s1": b1.to(device), "w3": f(conv.nn[3].weight),
                              "b3": f(conv.nn[3].bias), "a2": a2.to(device), "s2": b2.to(device)})
+            if conv.nn[3].weight.shape[0] % 16 == 0:      # MFMA B-fragment layout for the one-launch GIN branch
+                p["gin"][-1].update(w0p=ops.pack_mfma_b(p["gin"][-1]["w0"]), w3p=ops.pack_mfma_b(p["gin"][-1]["w3"]))
         for conv, bn in zip(self.serviceConvs, self.serviceBatchNorms):
             a, b = _bn_affine(bn)
             p["gcn"].append({"wt": f(conv.weight.detach().t()), "bias": f(conv.bias), "a": a.to(device),
                              "s": b.to(device)})
         p["nodeLin"] = (f(self.nodeLin.weight), f(self.nodeLin.bias))
+        if self.nodeLin.weight.shape[0] % 16 == 0:
+            p["nodeLin_p"] = ops.pack_mfma_b(p["nodeLin"][0])
         p["serviceLin"] = (f(self.serviceLin.weight), f(self.serviceLin.bias))
         self._prep = p
         return p
 
     # ---- the two branches + head, on kernel-ready inputs ---------------------------------------
     @torch.no_grad()
-    def request_embedding(self, x, wf_csr, seg_ptr):
+    def fused_request_branch_ok(self, x, max_nodes):
+        """Shapes gnnpn_request_branch_f32 is built for (else the separate kernels; same bits either way)."""
+        h = self.nodeLin.weight.shape[0]
+        return (self.fuse_request_branch and 0 < max_nodes <= ops.REQUEST_BRANCH_MAX_NODES and h == 128 and
+                self.numLayersGIN <= 4 and self.reqAndServiceChannels + x.shape[1] - 1 <= 32)
+
+    @torch.no_grad()
+    def request_embedding(self, x, wf_csr, seg_ptr, max_nodes=0):
         """Workflow branch (modelML.py:133-143,165-166): x [N,7], CSR of the batched workflow graphs,
-        graph segment pointer -> [B, hidden]."""
+        graph segment pointer -> [B, hidden].  ``max_nodes`` > 0 promises that every graph has at most that many nodes
+        and that every edge stays inside its graph: up to 16 the whole branch then runs as ONE launch."""
         p = self.prepared(x.device)
+        if self.fused_request_branch_ok(x, max_nodes):
+            flat = [lp[k] for lp in p["gin"] for k in ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")]
+            return torch.ops.gnnpn.request_branch(x, p["node_table"], wf_csr.rowptr, wf_csr.col, seg_ptr, int(max_nodes),
+                                                  flat, p["nodeLin_p"], p["nodeLin"][1], 128)
         h = torch.ops.gnnpn.embed_concat(x, p["node_table"])                                               # :134-137
         for lp in p["gin"]:                                                                     # :139-142
             agg = torch.ops.gnnpn.csr_aggregate(wf_csr.rowptr, wf_csr.col, None, h, self_coef=lp["eps"])
@@ -186,17 +203,17 @@ class Net(nn.Module):
         return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                                 # :164
 
     @torch.no_grad()
-    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr, service_emb=None):
+    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr, service_emb=None, max_nodes=0):
         """The two branches are independent until the score product: the service branch (GCN) is forked onto
         a side stream and joined before the GEMM, so ~20 small launch-latency-bound kernels run two abreast
         (fork/join is stream-capturable: inside a HIP graph it becomes two parallel branches).
         ``service_emb`` [S, hidden]: the service branch's result computed earlier (it depends on the weights and the
         service table only — pipeline.ML2PNPipeline caches it per (weights, table)); the branch is then skipped."""
         if service_emb is not None:
-            xr = self.request_embedding(x, wf_csr, seg_ptr)
+            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
             return torch.ops.gnnpn.linear(xr, service_emb, act=ACT_SIGMOID)                                 # :173-176
         if not self.parallel_branches:
-            xr = self.request_embedding(x, wf_csr, seg_ptr)
+            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
             xs = self.service_embedding(x_service, svc_csr)
             return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                          # :173-176
         cur = torch.cuda.current_stream(x.device)
@@ -206,7 +223,7 @@ class Net(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             xs = self.service_embedding(x_service, svc_csr)
-        xr = self.request_embedding(x, wf_csr, seg_ptr)
+        xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
         cur.wait_stream(side)
         xs.record_stream(cur)
         return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176
@@ -214,7 +231,14 @@ class Net(nn.Module):
     def forward(self, data):
         """Net.forward (modelML.py:131-176) on a PyG-style ``data`` object with attributes x,
         edge_index, batch, x_service, edge_index_service, edge_attr_service (device tensors).
-        The CSR layouts are cached on ``data`` (``_gnnpn_csr``) so repeated forwards skip the sort."""
+        The CSR layouts are cached on ``data`` (``_gnnpn_csr``) so repeated forwards skip the sort.
+
+        Service branch, exactly as the reference evaluates it: the GCN layers run over ALL rows of ``x_service`` with
+        ``edge_index_service`` AS GIVEN — a batch of B graphs carries B concatenated copies of the service table
+        (trainML.py:109-114) and whatever index offsets the batching gave copy b's edges (torch_geometric 1.7.0 shifts
+        them by the workflow node counts, see oracle/ml.py) — and ``scatter(.., serviceBatch, reduce='mean')``
+        (:167-172) then averages row s of every copy.  No layout is assumed and nothing is masked away.  With ONE copy
+        (``x_service`` has outChannels rows) this is the problem-independent embedding the device pipeline caches."""
         if self.training:
             raise NotImplementedError("training mode: this build is the inference path only")
         x = data.x.squeeze().float().contiguous()
@@ -222,16 +246,31 @@ class Net(nn.Module):
         if cache is None:
             S = self.outChannels
             n_graphs = int(data.batch.max().item()) + 1
-            ei_s, ea_s = data.edge_index_service, data.edge_attr_service
-            if data.x_service.shape[0] > S:                      # B replicated copies: keep copy 0
-                m = (ei_s[0] < S) & (ei_s[1] < S)
-                ei_s, ea_s = ei_s[:, m], ea_s[m]
+            xs = data.x_service.squeeze().float().contiguous()
+            n_svc = xs.shape[0]
+            if n_svc != S and n_svc != n_graphs * S:      # the reference's scatter would fail on the size mismatch (:167-172)
+                raise ValueError(f"x_service has {n_svc} rows: expected outChannels = {S} (one copy) or one copy per "
+                                 f"graph = {n_graphs * S}")
+            copies = n_svc // S
+            b = data.batch.long()
+            inside = bool((b[data.edge_index[0].long()] == b[data.edge_index[1].long()]).all().item()) if data.edge_index.numel() else True
             cache = {"wf": graph.csr_by_destination(data.edge_index, x.shape[0]),
                      "seg": graph.segment_ptr(data.batch, n_graphs),
-                     "svc": graph.gcn_csr(ei_s, ea_s, S),
-                     "xs": data.x_service.squeeze()[:S].float().contiguous()}
+                     "svc": graph.gcn_csr(data.edge_index_service, data.edge_attr_service, n_svc),
+                     "xs": xs, "copies": copies,
+                     "max_nodes": int(torch.bincount(b).max().item()) if inside else 0}
+            if copies > 1:    # rows (s, S+s, 2S+s, ...) as one CSR row: csr_aggregate sums them in copy order = scatter order
+                dev = xs.device
+                cache["mean_rowptr"] = (torch.arange(S + 1, device=dev, dtype=torch.int32) * copies).contiguous()
+                cache["mean_col"] = (torch.arange(S, device=dev, dtype=torch.int32).view(S, 1) +
+                                     S * torch.arange(copies, device=dev, dtype=torch.int32).view(1, copies)).reshape(-1).contiguous()
             try:
                 data._gnnpn_csr = cache
             except AttributeError:
                 pass
-        return self.scores(x, cache["wf"], cache["seg"], cache["xs"], cache["svc"])
+        if cache["copies"] == 1:
+            return self.scores(x, cache["wf"], cache["seg"], cache["xs"], cache["svc"], max_nodes=cache["max_nodes"])
+        emb_all = self.service_embedding(cache["xs"], cache["svc"])                            # :145-156,164
+        total = torch.ops.gnnpn.csr_aggregate(cache["mean_rowptr"], cache["mean_col"], None, emb_all)
+        emb = total / float(cache["copies"])                                                    # :172 (sum / count)
+        return self.scores(x, cache["wf"], cache["seg"], None, None, service_emb=emb, max_nodes=cache["max_nodes"])

@@ -79,6 +79,46 @@ def segment_mean(segptr, x):
     return out
 
 
+def pack_mfma_b(w):
+    """[N, K] weight (rows = output features) -> v_mfma_f32_16x16x4_f32 B-fragments [N/16, K16, 64, 4]:
+    packed[t][k16][lane][j] = w[16t + lane%16][16*k16 + 4j + lane//16], K zero-padded to a multiple of 16.
+    A one-time layout change at weight-load time (no arithmetic)."""
+    N, K = w.shape
+    if N % 16:
+        raise GnnpnError(f"pack_mfma_b: output features {N} must be a multiple of 16")
+    Kp = (K + 15) // 16 * 16
+    wp = torch.zeros((N, Kp), dtype=w.dtype, device=w.device)
+    wp[:, :K] = w
+    v = wp.view(N // 16, 16, Kp // 16, 4, 4)              # [t, c, k16, j, kq]
+    return v.permute(0, 2, 4, 1, 3).reshape(N // 16, Kp // 16, 64, 4).contiguous()   # [t, k16, (kq, c), j]
+
+
+REQUEST_BRANCH_MAX_NODES = 16
+
+
+def request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layers, lin_w_packed, lin_b, hidden):
+    """The whole GIN branch in one launch (gnnpn_request_branch_f32): x [N,1+f] node rows, CSR of the batched workflow
+    graphs (every edge inside its graph, at most 16 nodes per graph) -> [B, hidden].  ``layers``: list of dicts with
+    w0p, b0, a1, s1, w3p, b3, a2, s2 (packed weights: pack_mfma_b; BN folded) and eps.  Raises GnnpnError for shapes
+    the fused kernel is not built for (callers fall back to the separate kernels)."""
+    x = _rows2d(x, "request_branch.x")
+    vocab, emb = table.shape
+    B = seg_ptr.numel() - 1
+    out = torch.empty((B, hidden), dtype=F32, device=x.device)
+    arr = (_lib.GinLayer * len(layers))()
+    for i, lp in enumerate(layers):
+        a = arr[i]
+        for field, key in (("w0_packed", "w0p"), ("b0", "b0"), ("bn1_scale", "a1"), ("bn1_shift", "s1"), ("w3_packed", "w3p"),
+                           ("b3", "b3"), ("bn2_scale", "a2"), ("bn2_shift", "s2"), ("eps", "eps")):
+            setattr(a, field, dev_ptr(lp[key], F32, f"layers[{i}].{key}").value)
+    check(_lib.load().gnnpn_request_branch_f32(
+        dev_ptr(x, F32, "x"), x.shape[1] - 1, dev_ptr(table, F32, "table"), vocab, emb, dev_ptr(rowptr, I32, "rowptr"),
+        dev_ptr(col, I32, "col"), dev_ptr(seg_ptr, I32, "seg_ptr"), B, int(max_nodes), len(layers), arr, int(hidden),
+        dev_ptr(lin_w_packed, F32, "lin_w_packed"), dev_ptr(lin_b, F32, "lin_b"), dev_ptr(out, F32, "out"), stream_ptr()),
+        "gnnpn_request_branch_f32")
+    return out
+
+
 def select_candidates(scores, cat_ptr, qos, local_bounds, present, global_bounds, n_per):
     """Per (problem, category) top-``n_per`` feasible services -> (rows [B,L,8] fp32, ids [B,L] int32)."""
     scores = _rows2d(scores, "select.scores")

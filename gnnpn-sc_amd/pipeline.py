@@ -48,6 +48,8 @@ class DeviceBatch:
     local_bounds: torch.Tensor   # f64 [B,T,4]
     present: torch.Tensor        # u8  [B,T]
     global_bounds: torch.Tensor  # f64 [B,4]
+    max_nodes: int = 0           # > 0: every workflow graph has at most this many nodes AND every edge stays inside its
+    #                              graph (host-checked when the batch was packed) -> the one-launch GIN branch may be used
 
     @property
     def n_problems(self):
@@ -58,11 +60,13 @@ class DeviceBatch:
         ei = torch.from_numpy(np.ascontiguousarray(pb.edge_index))
         batch = torch.from_numpy(np.ascontiguousarray(pb.batch))
         n = pb.x.shape[0]
+        inside = bool((pb.batch[pb.edge_index[0]] == pb.batch[pb.edge_index[1]]).all()) if pb.edge_index.size else True
+        max_nodes = int(np.bincount(pb.batch, minlength=1).max()) if inside and n else 0
         return DeviceBatch(torch.from_numpy(pb.x).to(device), graph.csr_by_destination(ei, n).to(device),
                            graph.segment_ptr(batch, pb.n_problems).to(device),
                            torch.from_numpy(np.ascontiguousarray(pb.local_bounds)).to(device),
                            torch.from_numpy(np.ascontiguousarray(pb.present)).to(device),
-                           torch.from_numpy(np.ascontiguousarray(pb.global_bounds)).to(device))
+                           torch.from_numpy(np.ascontiguousarray(pb.global_bounds)).to(device), max_nodes)
 
     def shard(self, rank, world):
         """Contiguous shard of the problems for one rank (dist.py); graphs stay whole."""
@@ -76,7 +80,7 @@ class DeviceBatch:
         csr = graph.CSR((rp[n0:n1 + 1] - e0).to(dev), (self.wf_csr.col[e0:e1] - n0).contiguous(), None, n1 - n0)
         return DeviceBatch(self.x[n0:n1].contiguous(), csr, (seg[lo:hi + 1] - n0).to(dev),
                            self.local_bounds[lo:hi].contiguous(), self.present[lo:hi].contiguous(),
-                           self.global_bounds[lo:hi].contiguous())
+                           self.global_bounds[lo:hi].contiguous(), self.max_nodes)
 
 
 class ML2PNPipeline:
@@ -103,7 +107,8 @@ class ML2PNPipeline:
     def scores(self, services, batch):
         """TrainML.test's forward (trainML.py:56-58)."""
         return self.net.scores(batch.x, batch.wf_csr, batch.seg_ptr, services.x_service, services.csr,
-                               service_emb=self.service_embedding(services) if self.cache_service_embedding else None)
+                               service_emb=self.service_embedding(services) if self.cache_service_embedding else None,
+                               max_nodes=batch.max_nodes)
 
     @torch.no_grad()
     def candidates(self, services, batch, scores):
@@ -197,7 +202,7 @@ class PipelinedRunner:
     def _clone(b):
         c = graph.CSR(b.wf_csr.rowptr.clone(), b.wf_csr.col.clone(), None, b.wf_csr.n)
         return DeviceBatch(b.x.clone(), c, b.seg_ptr.clone(), b.local_bounds.clone(), b.present.clone(),
-                           b.global_bounds.clone())
+                           b.global_bounds.clone(), b.max_nodes)
 
     def submit(self, batch=None):
         """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
@@ -207,6 +212,10 @@ class PipelinedRunner:
         with torch.cuda.stream(self.streams[s]):
             if batch is not None:
                 dst = self.batches[s]
+                lim = ops.REQUEST_BRANCH_MAX_NODES        # the captured graph holds the one-launch GIN branch (small
+                if 0 < dst.max_nodes <= lim and not 0 < batch.max_nodes <= lim:   # workflow graphs) or the layered kernels
+                    raise ops.GnnpnError(f"PipelinedRunner: the captured graph holds the one-launch GIN branch (graphs of <= "
+                                         f"{lim} nodes); this batch has max_nodes = {batch.max_nodes}")
                 for a, b in ((dst.x, batch.x), (dst.wf_csr.rowptr, batch.wf_csr.rowptr), (dst.wf_csr.col, batch.wf_csr.col),
                              (dst.seg_ptr, batch.seg_ptr), (dst.local_bounds, batch.local_bounds),
                              (dst.present, batch.present), (dst.global_bounds, batch.global_bounds)):

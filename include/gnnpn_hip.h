@@ -87,6 +87,37 @@ int gnnpn_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, const float* w
 int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, float* out,
                            int64_t ldo, int32_t n_seg, int32_t C, void* stream);
 
+/* The whole workflow (GIN) branch of Net.forward in ONE launch, for batches whose workflow graphs have at most 16 nodes
+ * (QWS / Normal requests: <= 11): embedding lookup + concat, n_layers x {GIN aggregate, Linear+BN+ReLU, Linear+BN+ReLU},
+ * nodeLin, mean over each graph's nodes; node features stay in LDS between the stages.  Stage for stage the arithmetic of
+ * gnnpn_embed_concat_f32 / gnnpn_csr_aggregate_f32 / gnnpn_linear_f32 / gnnpn_segment_mean_f32, so the result is
+ * bit-identical to calling those in sequence.
+ *   x [N, 1+nfeat], table [vocab, emb]; rowptr/col: destination-major CSR of the batched workflow graphs, every edge
+ *   inside its graph; seg_ptr [n_graphs+1]; max_nodes = the largest graph (host value);
+ *   per layer (gnnpn_gin_layer_t): weights as v_mfma_f32_16x16x4_f32 B-fragments, packed[t][k16][lane][j] =
+ *   W[16t + lane%16][16*k16 + 4j + lane/16] with K zero-padded to a multiple of 16 (ops.pack_mfma_b: layout only);
+ *   bias, BN folded to scale/shift as for gnnpn_linear_f32; eps: one device float.
+ *   out [n_graphs, hidden].
+ * GNNPN_E_UNSUP (nothing enqueued) unless hidden == 128, n_layers <= 4, emb + nfeat <= 32 and max_nodes <= 16: callers
+ * then use the separate kernels.
+ * Replaces: src/models/modelML.py:133-143,165-166 (NodeEncoder, GINConv x numLayersGIN with BatchNorm/ReLU, nodeLin,
+ * scatter mean). */
+typedef struct {
+    const float* w0_packed;   /* Linear(in -> 2*hidden) of the GIN MLP (modelML.py:77-90) */
+    const float* b0;
+    const float* bn1_scale;
+    const float* bn1_shift;
+    const float* w3_packed;   /* Linear(2*hidden -> hidden) */
+    const float* b3;
+    const float* bn2_scale;   /* nodeBatchNorms[i] (modelML.py:141) */
+    const float* bn2_shift;
+    const float* eps;
+} gnnpn_gin_layer_t;
+int gnnpn_request_branch_f32(const float* x, int32_t nfeat, const float* table, int32_t vocab, int32_t emb,
+                             const int32_t* rowptr, const int32_t* col, const int32_t* seg_ptr, int32_t n_graphs,
+                             int32_t max_nodes, int32_t n_layers, const gnnpn_gin_layer_t* layers, int32_t hidden,
+                             const float* lin_w_packed, const float* lin_b, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Candidate reduction: for every (problem b, category c) choose the n_per best-scored services
  * of that category that satisfy the problem's local bounds, best first (score descending, ties

@@ -9,10 +9,17 @@ sigmoid; modelML.py:131-176) is run unmodified by tests/golden/make_golden.py an
 are absent from /root/reference and from this image; their arithmetic below restates the
 published algorithm  => **parity unpinned** at that boundary.
 
-Service-branch semantics: the service graph / service embedding is problem independent.  The
-oracle evaluates it ONCE per forward (= the reference's behaviour at batch size 1); the
-reference's B-fold replication of the service graph inside a PyG batch (modelML.py:145-156,
-167-172) averages B copies of the same thing and is not reproduced.
+Service-branch semantics, two forms:
+* ``net_forward``: the service graph / service embedding is problem independent and is evaluated ONCE (what the
+  device pipeline does; the mathematically intended model);
+* ``net_forward_batched``: the reference's forward LITERALLY on whatever a batched ``data`` object holds — the GCN runs
+  over all ``x_service`` rows (B concatenated copies of the table, trainML.py:109-114) with ``edge_index_service`` as
+  the batching produced it, then ``scatter(..., serviceBatch, reduce='mean')`` averages row s of every copy
+  (modelML.py:145-156,164,167-172).  ``pyg_batch_service_edges`` builds the edge list the way torch_geometric 1.7.0's
+  ``Batch.from_data_list`` would: ``Data.__inc__`` offsets every key containing "index" by ``data.num_nodes`` — the
+  WORKFLOW node count x.size(0), not S — so copy b's service edges are shifted by the number of workflow nodes of the
+  graphs before it and land (mostly) among copy 0's rows.  [From memory of the 1.7.0 source; the package is not in
+  this image, so this too is "parity unpinned".]
 """
 import math
 from types import SimpleNamespace
@@ -164,6 +171,26 @@ def net_forward(sd, data, n_gin, n_gcn):
     xr = request_embedding(sd, data.x, data.edge_index, data.batch, n_graphs, n_gin)
     xs = service_embedding(sd, data.x_service, data.edge_index_service, data.edge_attr_service, n_gcn)
     return torch.sigmoid(torch.matmul(xr, xs.t()))                                          # :173-176
+
+
+def pyg_batch_service_edges(edge_index_service, edge_attr_service, offsets):
+    """The batched ``edge_index_service`` / ``edge_attr_service`` of B graphs that each carry the same service graph
+    (trainML.py:109-114): copy b's edges shifted by ``offsets[b]``.
+    torch_geometric 1.7.0 (``Data.__inc__`` -> ``num_nodes`` = ``x.size(0)``, see the module docstring): offsets =
+    cumulative WORKFLOW node counts [0, N_0, N_0+N_1, ...];  B clean block-diagonal replicas: offsets = [0, S, 2S, ...]."""
+    return (torch.cat([edge_index_service + int(o) for o in offsets], 1), edge_attr_service.repeat(len(offsets)))
+
+
+@torch.no_grad()
+def net_forward_batched(sd, data, n_gin, n_gcn, S):
+    """Net.forward (modelML.py:131-176) literally on a batched ``data``: x_service [B*S,5] (B copies), edge_index_service /
+    edge_attr_service as the batching left them -> sigmoid scores [B,S]."""
+    n_graphs = int(data.batch.max()) + 1
+    xr = request_embedding(sd, data.x, data.edge_index, data.batch, n_graphs, n_gin)
+    xs = service_embedding(sd, data.x_service, data.edge_index_service, data.edge_attr_service, n_gcn)   # :145-156,164
+    service_batch = torch.arange(S).repeat(n_graphs)                                                     # :167-171
+    xs = scatter_mean(xs, service_batch, S)                                                              # :172
+    return torch.sigmoid(torch.matmul(xr, xs.t()))                                                       # :173-176
 
 
 def rank_services(scores):

@@ -236,6 +236,39 @@ def gen_ml(modelML, name, hidden, emb, n_gin, n_gcn, T, S, B, seed, n_t=3, degre
     print(f"ml_{name}: B={B} S={S} max|ref-oracle|={err:.2e}")
 
 
+def gen_ml_pygbatch(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, n_t=3, degree=6):
+    """The reference's forward on a batch of TWO graphs (DataLoader(batch_size=2), trainML.py:121-122) assembled the
+    way torch_geometric 1.7.0 would assemble it: x_service concatenated (2 copies), edge_index_service of copy 1
+    offset by graph 0's WORKFLOW node count (Data.__inc__ -> num_nodes = x.size(0); from memory of the 1.7.0 source —
+    see oracle/ml.py).  The real Net glue runs on it (stand-in convs); the oracle's literal batched form must agree."""
+    B = 2
+    table = synth.make_service_table(T, S, seed, degree=degree)
+    batch = synth.make_problem_batch(table, B, seed + 1, tasks_per_problem=n_t)
+    sd = oml.make_state_dict(hidden, emb, n_gin, n_gcn, seed + 2)
+    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=True, dropout=0.0)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    xs, eis, eas = (torch.from_numpy(a) for a in (table.x_service, table.edge_index, table.edge_attr))
+    nodes = np.bincount(batch.batch, minlength=B)
+    offsets = np.concatenate([[0], np.cumsum(nodes)[:-1]])
+    ei_b, ea_b = oml.pyg_batch_service_edges(eis, eas, offsets)
+    data = oml.make_data(torch.from_numpy(batch.x), torch.from_numpy(batch.edge_index), torch.from_numpy(batch.batch),
+                         xs.repeat(B, 1), ei_b, ea_b)
+    with torch.no_grad():
+        ref = net(data)
+    orc = oml.net_forward_batched(sd, data, n_gin, n_gcn, S)
+    err = float((ref - orc).abs().max())
+    assert err <= 1e-6, f"oracle batched Net != reference glue: {err}"
+    clean = oml.net_forward(sd, oml.make_data(data.x, data.edge_index, data.batch, xs, eis, eas), n_gin, n_gcn)
+    np.savez_compressed(
+        os.path.join(HERE, f"ml_{name}.npz"), scores=ref.numpy(), hidden=hidden, emb=emb, n_gin=n_gin, n_gcn=n_gcn, T=T, S=S,
+        B=B, seed=seed, x=batch.x, edge_index=batch.edge_index, batch=batch.batch, x_service=table.x_service,
+        edge_index_service=table.edge_index, edge_attr_service=table.edge_attr, offsets=offsets,
+        scores_single_copy=clean.numpy())
+    print(f"ml_{name}: pyg-1.7.0-style batch of 2, max|ref-oracle|={err:.2e}, max|batched - single-copy scores|="
+          f"{float((ref - clean).abs().max()):.3f}")
+
+
 def gen_hand_graph():
     """G6: a 5-node hand-checkable graph for the aggregate ops (expected values by oracle, which
     the stand-in cross-checks)."""
@@ -273,6 +306,7 @@ def main():
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)
     gen_ml(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, B=2, seed=61, n_t=10, degree=8)
     gen_ml(modelML, "normal", hidden=128, emb=20, n_gin=2, n_gcn=4, T=50, S=250, B=1, seed=71, n_t=10, degree=8)
+    gen_ml_pygbatch(modelML, "pygbatch", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=81, n_t=10, degree=8)
     gen_hand_graph()
 
 

@@ -260,3 +260,34 @@ def test_rank_rows(dev, B, S):
     scores[:, : S // 4] = scores[:, S // 2: S // 2 + S // 4]      # exact ties -> lowest id first
     out = ops.rank_rows(scores.to(dev)).cpu().long()
     assert torch.equal(out, oml.rank_services(scores))
+
+
+@pytest.mark.parametrize("B,n_t,n_gin", [(1, 1, 2), (37, 10, 2), (256, 10, 2), (64, 15, 3), (50, 0, 1)])
+def test_request_branch_equals_layered(dev, B, n_t, n_gin):
+    """gnnpn_request_branch_f32 (the whole GIN branch of small workflow graphs in one launch, node features resident in
+    LDS) is stage for stage the arithmetic of embed_concat / csr_aggregate / linear / segment_mean: bit-identical result.
+    Ragged sizes: one graph, graphs of 1, 2, 11 and 16 nodes, 1-3 layers."""
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.pipeline import DeviceBatch
+    from oracle import ml as oml
+    T, S = 20, 80
+    table = synth.make_service_table(T, S, seed=1, degree=4)
+    pb = synth.make_problem_batch(table, B, seed=B + n_t, tasks_per_problem=n_t)
+    net = Net(128, S, 20, n_gin, 2)
+    net.load_state_dict(oml.make_state_dict(128, 20, n_gin, 2, seed=3))
+    net = net.to(dev).eval()
+    batch = DeviceBatch.from_problems(pb, dev)
+    assert batch.max_nodes == n_t + 1
+    fused = net.request_embedding(batch.x, batch.wf_csr, batch.seg_ptr, batch.max_nodes)
+    layered = net.request_embedding(batch.x, batch.wf_csr, batch.seg_ptr, 0)
+    assert fused.shape == (B, 128) and torch.equal(fused, layered)
+    ref = oml.request_embedding(oml.make_state_dict(128, 20, n_gin, 2, seed=3), torch.from_numpy(pb.x),
+                                torch.from_numpy(pb.edge_index), torch.from_numpy(pb.batch), B, n_gin)
+    assert float((fused.cpu() - ref).abs().max()) < 1e-5
+    ops = _ops()
+    with pytest.raises(ops.GnnpnError):          # graphs beyond 16 nodes are refused, not truncated
+        p = net.prepared(dev)
+        flat = [lp[k] for lp in p["gin"] for k in ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")]
+        torch.ops.gnnpn.request_branch(batch.x, p["node_table"], batch.wf_csr.rowptr, batch.wf_csr.col, batch.seg_ptr, 17,
+                                       flat, p["nodeLin_p"], p["nodeLin"][1], 128)

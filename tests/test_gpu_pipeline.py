@@ -51,6 +51,28 @@ def test_net_forward_golden(dev, name):
     assert torch.equal(net(data), scores)
 
 
+def test_net_forward_on_a_pyg_style_batch(dev):
+    """Net.forward must do what the reference's forward does on the batch it is GIVEN.  ml_pygbatch.npz is the
+    reference's own glue on two graphs batched as torch_geometric 1.7.0 batches them (copy 1's service edges shifted by
+    graph 0's workflow node count): the GCN runs over both copies with those edges and the copies are averaged."""
+    fx = golden("ml_pygbatch.npz")
+    net = make_net(fx, dev)
+    B, S = int(fx["B"]), int(fx["S"])
+    t = lambda k: torch.from_numpy(fx[k]).to(dev)   # noqa: E731
+    ei, ea = oml.pyg_batch_service_edges(t("edge_index_service"), t("edge_attr_service"), fx["offsets"])
+    data = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service").repeat(B, 1), ei, ea)
+    scores = net(data)
+    err = float((scores.cpu() - torch.from_numpy(fx["scores"])).abs().max())
+    assert err < SCORE_ATOL, err
+    one = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service"), t("edge_index_service"), t("edge_attr_service"))
+    single = net(one)
+    assert float((single.cpu() - torch.from_numpy(fx["scores_single_copy"])).abs().max()) < SCORE_ATOL
+    assert float((single - scores).abs().max()) > 1e-3           # the two semantics really differ on this batch
+    bad = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service").repeat(3, 1), ei, ea)
+    with pytest.raises(ValueError):
+        net(bad)                                                  # neither one copy nor one copy per graph
+
+
 def test_net_rejects_training_and_noservices(dev):
     from gnnpn_sc_amd.modelML import Net
     with pytest.raises(NotImplementedError):
@@ -256,3 +278,83 @@ def test_all_gather_indices_rccl_world1(dev):
     finally:
         if td.is_initialized():
             td.destroy_process_group()
+
+
+def test_infer_writes_artifacts_that_check_scores(dev, tmp_path, monkeypatch):
+    """ML2PN.infer (the write side of the artefact formats) on a dataset in the reference's JSON formats: the rankings
+    and actions files it writes have the reference's shapes, `check` reads them back, and they equal the CPU oracle
+    chain's (rankings wherever the oracle's scores are separated, actions on problems whose decisions are robust);
+    `python main.py QWS ML+2PN -1 --infer` does the same from the command line and prints the reference's line."""
+    import contextlib
+    import io
+    import json
+    import os
+    import subprocess
+    import sys
+    import gnnpn_sc_amd.synth as synth
+    from conftest import ROOT
+    from gnnpn_sc_amd import ML2PN
+    from gnnpn_sc_amd.modelML import Net
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    T, S, P, K, H = 6, 60, 16, 3, 256
+    ds = synth.make_dataset(T, S, P, seed=3, tasks_per_problem=3, lo_range=(0.80, 0.955))
+    synth.write_dataset(str(tmp_path), "QWS", ds)
+    monkeypatch.chdir(tmp_path)
+    sd_ml = oml.make_state_dict(128, 20, 2, 2, seed=7)
+    sd_low, sd_high = opn.make_state_dict(H, 8), opn.make_state_dict(H, 9)
+    net = Net(128, S, 20, 2, 2)
+    net.load_state_dict(sd_ml)
+    low = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="Low")
+    high = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level="High")
+    low.load_state_dict(sd_low)
+    high.load_state_dict(sd_high)
+    p_rank, p_act = ML2PN.infer("QWS", net, low, high, K, epoch=-1, device=str(dev), batch_size=5)
+    with open(p_rank) as f:
+        rankings = json.load(f)
+    with open(p_act) as f:
+        actions = json.load(f)
+    n_test = P // 4
+    assert len(rankings) == P and sorted(rankings[0]) == list(range(S))
+    assert len(actions) == T and len(actions[0]) == n_test and len(actions[0][0]) == 8
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        got = ML2PN.check("QWS", T, -1)
+    assert buf.getvalue().split()[0] == "-1" and np.isfinite(got)
+    # the oracle chain on the same files
+    import gnnpn_sc_amd.loadData as ld
+    table, pb = ld.tables_from_dataset(ds, 0, P)
+    data = oml.make_data(torch.from_numpy(pb.x), torch.from_numpy(pb.edge_index), torch.from_numpy(pb.batch),
+                         torch.from_numpy(table.x_service), torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr))
+    scores = oml.net_forward(sd_ml, data, 2, 2)
+    want_rank = oml.rank_services(scores)
+    ss = torch.gather(scores, 1, want_rank)
+    sep = torch.ones_like(want_rank, dtype=torch.bool)
+    gap = (ss[:, :-1] - ss[:, 1:]) > 4 * SCORE_ATOL
+    sep[:, 1:] &= gap
+    sep[:, :-1] &= gap
+    assert torch.equal(torch.tensor(rankings)[sep], want_rank[sep])
+    rows, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], rankings, ds["minCostList"], K)
+    x = torch.tensor([odata.pn_inputs(r).tolist() for r in rows[P - n_test:]], dtype=torch.float32)
+    ref = opn.two_level_greedy(sd_low, sd_high, x, T, K)
+    robust = robust_problems(ref["margin_low"], ref["margin_high"])
+    got_act = torch.tensor(actions).permute(1, 0, 2).float()                      # [n_test, T, 8]
+    same = (got_act == ref["actions"]).all(-1).all(-1)
+    assert bool(same[robust].all()) and bool(robust.any())
+    if bool(same.all()):
+        k1, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], rankings, ds["minCostList"], 1)
+        assert abs(odata.check(k1, ds["minCostList"], actions, T) - got) < 1e-12
+    # the command line: weights from ./solutions/pretrained/ in the reference's checkpoint formats
+    os.remove(p_rank), os.remove(p_act)
+    torch.save(sd_ml, "solutions/pretrained/QWS-ML.pt")
+    torch.save({"epoch": 0, "model": sd_low, "optimizer": {}}, "solutions/pretrained/QWS-PNLow.model")
+    torch.save({"epoch": 0, "model": sd_high, "optimizer": {}}, "solutions/pretrained/QWS-PNHigh.model")
+    with open("environment.ini", "w") as f:
+        f.write("[QWS-ML]\nnumLayersGIN = 2\nnumLayersGCN = 2\nhiddenChannels = 128\nembeddingChannels = 20\ndropout = 0.0\n"
+                f"[QWS-PNHigh]\nserNumber = {K}\nhidden_size = {H}\nn_glimpses = 0\ntanh_exploration = 10\nuse_tanh = 1\n"
+                f"[QWS-ML+2PN]\nserviceCategory = {T}\nepoch = -1\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "QWS", "ML+2PN", "-1", "--infer"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1].split()
+    assert line[0] == "-1" and abs(float(line[1]) - got) < 1e-9                   # same weights, same data -> same score
+    assert os.path.exists(p_rank) and os.path.exists(p_act)

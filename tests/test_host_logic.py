@@ -233,3 +233,56 @@ def test_load_data_other_and_adds_match_reference(tmp_path, monkeypatch):
             r = owoa.eswoa(lists[b], cons[b], copy.deepcopy(sols[b]), p["popSize"], p["MAX_Iter"],
                            owoa.DrawStream(p["base_seed"] + n_train + b))
             assert mins[n_train + b] / r["best_fitness"] == want["quality"][b], (reduct, b)
+
+
+def test_artifact_write_side_round_trips_through_check(fx, workdir):
+    """The WRITE side of the artefact formats (ML2PN.write_artifacts, what ML2PN.infer / main.py --infer end with):
+    rankings and actions produced by the CPU oracle chain are written in the reference's two formats, at the paths
+    loadDataPN / check read (epoch -1 and epoch N), and check() scores them exactly as the oracle's check does."""
+    from gnnpn_sc_amd import ML2PN
+    from oracle import data as odata
+    from oracle import pn as opn
+    import torch
+    ds, P, T, K = fx["dataset"], fx["P"], fx["T"], fx["K"]
+    rankings = fx["rank_each"]
+    rows, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], rankings, ds["minCostList"], K)
+    n_train = P // 4 * 3
+    x = torch.tensor([odata.pn_inputs(r).tolist() for r in rows[n_train:]], dtype=torch.float32)
+    out = opn.two_level_greedy(opn.make_state_dict(32, 1), opn.make_state_dict(32, 2), x, T, K)
+    actions = [[out["actions"][j, t].double().tolist() for j in range(P - n_train)] for t in range(T)]
+    k1, _ = odata.load_data_pn(ds["nodefeatures"], ds["serviceFeature"], rankings, ds["minCostList"], 1)
+    want = odata.check(k1, ds["minCostList"], actions, T)
+    for epoch in (-1, 7):
+        p_rank, p_act = ML2PN.write_artifacts("QWS", epoch, rankings, actions)
+        assert (p_rank, p_act) == ML2PN.artifact_paths("QWS", epoch) and os.path.exists(p_rank) and os.path.exists(p_act)
+        with open(p_rank) as f:
+            assert json.load(f) == rankings
+        with open(p_act) as f:
+            got = json.load(f)
+        assert len(got) == T and len(got[0]) == P - n_train and len(got[0][0]) == 8
+        if epoch != -1:      # check() always takes the rankings of epoch -1 (ML2PN.py:19) and the actions of `epoch`
+            ML2PN.write_artifacts("QWS", -1, rankings, [[[0.0] * 8]])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = ML2PN.check("QWS", T, epoch)
+        assert abs(res - want) < 1e-12 and buf.getvalue().split()[0] == str(epoch)
+
+
+def test_bench_strong_scaling_partition_is_the_same_global_set():
+    """bench.py --scaling strong: the global batch is 8 seeded chunks; whatever the number of ranks, the union of the
+    ranks' shards (in rank order) is the same problem set, so N=1 and N=8 work on identical data."""
+    import bench
+    import gnnpn_sc_amd.synth as synth
+    w = dict(T=6, K=3, S=60, B=0, n_t=3, G=32)
+    table = synth.make_service_table(w["T"], w["S"], seed=0, degree=4)
+    whole = bench.rank_batches(synth, table, w, 0, 1, "strong", 2)
+    for world in (2, 4, 8):
+        for j in range(2):
+            parts = [bench.rank_batches(synth, table, w, r, world, "strong", 2)[j] for r in range(world)]
+            assert sum(p.n_problems for p in parts) == 32
+            assert np.array_equal(np.concatenate([p.x for p in parts]), whole[j].x)
+            assert np.array_equal(np.concatenate([p.local_bounds for p in parts]), whole[j].local_bounds)
+            assert np.array_equal(np.concatenate([p.present for p in parts]), whole[j].present)
+    assert not np.array_equal(whole[0].local_bounds, whole[1].local_bounds)       # resident batches differ
+    b0 = whole[0]
+    assert b0.batch.max() == 31 and b0.edge_index.max() == b0.x.shape[0] - 1       # offsets of the merged chunks

@@ -173,3 +173,21 @@ def test_pn_oracle_reproduces_reference_at_baseline_shape(name):
     nw = min(n, fx["win_low"].shape[0])
     m = rec["same_mask"][:nw]
     assert np.allclose(out["win_low"].numpy()[:nw][m], fx["win_low"][:nw][m], rtol=0, atol=2e-5)
+
+
+def test_ml_oracle_batched_forward_reproduces_reference_glue():
+    """ml_pygbatch.npz: the reference's own Net.forward on a batch of two graphs assembled as torch_geometric 1.7.0's
+    Data.__inc__ would (service edges of copy 1 shifted by graph 0's workflow node count).  The oracle's literal batched
+    form reproduces it; the single-copy form does NOT (that is the documented divergence of the device pipeline)."""
+    fx = golden("ml_pygbatch.npz")
+    sd = oml.make_state_dict(int(fx["hidden"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]), int(fx["seed"]) + 2)
+    t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
+    B, S = int(fx["B"]), int(fx["S"])
+    ei, ea = oml.pyg_batch_service_edges(t("edge_index_service"), t("edge_attr_service"), fx["offsets"])
+    data = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service").repeat(B, 1), ei, ea)
+    out = oml.net_forward_batched(sd, data, int(fx["n_gin"]), int(fx["n_gcn"]), S)
+    assert float((out - t("scores")).abs().max()) <= 1e-6
+    single = oml.net_forward(sd, oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service"),
+                                               t("edge_index_service"), t("edge_attr_service")), int(fx["n_gin"]), int(fx["n_gcn"]))
+    assert float((single - t("scores_single_copy")).abs().max()) <= 1e-6
+    assert float((single - t("scores")).abs().max()) > 1e-3

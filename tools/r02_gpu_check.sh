@@ -13,3 +13,6 @@ timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; ech
 GNNPN_FORCE_DIST=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-line > $O/bench_force_dist_rccl_world1.json 2> $O/bench_force_dist_rccl_world1.err; echo "force_dist rc=$?"
 timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
 head -c 600 $O/bench_default.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_solo -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-split-line --graph 0 --inflight 1 --min-time 0 > $O/prof_solo.log 2>&1
+f=$(ls -t $O/prof_solo/*/*kernel_stats.csv | head -1); head -25 $f
