@@ -24,6 +24,8 @@ _SIGNATURES = {
     "gnnpn_embed_concat_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
     "gnnpn_csr_aggregate_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
                                         c_int32, _P]),
+    "gnnpn_csr_aggregate_blocks_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
+                                               c_int32, c_int32, _P]),
     "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,
@@ -50,7 +52,7 @@ class DecodeNet(ctypes.Structure):
     _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih_packed", "whh_packed", "bih",
                                   "bhh", "latent_win", "emb_w", "emb_b", "xw_fold", "xb_fold", "start_fold", "idx", "win_logits", "pick_prob", "actions",
                                   "queries")] + \
-               [("latent_from", c_int32), ("reserved", c_int32)]
+               [("latent_from", c_int32), ("sample", c_int32), ("sample_seed", ctypes.c_uint64)]
 
 
 class LaunchOpts(ctypes.Structure):

@@ -51,6 +51,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// draw `ctr` of the counter-based uniform stream of `seed` (splitmix64 finaliser, the stream of oracle/woa.py), as a
+// 24-bit uniform in [0, 1) — exactly representable in fp32
+__device__ __forceinline__ float stream_uniform24(unsigned long long seed, unsigned long long ctr) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * 5.9604644775390625e-08f;
+}
+
 // monotone map fp32 -> u32 (larger float -> larger unsigned; -0 < +0; NaNs sort above +inf)
 __device__ __forceinline__ unsigned float_order_key(float f) {
     unsigned u = __float_as_uint(f);

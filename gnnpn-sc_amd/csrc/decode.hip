@@ -22,7 +22,8 @@ __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_kernel(
     const float* __restrict__ whh, const float* __restrict__ bih, const float* __restrict__ bhh,
     const float* __restrict__ latent_win, const float* __restrict__ inputs, float tanh_c, int use_tanh,
     int32_t* __restrict__ idx_out, float* __restrict__ win_logits, float* __restrict__ pick_prob,
-    float* __restrict__ actions, float* __restrict__ queries, int32_t B, int32_t T, int32_t n_per) {
+    float* __restrict__ actions, float* __restrict__ queries, int32_t B, int32_t T, int32_t n_per, int sample,
+    unsigned long long sample_seed) {
     constexpr int NT = H < 64 ? 64 : H;
     constexpr int NW = NT / 64;
     __shared__ __attribute__((aligned(16))) float xs[BT][H];
@@ -120,7 +121,22 @@ __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_kernel(
             }
             float denom = 0.0f;
             for (int r = 0; r < n_per; ++r) denom = __fadd_rn(denom, expf(__fsub_rn(lg[p][r], best)));
-            pick_prob[(int64_t)(b0 + p) * T + k] = 1.0f / denom;   // exp(best-best)/sum
+            float prob = 1.0f / denom;                              // exp(best-best)/sum
+            if (sample) {   // multinomial(1) from the window softmax (modelPN.py:227-228): first r with u < cdf_r
+                const float u = stream_uniform24(sample_seed, (unsigned long long)(b0 + p) * T + k);
+                float cdf = 0.0f;
+                int pick = -1, last_pos = 0;
+                for (int r = 0; r < n_per; ++r) {
+                    const float pr = expf(__fsub_rn(lg[p][r], best)) / denom;
+                    cdf = __fadd_rn(cdf, pr);
+                    if (pr > 0.0f) last_pos = r;
+                    if (pick < 0 && u < cdf) pick = r;
+                }
+                if (pick < 0) pick = last_pos;
+                best_r = pick;
+                prob = expf(__fsub_rn(lg[p][pick], best)) / denom;
+            }
+            pick_prob[(int64_t)(b0 + p) * T + k] = prob;
             idx_out[(int64_t)(b0 + p) * T + k] = k * n_per + best_r;
             sel[p] = k * n_per + best_r;
         }
@@ -144,7 +160,8 @@ static void launch_decode(const float* embedded, const float* enc_out, const flo
                           const float* start, const float* wih, const float* whh, const float* bih,
                           const float* bhh, const float* latent_win, const float* inputs, float tanh_c,
                           int use_tanh, int32_t* idx, float* win_logits, float* pick_prob, float* actions,
-                          float* queries, int32_t B, int32_t T, int32_t n_per, hipStream_t s) {
+                          float* queries, int32_t B, int32_t T, int32_t n_per, int sample, unsigned long long sample_seed,
+                          hipStream_t s) {
     constexpr int NT = H < 64 ? 64 : H;
     int bt = 1;
     while (bt < 4 && B / (bt * 2) >= 256) bt *= 2;
@@ -152,7 +169,7 @@ static void launch_decode(const float* embedded, const float* enc_out, const flo
 #define GNNPN_LAUNCH_DEC(BT_)                                                                                  \
     hipLaunchKernelGGL((pointer_decode_kernel<H, BT_>), grid, block, 0, s, embedded, enc_out, h0, c0, start, wih, \
                        whh, bih, bhh, latent_win, inputs, tanh_c, use_tanh, idx, win_logits, pick_prob, actions,  \
-                       queries, B, T, n_per)
+                       queries, B, T, n_per, sample, sample_seed)
     switch (bt) {
         case 1: GNNPN_LAUNCH_DEC(1); break;
         case 2: GNNPN_LAUNCH_DEC(2); break;
@@ -188,6 +205,7 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         GNNPN_REQUIRE(d.latent_from < n && d.latent_from >= -1, "pointer_decode: latent_from of net %d must name an "
                       "earlier net of the call", n);
         GNNPN_REQUIRE(!(d.latent_win && d.latent_from >= 0), "pointer_decode: net %d has two latent sources", n);
+        GNNPN_REQUIRE(d.sample == 0 || d.sample == 1, "pointer_decode: net %d: sample must be 0 (greedy) or 1 (multinomial)", n);
         GNNPN_REQUIRE(gnnpn_aligned(d.wih_packed, 16) && gnnpn_aligned(d.whh_packed, 16) &&
                           gnnpn_aligned(d.enc_out, 16) && (!d.embedded || gnnpn_aligned(d.embedded, 16)),
                       "pointer_decode: weights / enc_out / embedded must be 16-byte aligned");
@@ -202,6 +220,11 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     args.K = n_per;
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
+    bool any_sample = false;
+    for (int n = 0; n < n_nets; ++n) any_sample |= nets[n].sample != 0;
+    if (any_sample && (precision != GNNPN_PREC_F32 || opts.impl >= 3))
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: sampling is built in the streaming and the 8-CU-group fp32 forms (impl 0-2, "
+                   "GNNPN_PREC_F32)");
     const int impl = opts.impl;   // 0 auto, 1 streaming, 2 8-CU groups, 3 16-CU groups, 4 8-CU groups sized for 2 per CU
     if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl >= 2)) {
         // auto / 2: 8-member groups — fastest when the launch has the GPU to itself (0.32 ms at QWS B=256).
@@ -229,10 +252,12 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         const float* latent = d.latent_from >= 0 ? args.net[d.latent_from].win_logits : d.latent_win;
         if (H == 256)
             launch_decode<256>(d.embedded, d.enc_out, d.h0, d.c0, d.start, d.wih, d.whh, d.bih, d.bhh, latent, inputs,
-                               tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per, s);
+                               tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per,
+                               d.sample, d.sample_seed, s);
         else
             launch_decode<32>(d.embedded, d.enc_out, d.h0, d.c0, d.start, d.wih, d.whh, d.bih, d.bhh, latent, inputs,
-                              tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per, s);
+                              tanh_c, use_tanh, d.idx, d.win_logits, d.pick_prob, d.actions, d.queries, B, T, n_per,
+                              d.sample, d.sample_seed, s);
     }
     GNNPN_CHECK_LAUNCH("pointer_decode_f32");
     return GNNPN_OK;

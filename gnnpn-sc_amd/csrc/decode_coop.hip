@@ -53,7 +53,9 @@ __device__ __forceinline__ int ror16(int v, int n) {
 // SPLIT: W_hh.h with fp16 hi+lo operands (coop_common.h); everything else as in the fp32 form
 // OCC: workgroups per CU the build is sized for — 1 (512 registers: fastest alone) or 2 (256 registers: shares the
 // CU with a workgroup of another launch, pipeline.PipelinedRunner)
-template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 : 1)>
+// SAMPLE: the build that can draw the pick from the window softmax (gnnpn_decode_net_t.sample); the greedy builds carry
+// none of that code
+template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 : 1), bool SAMPLE = false>
 __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
@@ -264,13 +266,36 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 #pragma unroll
                     for (int n = 1; n <= 8; n <<= 1) best = fmaxf(best, __int_as_float(ror16(__float_as_int(best), n)));
                     float e = live ? expf(__fsub_rn(v, best)) : 0.0f;
+                    const float e_own = e;
 #pragma unroll
                     for (int n = 8; n >= 1; n >>= 1) e = __fadd_rn(e, __int_as_float(ror16(__float_as_int(e), n)));
+                    int pick_r = best_r;
+                    float pick_p = 1.0f / e;
+                    if constexpr (SAMPLE) {
+                        if (net.sample) {   // multinomial(1) from the window softmax (modelPN.py:227-228)
+                            // every lane r of the row accumulates cdf_r = p_0 + ... + p_r in candidate order (the order the
+                            // oracle's running sum uses); the pick is the first r with u < cdf_r
+                            const float pr = e_own / e;
+                            float cdf = 0.0f;
+                            for (int j = 0; j < K; ++j) {
+                                const float pj = __shfl(pr, (lane & ~15) + j, 64);
+                                if (j <= r) cdf = __fadd_rn(cdf, pj);
+                            }
+                            const float u = stream_uniform24(net.sample_seed, (unsigned long long)min(b, B - 1) * T + (k - 1));
+                            const unsigned below = (unsigned)(__ballot(live && !(u < cdf)) >> (16 * kq)) & 0xffffu;
+                            const unsigned pos = (unsigned)(__ballot(live && pr > 0.0f) >> (16 * kq)) & 0xffffu;
+                            int cand = min((int)__popc(below), K - 1);           // cdf is non-decreasing: count = first r with u < cdf_r
+                            const unsigned upto = pos & ((2u << cand) - 1u);     // rounding left none: the last r with p_r > 0
+                            if (!((pos >> cand) & 1u) && upto) cand = 31 - __clz(upto);
+                            pick_r = cand;
+                            pick_p = __shfl(pr, (lane & ~15) + cand, 64);
+                        }
+                    }
                     if (r == 0) {
-                        sel[row] = (k - 1) * K + best_r;
+                        sel[row] = (k - 1) * K + pick_r;
                         if (member == 0 && b < B) {
-                            net.pick_prob[(int64_t)b * T + (k - 1)] = 1.0f / e;
-                            net.idx[(int64_t)b * T + (k - 1)] = (k - 1) * K + best_r;
+                            net.pick_prob[(int64_t)b * T + (k - 1)] = pick_p;
+                            net.idx[(int64_t)b * T + (k - 1)] = (k - 1) * K + pick_r;
                         }
                     }
                 }
@@ -523,6 +548,16 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
                        coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
                        s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, abl)
 #define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
+    bool any_sample = false;
+    for (int n = 0; n < n_nets; ++n) any_sample |= args.net[n].sample != 0;
+    if (any_sample) {
+        if (!fold || split || (abl & 32))
+            GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the sampling build exists for the folded fp32 input side only");
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false, 1, 1, true>), dim3(groups * G), dim3(256),
+                           coop_lds_padding((const void*)pointer_decode_coop_kernel<true, false, false, 1, 1, true>, lds_kb), s,
+                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, abl);
+        return GNNPN_OK;
+    }
     if (shared_cu && (!fold || (abl & 32)))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side only");
     const bool wide_k = args.K > 8;                       // two threads per (row, candidate) need 2*16*K <= 256

@@ -26,7 +26,8 @@ struct DecodeNet {
     float* actions;
     float* queries;
     int32_t latent_from;
-    int32_t reserved;
+    int32_t sample;
+    uint64_t sample_seed;
 };
 static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "DecodeNet must mirror gnnpn_decode_net_t");
 

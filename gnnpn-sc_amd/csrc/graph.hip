@@ -120,6 +120,158 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-staged form for BLOCK-LOCAL graphs (north star: "node features staged in LDS").  A batch of service graphs is block
+// diagonal: destination rows [b*R, (b+1)*R) only gather source rows of the same block (R = the table size S).  The kernel
+// above re-fetches every source row from L2 once per neighbour (33 x 1 KiB per output row at degree 32: L2-gather-bound,
+// 14 % of the HBM roofline).  Here a workgroup owns (block b, channel slice s of SLICE channels): it copies the block's
+// slice x[b*R .. (b+1)*R)[SLICE*s .. SLICE*(s+1)) into LDS ONCE (R * SLICE * 4 B <= 160 KB: SLICE = 16 up to R = 2560,
+// 8 up to 5120, 4 up to 10240) and serves every gather from there, so each source element crosses the L2 -> CU path once.
+// LPR = SLICE/4 lanes per destination row, one float4 each; a wave works on 64/LPR rows at a time and walks their neighbour
+// lists in step (4 edges per trip, the (col, w) loads of a trip issued before its LDS reads).  Sums are strictly in CSR
+// order with separately rounded multiply and add: bit-identical to csr_aggregate_kernel.
+// Placement (speed only): the SLICE-WGs of one block get equal blockIdx % 8 (one XCD), so the two halves of every 128-B
+// line of x — read by two different slices — meet in that XCD's L2 and the (col, w) lists are fetched from HBM once.
+// value of lane L of the own group of LPR (4, 2 or 1) consecutive lanes, as a DPP quad permute (no LDS round trip)
+template <int LPR, int L>
+__device__ __forceinline__ int quad_from(int v) {
+    if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xF, 0xF, false);                 // [L,L,L,L]
+    else if constexpr (LPR == 2) return __builtin_amdgcn_update_dpp(0, v, L | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6), 0xF, 0xF, false);
+    else return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ y, int64_t ldy,
+    int32_t n_rows, int32_t C, int32_t R, int32_t n_blocks, int32_t n_slices) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [R][SLICE]
+    constexpr int SLICE = 4 * LPR;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int s = j % n_slices, b = (j / n_slices) * 8 + xcd;
+    if (b >= n_blocks) return;
+    const int r0 = b * R, rows = min(R, n_rows - r0);
+    const int c0 = s * SLICE;
+    const int sub = threadIdx.x % LPR, c = c0 + 4 * sub;               // this lane's 4 channels
+    // ---- fill: the block's channel slice, 16 B per lane
+    for (int r = threadIdx.x / LPR; r < rows; r += 1024 / LPR) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + c);
+        *reinterpret_cast<float4*>(tile + r * SLICE + 4 * sub) = v;
+    }
+    __syncthreads();
+    const float one_plus_eps = self_coef ? __fadd_rn(1.0f, *self_coef) : 0.0f;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        if (bias) bv[v] = bias[c + v];
+        if (scale) {
+            sc[v] = scale[c + v];
+            sh[v] = shift[c + v];
+        }
+    }
+    // ---- gather: rows dealt to (wave, lane group) round-robin; a wave's rows advance together
+    for (int rb = 0; rb < rows; rb += 1024 / LPR) {
+        const int r = rb + threadIdx.x / LPR;
+        const bool live = r < rows;
+        int e = 0, e1 = 0;
+        if (live) {
+            e = rowptr[r0 + r];
+            e1 = rowptr[r0 + r + 1];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        while (__any(e < e1)) {
+            // (col, w) of the trip's 4 edges: the LPR lanes of a row each fetch a DIFFERENT edge (consecutive addresses: one
+            // line per row and instruction instead of one per row, edge and instruction) and hand it round by a DPP
+            // quad permute — the texture-addresser was the bound with every lane of a row fetching the same word
+            constexpr int NL = 4 / LPR;
+            int cl[NL];
+            float wl[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int idx = e + k * LPR + sub;
+                const bool ok = idx < e1;
+                cl[k] = ok ? col[idx] - r0 : 0;
+                wl[k] = (ok && w) ? w[idx] : 1.0f;
+            }
+            int cj[4];
+            float wj[4];
+            cj[0] = quad_from<LPR, 0>(cl[0]);
+            wj[0] = __int_as_float(quad_from<LPR, 0>(__float_as_int(wl[0])));
+            cj[1] = quad_from<LPR, 1 % LPR>(cl[1 / LPR]);
+            wj[1] = __int_as_float(quad_from<LPR, 1 % LPR>(__float_as_int(wl[1 / LPR])));
+            cj[2] = quad_from<LPR, 2 % LPR>(cl[2 / LPR]);
+            wj[2] = __int_as_float(quad_from<LPR, 2 % LPR>(__float_as_int(wl[2 / LPR])));
+            cj[3] = quad_from<LPR, 3 % LPR>(cl[3 / LPR]);
+            wj[3] = __int_as_float(quad_from<LPR, 3 % LPR>(__float_as_int(wl[3 / LPR])));
+            float4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(tile + cj[u] * SLICE + 4 * sub);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e + u < e1) {
+                    const float t4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], w ? __fmul_rn(wj[u], t4[v]) : t4[v]);
+                }
+            }
+            e += 4;
+        }
+        if (!live) continue;
+        const float4 own = *reinterpret_cast<const float4*>(tile + r * SLICE + 4 * sub);
+        const float o4[4] = {own.x, own.y, own.z, own.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float t = acc[v];
+            if (self_coef) t = __fadd_rn(t, __fmul_rn(one_plus_eps, o4[v]));
+            if (bias) t = __fadd_rn(t, bv[v]);
+            if (scale) t = __fadd_rn(__fmul_rn(t, sc[v]), sh[v]);
+            acc[v] = apply_act(t, act);
+        }
+        *reinterpret_cast<float4*>(y + (int64_t)(r0 + r) * ldy + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+extern "C" int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
+                                              int64_t ldx, const float* self_coef, const float* bias, const float* scale,
+                                              const float* shift, int act, float* y, int64_t ldy, int32_t n_rows, int32_t C,
+                                              int32_t block_rows, void* stream) {
+    GNNPN_REQUIRE(rowptr && x && y, "csr_aggregate_blocks: null operand");
+    GNNPN_REQUIRE(n_rows >= 0 && C > 0 && ldx >= C && ldy >= C && block_rows > 0, "csr_aggregate_blocks: bad shape");
+    GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "csr_aggregate_blocks: scale and shift go together");
+    GNNPN_REQUIRE(x != y, "csr_aggregate_blocks: in-place aggregation is not supported");
+    if (n_rows == 0) return GNNPN_OK;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gnnpn_aligned(x, 16) && gnnpn_aligned(y, 16);
+    constexpr int64_t LDS_BYTES = 160 * 1024;
+    int lpr = 0;                                   // lanes per row = SLICE / 4: the widest slice whose block fits the LDS
+    for (int cand = 4; cand >= 1; cand >>= 1)
+        if (C % (4 * cand) == 0 && (int64_t)block_rows * 16 * cand <= LDS_BYTES) {
+            lpr = cand;
+            break;
+        }
+    if (!vec || lpr == 0)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "csr_aggregate_blocks: blocks of %d rows x %d channels do not fit the LDS-staged form "
+                   "(16-byte aligned rows, block_rows * 16 B <= 160 KB): use gnnpn_csr_aggregate_f32", block_rows, C);
+    const int n_blocks = (n_rows + block_rows - 1) / block_rows, n_slices = C / (4 * lpr);
+    const unsigned lds = (unsigned)((int64_t)block_rows * 16 * lpr);
+    dim3 grid((unsigned)(((n_blocks + 7) / 8) * n_slices * 8)), block(1024);
+    hipStream_t st = (hipStream_t)stream;
+#define GNNPN_AGG_LDS(LPR_)                                                                                              \
+    do {                                                                                                                 \
+        if (hipFuncSetAttribute((const void*)csr_aggregate_lds_kernel<LPR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds) != hipSuccess)                                                                  \
+            GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_blocks: cannot reserve %u B of LDS", lds);                          \
+        hipLaunchKernelGGL((csr_aggregate_lds_kernel<LPR_>), grid, block, lds, st, rowptr, col, w, x, ldx, self_coef,    \
+                           bias, scale, shift, act, y, ldy, n_rows, C, block_rows, n_blocks, n_slices);                  \
+    } while (0)
+    if (lpr == 4) GNNPN_AGG_LDS(4);
+    else if (lpr == 2) GNNPN_AGG_LDS(2);
+    else GNNPN_AGG_LDS(1);
+#undef GNNPN_AGG_LDS
+    GNNPN_CHECK_LAUNCH("csr_aggregate_blocks_f32");
+    return GNNPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // GCN normalisation.  deg: one wave per row would waste lanes on short rows; rows are summed
 // sequentially (scatter_add order) by one lane each — the arrays are tiny next to the features.
 __global__ void gcn_deg_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ w_raw,

@@ -44,9 +44,9 @@ _op("linear(Tensor a, Tensor weight, Tensor? bias=None, Tensor? scale=None, Tens
     lambda a, weight, bias=None, scale=None, shift=None, act=0: ops.linear(a, weight, bias, scale, shift, act))
 _op("embed_concat(Tensor x, Tensor table) -> Tensor", ops.embed_concat)
 _op("csr_aggregate(Tensor rowptr, Tensor col, Tensor? w, Tensor x, Tensor? self_coef=None, Tensor? bias=None, "
-    "Tensor? scale=None, Tensor? shift=None, int act=0) -> Tensor",
-    lambda rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0:
-    ops.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act))
+    "Tensor? scale=None, Tensor? shift=None, int act=0, int block_rows=0) -> Tensor",
+    lambda rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0, block_rows=0:
+    ops.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act, block_rows))
 def _request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layer_tensors, lin_w_packed, lin_b, hidden):
     keys = ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")
     layers = [dict(zip(keys, layer_tensors[i:i + len(keys)])) for i in range(0, len(layer_tensors), len(keys))]
@@ -80,12 +80,14 @@ _op("lstm_encode(Tensor?[] net_tensors, int n_nets, str precision='f32', int imp
 
 
 def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False,
-                    precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1):
+                    precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, sample_seeds=()):
     n = len(DECODE_KEYS)
     nets = []
     for i, lf in enumerate(latent_from):
         d = {k: net_tensors[i * n + j] for j, k in enumerate(DECODE_KEYS)}
         d["latent_from"] = lf
+        if i < len(sample_seeds) and sample_seeds[i] >= 0:      # >= 0: draw this net's picks from the stream of that seed
+            d["sample"], d["sample_seed"] = True, sample_seeds[i]
         nets.append(d)
     outs = ops.pointer_decode(nets, inputs, n_cat, n_per, tanh_c, use_tanh, want_queries, precision, impl, lds_kb,
                               write_through, _ws(ws_id))
@@ -98,7 +100,7 @@ def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0,
 
 _op("pointer_decode(Tensor?[] net_tensors, int[] latent_from, Tensor inputs, int n_cat, int n_per, float tanh_c=10.0, "
     "bool use_tanh=True, bool want_queries=False, str precision='f32', int impl=0, int lds_kb=0, "
-    "bool write_through=False, int ws=-1) -> Tensor[]", _pointer_decode)
+    "bool write_through=False, int ws=-1, int[] sample_seeds=[]) -> Tensor[]", _pointer_decode)
 
 
 # ---- thin callers used by the mirrors: dict-of-tensors in, torch.ops.gnnpn.* underneath ------------------------------
@@ -115,8 +117,9 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
                    lds_kb=0, write_through=False, ws=None):
     flat = [d.get(k) for d in nets for k in DECODE_KEYS]
     lf = [int(d.get("latent_from", -1)) for d in nets]
+    seeds = [int(d["sample_seed"]) & 0x7FFFFFFFFFFFFFFF if d.get("sample") else -1 for d in nets]
     out = torch.ops.gnnpn.pointer_decode(flat, lf, inputs, n_cat, n_per, float(tanh_c), bool(use_tanh), bool(want_queries),
-                                         precision, impl, lds_kb, bool(write_through), -1 if ws is None else ws.id)
+                                         precision, impl, lds_kb, bool(write_through), -1 if ws is None else ws.id, seeds)
     m = len(DECODE_OUTS)
     res = []
     for i in range(len(nets)):

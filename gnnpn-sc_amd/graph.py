@@ -14,10 +14,11 @@ class CSR:
     col: torch.Tensor           # int32 [nnz]   source node of every in-edge
     w: torch.Tensor             # float32 [nnz] or None
     n: int
+    block_rows: int = 0         # > 0: every edge stays inside its block of that many consecutive rows (block_local())
 
     def to(self, device):
         return CSR(self.rowptr.to(device), self.col.to(device), None if self.w is None else self.w.to(device),
-                   self.n)
+                   self.n, self.block_rows)
 
 
 def csr_by_destination(edge_index, n, weight=None):
@@ -46,6 +47,15 @@ def gcn_csr(edge_index, edge_weight, n):
     loops = torch.arange(n, dtype=torch.long, device=row.device)
     ei = torch.stack([torch.cat([row[keep], loops]), torch.cat([col[keep], loops])])
     return csr_by_destination(ei, n, torch.cat([edge_weight.float()[keep], loop_w]))
+
+
+def block_local(edge_index, block_rows):
+    """True when every edge's two endpoints lie in the same block of ``block_rows`` consecutive node ids — a batch of
+    block-diagonal graph copies.  The LDS-staged aggregate (gnnpn_csr_aggregate_blocks_f32) relies on it."""
+    if edge_index.numel() == 0:
+        return True
+    return bool((torch.div(edge_index[0], block_rows, rounding_mode="floor") ==
+                 torch.div(edge_index[1], block_rows, rounding_mode="floor")).all().item())
 
 
 def segment_ptr(batch, n_graphs):

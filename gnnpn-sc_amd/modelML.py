@@ -199,7 +199,7 @@ class Net(nn.Module):
         for lp in p["gcn"]:                                                                     # :152-155
             xw = torch.ops.gnnpn.linear(xs, lp["wt"])                                                       # transform first
             xs = torch.ops.gnnpn.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
-                                   shift=lp["s"], act=ACT_RELU)
+                                               shift=lp["s"], act=ACT_RELU, block_rows=svc_csr.block_rows)
         return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                                 # :164
 
     @torch.no_grad()
@@ -259,6 +259,8 @@ class Net(nn.Module):
                      "svc": graph.gcn_csr(data.edge_index_service, data.edge_attr_service, n_svc),
                      "xs": xs, "copies": copies,
                      "max_nodes": int(torch.bincount(b).max().item()) if inside else 0}
+            if graph.block_local(data.edge_index_service, S):     # clean block-diagonal copies: features staged in LDS
+                cache["svc"].block_rows = S
             if copies > 1:    # rows (s, S+s, 2S+s, ...) as one CSR row: csr_aggregate sums them in copy order = scatter order
                 dev = xs.device
                 cache["mean_rowptr"] = (torch.arange(S + 1, device=dev, dtype=torch.int32) * copies).contiguous()

@@ -6,10 +6,11 @@
 in the hand-written gfx950 kernels of libgnnpn_hip.so (``ops.py``); torch modules are used here
 only as parameter containers.
 
-Scope of this build = the inference configuration the reference ships
+Scope of this build = the configuration the reference ships
 (/root/reference/environment.ini:49-79, src/models/trainPNHigh.py:208-236):
-``embedding_size=0``, ``n_glimpses=0``, ``attention='Dot'``, ``sample='greedy'``.  Anything else
-raises ``NotImplementedError`` (sampling / training are SURVEY.md §8f "next" rows).
+``embedding_size=0``, ``n_glimpses=0``, ``attention='Dot'``; ``sample='greedy'`` (the inference path) and the forward of
+the sampling mode (``sample='sample'``: every pick drawn from the window softmax, modelPN.py:227-228 — SURVEY.md §8f
+row 3, forward only).  Anything else raises ``NotImplementedError`` (the REINFORCE backward is the next row).
 """
 import math
 
@@ -97,6 +98,14 @@ class PointerNet(nn.Module):
         self.decoder_start_input = nn.Parameter(torch.FloatTensor(hidden_size))        # :162-163
         self.decoder_start_input.data.uniform_(-(1. / math.sqrt(hidden_size)), 1. / math.sqrt(hidden_size))
         self._packed = None
+        # sampling mode: the reference draws from torch's global generator; here the draws of forward call n come from
+        # the counter-based stream seeded (sample_seed, n) — reproducible, and a function of nothing but the two numbers
+        self.sample_seed = int(torch.initial_seed()) & 0x7FFFFFFF
+        self.sample_calls = 0
+
+    def next_sample_seed(self):
+        self.sample_calls += 1
+        return (self.sample_seed * 1000003 + self.sample_calls) & 0x7FFFFFFFFFFFFFFF
 
     # weights are re-laid-out once (k-major float4 packing for the recurrent kernels)
     def _load_from_state_dict(self, *a, **k):
@@ -157,7 +166,7 @@ class PointerNet(nn.Module):
         return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
             embedded.view(B, L, H)
 
-    def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1, fold=None):
+    def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1, fold=None, sample_seed=None):
         """One entry of the ``nets`` list of ops.pointer_decode (embedded=None: picks are embedded
         in-kernel from the raw rows; fold: the cell's input side uses the folded [4H,8] matrix)."""
         w = self.packed()
@@ -167,17 +176,20 @@ class PointerNet(nn.Module):
              "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from}
         if fold and embedded is None:
             d.update(xw_fold=w["dec_wfold"], xb_fold=w["dec_bfold"], start_fold=w["dec_sfold"])
+        if sample_seed is not None:
+            d.update(sample=True, sample_seed=int(sample_seed))
         return d
 
     @torch.no_grad()
-    def run(self, inputs, latent=None, want_queries=False, fold=None):
-        """Encode + greedy decode; returns the decode dict of ops.pointer_decode plus enc_out."""
+    def run(self, inputs, latent=None, want_queries=False, fold=None, sample_seed=None):
+        """Encode + decode (greedy, or with ``sample_seed`` every pick drawn from the window softmax); returns the decode
+        dict of ops.pointer_decode plus enc_out."""
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
         enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
         out = custom_ops.pointer_decode(
             [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
-                              _window_tensor(latent, self.serCategory, self.serNumber), fold=fold)],
+                              _window_tensor(latent, self.serCategory, self.serNumber), fold=fold, sample_seed=sample_seed)],
             inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
         out["enc_out"] = enc[0]
         return out
@@ -185,9 +197,8 @@ class PointerNet(nn.Module):
     def forward(self, inputs, latent, sample="sample"):
         """(probs, idxs, logits) lists as PointerNet.forward returns them (:241).  probs / logits
         are lazily materialised full-length views (see LatentWindows)."""
-        if sample != "greedy":
-            raise NotImplementedError("only sample='greedy' (the inference path, trainPNHigh.py:138-139)")
-        out = self.run(inputs, latent, want_queries=True)
+        out = self.run(inputs, latent, want_queries=True,
+                       sample_seed=None if sample == "greedy" else self.next_sample_seed())      # :225-228
         lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.C, self.use_tanh)
         idxs = [out["idx"][:, k].long() for k in range(self.serCategory)]
         return _ProbList(out, latent, self.serCategory, self.serNumber), idxs, lat
@@ -259,9 +270,8 @@ class CombinatorialRL(nn.Module):
     @torch.no_grad()
     def forward(self, inputs, labs, latent=None, sample="sample", training="RL"):
         """-> (R | probs, action_probs T x [B], actions T x [B,8], action_idxs T x [B] int64, latent_p)."""
-        if sample != "greedy":
-            raise NotImplementedError("only sample='greedy' (the inference path, trainPNHigh.py:138-139)")
-        out = self.actor.run(inputs, latent, want_queries=True)
+        out = self.actor.run(inputs, latent, want_queries=True,
+                             sample_seed=None if sample == "greedy" else self.actor.next_sample_seed())   # modelPN.py:225-228
         T = self.serCategory
         action_idxs = [out["idx"][:, k].long() for k in range(T)]
         actions = [out["actions"][:, k, :] for k in range(T)]                       # :293-295
@@ -276,7 +286,8 @@ class CombinatorialRL(nn.Module):
 
 
 @torch.no_grad()
-def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=0, lds_kb=0, write_through=False, ws=None):
+def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=0, lds_kb=0, write_through=False, ws=None,
+                     sample_high_seed=None):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
@@ -284,6 +295,8 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     win_high_raw + win_low (modelPN.py:216).
     precision: "f32" (default) | "split" (fp16 hi+lo operands in both W_hh.h products, fp32 accumulate: measured as
     accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
+    sample_high_seed: the High level DRAWS its picks from that stream instead of taking the argmax — the forward of the
+    PNHigh training step (trainPNHigh.py:83-84: Low greedy -> latent, High sample='sample'); the Low level stays greedy.
     decode_impl / lds_kb / write_through / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,
     ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
@@ -301,7 +314,8 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     enc, h_n, c_n = custom_ops.lstm_encode([enc_l, enc_h], precision=precision, lds_kb=lds_kb, write_through=write_through, ws=ws)
     del enc_l, enc_h
     dl, dh = custom_ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
-                                 ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold)],
+                                 ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold,
+                                                sample_seed=sample_high_seed)],
                                 inputs, la.serCategory, la.serNumber, la.C, la.use_tanh,
                                 precision="split" if precision == "split" else "f32", impl=decode_impl, lds_kb=lds_kb,
                                 write_through=write_through, ws=ws)

@@ -44,12 +44,28 @@ def embed_concat(x, table):
     return out
 
 
-def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE):
-    """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32)."""
+LDS_BLOCK_ROWS_MAX = 10240      # block_rows * 16 B <= 160 KB
+LDS_MIN_WORKGROUPS = 128        # below this many (block, slice) workgroups the one-wave-per-row gather fills the chip better
+
+
+def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
+    """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
+    ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
+    records it): the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a block fits the LDS and there
+    are enough (block, slice) workgroups to fill the chip; the results are bit-identical either way."""
     x = _rows2d(x, "csr_aggregate.x")
     n = rowptr.numel() - 1
     C = x.shape[1]
     y = torch.empty((n, C), dtype=F32, device=x.device)
+    if 0 < block_rows <= LDS_BLOCK_ROWS_MAX and C % 4 == 0:
+        lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and block_rows * 16 * c <= 160 * 1024)
+        if -(-n // block_rows) * (C // (4 * lpr)) >= LDS_MIN_WORKGROUPS:
+            check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
+                dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
+                dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
+                dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act, dev_ptr(y, F32, "y"), C, n, C,
+                int(block_rows), stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
+            return y
     check(_lib.load().gnnpn_csr_aggregate_f32(
         dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
         dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
@@ -333,7 +349,8 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
 
     nets: list of dicts with keys enc_out, h0, c0, start, wih, whh, bih, bhh, EITHER embedded [B,L,H]
     OR emb_w [H,8] + emb_b [H] (picked rows embedded in-kernel), and optionally latent_win ([B,T,K]
-    tensor computed earlier) or latent_from (index of an earlier net of this call).
+    tensor computed earlier) or latent_from (index of an earlier net of this call), and optionally sample=True +
+    sample_seed (the pick of every step is drawn from the window softmax: gnnpn_decode_net_t.sample).
     Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
     queries [B,T,H] | None.
     precision="split": the W_hh.h product with fp16 hi+lo operands (cooperative, folded form only); "f16" is an
@@ -375,6 +392,8 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         lw = d.get("latent_win")
         a.latent_win = None if lw is None else dev_ptr(lw, F32, f"nets[{i}].latent_win").value
         a.latent_from = int(d.get("latent_from", -1))
+        a.sample = int(bool(d.get("sample", False)))
+        a.sample_seed = int(d.get("sample_seed", 0)) & 0xFFFFFFFFFFFFFFFF
         a.idx = dev_ptr(out["idx"], I32, "idx").value
         a.win_logits = dev_ptr(out["win_logits"], F32, "win").value
         a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value

@@ -74,6 +74,20 @@ int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col, const flo
                             const float* scale, const float* shift, int act, float* y, int64_t ldy,
                             int32_t n_rows, int32_t C, void* stream);
 
+/* The same aggregate for BLOCK-LOCAL graphs with the node features staged in LDS: the caller promises that every edge
+ * whose destination row lies in block b = [b*block_rows, (b+1)*block_rows) has its source row in the same block — a batch of
+ * B service graphs (B block-diagonal copies of the table, src/models/trainML.py:109-114, modelML.py:145-156) with
+ * block_rows = S, or a single graph with block_rows = n_rows.  One workgroup per (block, channel slice) copies the block's
+ * slice into LDS once and serves all gathers from there (each source element crosses L2 -> CU once instead of once per
+ * neighbour); same CSR-order sums, same epilogue, bit-identical results.
+ * GNNPN_E_UNSUP (nothing enqueued) when a block does not fit: block_rows * 16 B > 160 KB (block_rows > 10240), or rows
+ * not 16-byte aligned; callers then use gnnpn_csr_aggregate_f32.
+ * Replaces: GCNConv.propagate over the batched service graph, src/models/modelML.py:153. */
+int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, const float* w,
+                                   const float* x, int64_t ldx, const float* self_coef, const float* bias,
+                                   const float* scale, const float* shift, int act, float* y, int64_t ldy,
+                                   int32_t n_rows, int32_t C, int32_t block_rows, void* stream);
+
 /* GCN symmetric normalisation on a destination-major CSR that already contains one self-loop
  * entry per node (add_remaining_self_loops, fill 1): deg[i] = sum of w_raw over row i (CSR order),
  * dis = deg^-1/2 (inf -> 0), norm[e] = dis[src[e]] * w_raw[e] * dis[dst[e]].
@@ -248,6 +262,14 @@ int gnnpn_set_option(const char* name, int value);
  *               logits are used instead (the two-level scheme of trainPNHigh.py:138-139), or -1
  *   outputs: idx [B,T] int32; win_logits [B,T,n_per] (C*tanh(dot), before the latent is added);
  *            pick_prob [B,T] softmax prob of the pick; actions [B,T,8]; queries [B,T,H] or NULL.
+ *   sample = 1: the pick of step k is DRAWN from the window softmax (the reference's probs.multinomial(1),
+ *            src/models/modelPN.py:227-228; its re-draw loop :229-234 cannot trigger because the step windows are
+ *            disjoint): p_r = softmax over the window, cdf_r = p_0 + ... + p_r (fp32, in order), u = draw (b*T + k) of
+ *            the counter-based stream of sample_seed — splitmix64(sample_seed + (b*T + k + 1) * 0x9E3779B97F4A7C15) >> 40,
+ *            times 2^-24 — and the pick is the first r with u < cdf_r (the last r with p_r > 0 if rounding leaves none).
+ *            pick_prob is then the probability of the drawn candidate (CombinatorialRL.forward :297-299).  The
+ *            reference draws from torch's global generator; tests route its multinomial to this stream (oracle/pn.py).
+ *            Built in the streaming and the 8-CU-group cooperative forms (fp32); GNNPN_E_UNSUP elsewhere.
  * inputs [B,L,8] : rows gathered into `actions`.   nets: HOST array of n_nets (1 or 2) structs.
  * Two implementations: cooperative (H = 256, n_per <= 16, workspace given: 8-CU groups keep both
  * weight matrices in registers; both nets in one launch, the High net one step behind the Low net)
@@ -278,7 +300,8 @@ typedef struct {
     float* actions;
     float* queries;
     int32_t latent_from;
-    int32_t reserved;
+    int32_t sample;          /* 0: greedy, first-max argmax (modelPN.py:226); 1: multinomial draw (:228), see below */
+    uint64_t sample_seed;    /* stream of the draws of this net in this call */
 } gnnpn_decode_net_t;
 
 /* precision: GNNPN_PREC_F32 or GNNPN_PREC_SPLIT (the decoder cell's W_hh.h product; cooperative, folded form). */

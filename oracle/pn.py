@@ -69,9 +69,52 @@ def lstm_cell_explicit(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return h2, c2
 
 
+_M64 = (1 << 64) - 1
+
+
+def stream_uniform24(seed, ctr):
+    """Draw ``ctr`` of the counter-based stream of ``seed`` (splitmix64 finaliser, as oracle/woa.py's stream) as a 24-bit
+    uniform in [0,1): what the sampling mode of the HIP decoder uses (include/gnnpn_hip.h, gnnpn_decode_net_t.sample)."""
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(ctr) + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    z ^= z >> 31
+    return np.float32((z >> 40) * (1.0 / (1 << 24)))
+
+
+def multinomial_from_stream(probs, k, n_cat, n_per, seed):
+    """What ``probs.multinomial(num_samples=1)`` (modelPN.py:228) is routed to, so that a sampled forward is a pure
+    function of (weights, inputs, seed): probs [B,L] is zero outside step k's window; per problem b the window's running
+    sum cdf_r = p_0 + ... + p_r is formed in fp32 in candidate order, u = draw (b*T + k) of the stream, and the pick is
+    the first r with u < cdf_r (the last r with p_r > 0 should rounding leave none).
+    Returns (idx [B] int64 global positions, margin [B] = distance of u to the nearest cdf boundary that could change
+    the pick — a draw with a tiny margin is fragile the way a near-tie is for the argmax)."""
+    B = probs.shape[0]
+    win = probs[:, k * n_per:(k + 1) * n_per].numpy().astype(np.float32)
+    idx = np.zeros(B, np.int64)
+    margin = np.zeros(B, np.float32)
+    for b in range(B):
+        u = stream_uniform24(seed, b * n_cat + k)
+        cdf, pick, last_pos, bounds = np.float32(0.0), -1, 0, []
+        for r in range(n_per):
+            cdf = np.float32(cdf + win[b, r])
+            if win[b, r] > 0:
+                last_pos = r
+            if r < n_per - 1:
+                bounds.append(cdf)
+            if pick < 0 and u < cdf:
+                pick = r
+        if pick < 0:
+            pick = last_pos
+        idx[b] = k * n_per + pick
+        margin[b] = min([abs(float(u) - float(c)) for c in bounds], default=float("inf"))
+    return torch.from_numpy(idx), torch.from_numpy(margin)
+
+
 @torch.no_grad()
-def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True):
-    """PointerNet.forward, greedy, 'Dot' attention, n_glimpses=0 (modelPN.py:175-241).
+def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True, sample_seed=None, draw_margins=None):
+    """PointerNet.forward, 'Dot' attention, n_glimpses=0 (modelPN.py:175-241); greedy, or with ``sample_seed`` the sampling
+    mode (:227-228) with the draws taken from the counter-based stream (multinomial_from_stream).
 
     inputs  [B, L, 8] fp32 with L = n_cat * n_per (assert at modelPN.py:182)
     latent  None (Low net) or list of n_cat [B, L] tensors = the Low net's returned logits
@@ -106,7 +149,12 @@ def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True
         biased[:, : k * n_per] = NEG_INF                                                    # :220-222
         biased[:, (k + 1) * n_per:] = NEG_INF
         probs = F.softmax(biased, dim=1)                                                    # :224
-        _, idx = torch.max(probs, dim=1)                                                    # :226 (first max wins)
+        if sample_seed is None:
+            _, idx = torch.max(probs, dim=1)                                                # :226 (first max wins)
+        else:
+            idx, m = multinomial_from_stream(probs, k, n_cat, n_per, sample_seed)           # :228; the re-draw of :229-234
+            if draw_margins is not None:                                                    # cannot trigger: windows are disjoint
+                draw_margins.append(m)
         x = embedded[rows, idx, :]                                                          # :235
         all_probs.append(probs)
         all_idx.append(idx)
@@ -150,10 +198,10 @@ def reward(actions, level="High", tag=0):
 
 @torch.no_grad()
 def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", training="RL",
-                          C=10.0, use_tanh=True):
-    """CombinatorialRL.forward (modelPN.py:282-306), sample='greedy'."""
+                          C=10.0, use_tanh=True, sample_seed=None, draw_margins=None):
+    """CombinatorialRL.forward (modelPN.py:282-306), sample='greedy' (or sampled from the stream of ``sample_seed``)."""
     B = inputs.shape[0]
-    probs, idxs, logits = pointer_forward(sd, inputs, n_cat, n_per, latent, C, use_tanh)
+    probs, idxs, logits = pointer_forward(sd, inputs, n_cat, n_per, latent, C, use_tanh, sample_seed, draw_margins)
     rows = torch.arange(B)
     actions = [inputs[rows, i, :] for i in idxs]                                            # :293-295
     action_probs = [p[rows, i] for p, i in zip(probs, idxs)]                                # :297-299
@@ -164,7 +212,7 @@ def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", tr
 
 
 @torch.no_grad()
-def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=True):
+def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=True, sample_high_seed=None):
     """The eval block of trainPNHigh.py:138-139: Low greedy ("SL") -> latent -> High greedy ("RL").
 
     Returns dict with idx_low/idx_high [B,T] int64, R [B] fp32, actions [B,T,8], action_probs [B,T],
@@ -174,8 +222,9 @@ def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=Tru
     B, L, _ = inputs.shape
     _, _, _, idx_low, latent = combinatorial_forward(sd_low, inputs, n_cat, n_per, None, "Low", "SL",
                                                      C, use_tanh)
+    draws = [] if sample_high_seed is not None else None      # trainPNHigh.py:83-84: Low greedy -> latent, High sampled
     R, aprob, actions, idx_high, logits_high = combinatorial_forward(
-        sd_high, inputs, n_cat, n_per, latent, "High", "RL", C, use_tanh)
+        sd_high, inputs, n_cat, n_per, latent, "High", "RL", C, use_tanh, sample_high_seed, draws)
     win_low = torch.stack([latent[k][:, k * n_per:(k + 1) * n_per] for k in range(n_cat)], 1)
     win_high = torch.stack([(logits_high[k] + latent[k])[:, k * n_per:(k + 1) * n_per]
                             for k in range(n_cat)], 1)
@@ -183,7 +232,8 @@ def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=Tru
         "idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
         "actions": torch.stack(actions, 1), "action_probs": torch.stack(aprob, 1),
         "win_low": win_low, "win_high": win_high,
-        "margin_low": decision_margin(win_low, inputs), "margin_high": decision_margin(win_high, inputs),
+        "margin_low": decision_margin(win_low, inputs),
+        "margin_high": decision_margin(win_high, inputs) if draws is None else torch.stack(draws, 1),
         "latent": latent,
     }
 

@@ -104,6 +104,54 @@ def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0, weight_scale=1.0):
           f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
 
 
+def gen_pn_sample(modelPN, name, H, T, K, B, seed, sample_seed):
+    """The sampling mode (modelPN.py:227-228) of the REAL reference — Low greedy -> latent, High with sample='sample', the
+    forward of a PNHigh training step (trainPNHigh.py:83-84) — with ``Tensor.multinomial`` routed to the counter-based
+    stream (oracle.pn.multinomial_from_stream), which makes the run a function of (weights, inputs, seed).  Also checks
+    that the reference's re-draw branch (:229-234) never fires (it prints ' RESAMPLE!')."""
+    sd_low, sd_high = opn.make_state_dict(H, seed), opn.make_state_dict(H, seed + 1)
+    L = T * K
+
+    def build(level, sd):
+        m = modelPN.CombinatorialRL(0, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+
+    low, high = build("Low", sd_low), build("High", sd_high)
+    x = pn_inputs(B, T, K, seed + 2)
+    state = {"k": 0}
+    real = torch.Tensor.multinomial
+
+    def routed(self, num_samples=1, replacement=False, generator=None):
+        assert num_samples == 1
+        idx, _ = opn.multinomial_from_stream(self, state["k"], T, K, sample_seed)
+        state["k"] += 1
+        return idx.view(-1, 1)
+
+    torch.Tensor.multinomial = routed
+    buf = io.StringIO()
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(buf):
+            _, _, _, idx_low, latent = low(x, None, sample="greedy", training="SL")
+            R, probs, actions, idx_high, _ = high(x, None, latent)            # default sample="sample", training="RL"
+    finally:
+        torch.Tensor.multinomial = real
+    assert state["k"] == T and "RESAMPLE" not in buf.getvalue()
+    ref = {"idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
+           "actions": torch.stack(actions, 1), "action_probs": torch.stack(probs, 1)}
+    orc = opn.two_level_greedy(sd_low, sd_high, x, T, K, sample_high_seed=sample_seed)
+    for key in ref:
+        assert torch.equal(ref[key], orc[key]), f"oracle != reference on {key} ({name})"
+    greedy = opn.two_level_greedy(sd_low, sd_high, x, T, K)
+    frac = float((greedy["idx_high"] != ref["idx_high"]).float().mean())
+    out = {k: v.numpy() for k, v in ref.items()}
+    out.update(hidden=H, n_cat=T, n_per=K, B=B, seed_low=seed, seed_high=seed + 1, seed_inputs=seed + 2,
+               sample_seed=sample_seed, margin_low=orc["margin_low"].numpy(), margin_high=orc["margin_high"].numpy())
+    np.savez_compressed(os.path.join(HERE, f"pn_sample_{name}.npz"), **out)
+    print(f"pn_sample_{name}: B={B} T={T} K={K} H={H}: {frac:.2f} of the sampled picks differ from the greedy ones; "
+          f"min draw margin {float(orc['margin_high'].min()):.2e}")
+
+
 def gen_reward(modelPN):
     """reward/calc known-answer cases (modelPN.py:15-72)."""
     rng = np.random.default_rng(7)
@@ -301,6 +349,8 @@ def main():
     gen_pn(modelPN, "qws", H=256, T=47, K=5, B=8, seed=31)
     gen_pn(modelPN, "normal", H=256, T=50, K=10, B=4, seed=41)
     gen_pn(modelPN, "saturated", H=256, T=12, K=5, B=8, seed=51, weight_scale=6.0)
+    gen_pn_sample(modelPN, "small", H=32, T=6, K=3, B=8, seed=91, sample_seed=12345)
+    gen_pn_sample(modelPN, "qws", H=256, T=47, K=5, B=64, seed=95, sample_seed=987654321)
     gen_reward(modelPN)
     gen_data(loadData_mod, ML2PN_mod)
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)

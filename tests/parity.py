@@ -69,7 +69,10 @@ def assert_index_parity(got, want, robust, what, min_agree=0.9, rows=None):
     return same
 
 
-def prefix_parity(got_low, got_high, fx, what, rows=None):
+TAU_DRAW = 1e-5    # sampling mode: distance of the uniform draw to the nearest cdf boundary below which a draw is fragile
+
+
+def prefix_parity(got_low, got_high, fx, what, rows=None, tau_high=None):
     """Step-by-step parity for ONE batch against a reference fixture / oracle result holding idx_low, idx_high,
     margin_low, margin_high [B,T]: a problem is followed while its history equals the reference's; at its FIRST
     differing decision the reference's margin there must be <= TAU (a fragile decision: the flip is classified, and
@@ -95,11 +98,12 @@ def prefix_parity(got_low, got_high, fx, what, rows=None):
         for lvl, d, m in (("low", dl, ml), ("high", dh, mh)):
             if d[b, t]:
                 flips.append({"problem": int(b), "step": t, "level": lvl, "margin": float(m[b, t])})
-                if not m[b, t] <= TAU:
+                if not m[b, t] <= (TAU if lvl == "low" or tau_high is None else tau_high):
                     bad.append(flips[-1])
     assert not bad, f"{what}: decisions with a margin above {TAU} differ from the reference: {bad[:5]}"
-    robust = (ml > TAU).all(1) & (mh > TAU).all(1)
-    frag = (ml <= TAU) | (mh <= TAU)
+    th = TAU if tau_high is None else tau_high
+    robust = (ml > TAU).all(1) & (mh > th).all(1)
+    frag = (ml <= TAU) | (mh <= th)
     robust_prefix = np.where(frag.any(1), frag.argmax(1), T)
     return {"problems": int(B), "steps": int(T), "identical_problems": int((first == T).sum()),
             "robust_problems": int(robust.sum()), "robust_identical": int(((first == T) & robust).sum()),

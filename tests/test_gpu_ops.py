@@ -291,3 +291,49 @@ def test_request_branch_equals_layered(dev, B, n_t, n_gin):
         flat = [lp[k] for lp in p["gin"] for k in ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")]
         torch.ops.gnnpn.request_branch(batch.x, p["node_table"], batch.wf_csr.rowptr, batch.wf_csr.col, batch.seg_ptr, 17,
                                        flat, p["nodeLin_p"], p["nodeLin"][1], 128)
+
+
+@pytest.mark.parametrize("S,copies,C,weighted,self_loop", [(40, 3, 256, True, False), (2507, 9, 256, True, False),
+                                                            (300, 17, 128, False, True), (5000, 2, 256, True, False),
+                                                            (9000, 1, 64, True, False), (97, 5, 24, True, True)])
+def test_csr_aggregate_lds_staged_equals_gather(dev, S, copies, C, weighted, self_loop):
+    """gnnpn_csr_aggregate_blocks_f32 (node features of a block staged in LDS, one workgroup per (block, channel slice):
+    16-, 8- and 4-channel slices by block size) against gnnpn_csr_aggregate_f32 on block-diagonal copies of a random
+    weighted graph: bit-identical, with and without edge weights / the GIN self term, ragged last block included."""
+    import ctypes
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd import _lib, graph
+    from gnnpn_sc_amd._lib import check, dev_ptr, stream_ptr
+    ops = _ops()
+    table = synth.make_service_table(5, S, 1, degree=12)
+    csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
+    nnz = csr.col.numel()
+    n = copies * S - (S // 3 if copies > 1 else 0)                # ragged: the last block is shorter
+    rp_full = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])])
+    col_full = torch.cat([csr.col.long() + c * S for c in range(copies)])
+    w_full = csr.w.repeat(copies)
+    keep = (col_full < n)[: int(rp_full[n])]                      # drop edges whose source fell off the ragged end
+    seg = torch.repeat_interleave(torch.arange(n), (rp_full[1:n + 1] - rp_full[:n]))
+    cnt = torch.bincount(seg[keep], minlength=n)
+    rp = torch.zeros(n + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(cnt, 0)
+    col = col_full[: int(rp_full[n])][keep].int().to(dev)
+    w = w_full[: int(rp_full[n])][keep].to(dev) if weighted else None
+    rp = rp.to(dev)
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(n, C, generator=g).to(dev)
+    bias, scale, shift = (torch.randn(C, generator=g).to(dev) for _ in range(3))
+    eps = torch.tensor([0.125], device=dev) if self_loop else None
+    want = ops.csr_aggregate(rp, col, w, x, self_coef=eps, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)
+    y = torch.empty_like(x)
+    rc = _lib.load().gnnpn_csr_aggregate_blocks_f32(
+        dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), dev_ptr(w, torch.float32, "w", True),
+        dev_ptr(x, torch.float32, "x"), C, dev_ptr(eps, torch.float32, "eps", True), dev_ptr(bias, torch.float32, "b"),
+        dev_ptr(scale, torch.float32, "s"), dev_ptr(shift, torch.float32, "t"), ops.ACT_RELU, dev_ptr(y, torch.float32, "y"),
+        C, n, C, S, stream_ptr())
+    check(rc, "gnnpn_csr_aggregate_blocks_f32")
+    assert torch.equal(y, want)
+    rc = _lib.load().gnnpn_csr_aggregate_blocks_f32(
+        dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), None, dev_ptr(x, torch.float32, "x"), C, None, None, None,
+        None, 0, dev_ptr(y, torch.float32, "y"), C, n, C, 20000, stream_ptr())
+    assert rc == -2                                               # a block that cannot fit the LDS is refused (GNNPN_E_UNSUP)

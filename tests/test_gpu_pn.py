@@ -90,8 +90,8 @@ def test_unsupported_modes_fail_loudly(dev):
     with pytest.raises(NotImplementedError):
         CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Bahdanau", 3, 6)
     m = CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)
-    with pytest.raises(NotImplementedError):
-        m(torch.rand(2, 18, 8, device=dev), None)           # default sample="sample"
+    R, probs, actions, idxs, _ = m(torch.rand(2, 18, 8, device=dev), None)   # default sample="sample": the sampling forward
+    assert R.shape == (2,) and len(idxs) == 6 and probs[0].shape == (2,)
     with pytest.raises(AssertionError):
         m(torch.rand(2, 17, 8, device=dev), None, sample="greedy")   # seq_len assert (modelPN.py:182)
 
@@ -357,3 +357,51 @@ def test_split_precision_refuses_weights_outside_fp16_range(dev):
             two_level_greedy(low, high, x, precision=precision)
     two_level_greedy(low, high, x)      # plain fp32 takes any finite weight
     ops.check_status(dev)
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_sampling_mode_forward_golden(dev, name):
+    """sample='sample' — every pick DRAWN from the window softmax inside the decode
+    kernel (modelPN.py:227-228) — against fixtures produced by the real modelPN.py with Tensor.multinomial routed to the
+    same counter-based stream.  Low greedy -> latent -> High sampled, exactly the forward of a PNHigh training step
+    (trainPNHigh.py:83-84).  Picks are identical until a problem's first FRAGILE decision (a Low near-tie, or a High
+    draw within 1e-5 of a cdf boundary); action_probs (the log-prob gather of :297-299) within 1e-5."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    from parity import TAU_DRAW, assert_R_parity, prefix_parity
+    from pn_inputs import pn_inputs
+    fx = golden(f"pn_sample_{name}.npz")
+    low, high = build(fx, dev)
+    T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"])).to(dev)
+    seed = int(fx["sample_seed"])
+    out = two_level_greedy(low, high, x, sample_high_seed=seed)
+    ops.check_status(dev)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, f"sample/{name}", x.cpu(), tau_high=TAU_DRAW)
+    s = rec["same_mask"]
+    assert rec["identical_problems"] >= B - 2 and rec["robust_identical"] == rec["robust_problems"] > 0
+    assert np.abs(out["action_probs"].cpu().numpy()[s] - fx["action_probs"][s]).max() < 1e-5
+    assert np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
+    assert_R_parity(out["R"], fx["R"], f"sample/{name}", s)
+    # the reference's own entry points: CombinatorialRL.forward with its default sample="sample"
+    high.actor.sample_seed, high.actor.sample_calls = 5, 0
+    _, _, _, _, latent = low(x, None, sample="greedy", training="SL")
+    R1, probs1, actions1, idx1, _ = high(x, None, latent)                        # call 1 of the stream (5, ...)
+    R2, _, _, idx2, _ = high(x, None, latent)                                    # call 2: new draws
+    high.actor.sample_calls = 0
+    R3, probs3, _, idx3, _ = high(x, None, latent)                               # call 1 again: the same draws
+    assert torch.equal(torch.stack(idx1), torch.stack(idx3)) and torch.equal(R1, R3) and torch.equal(torch.stack(probs1), torch.stack(probs3))
+    assert not torch.equal(torch.stack(idx1), torch.stack(idx2))
+    assert len(probs1) == T and probs1[0].shape == (B,) and idx1[0].dtype == torch.int64
+    p = torch.stack(probs1, 1)
+    assert bool(((p > 0) & (p <= 1)).all())
+    greedy = two_level_greedy(low, high, x)
+    assert float((greedy["idx_high"] != out["idx_high"]).float().mean()) > 0.3  # the draws are not the argmax
+    # empirical distribution of step 0 over many seeds ~ the window softmax of step 0 (first problem)
+    if name == "small":
+        counts = torch.zeros(K)
+        for sd in range(300):
+            o = two_level_greedy(low, high, x[:1], sample_high_seed=1000 + sd)
+            counts[int(o["idx_high"][0, 0])] += 1
+        want = torch.softmax((greedy["win_high_raw"] + greedy["win_low"])[0, 0].cpu(), 0)
+        assert float((counts / 300 - want).abs().max()) < 0.12

@@ -191,3 +191,27 @@ def test_ml_oracle_batched_forward_reproduces_reference_glue():
                                                t("edge_index_service"), t("edge_attr_service")), int(fx["n_gin"]), int(fx["n_gcn"]))
     assert float((single - t("scores_single_copy")).abs().max()) <= 1e-6
     assert float((single - t("scores")).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_pn_oracle_sampling_mode_reproduces_reference(name):
+    """pn_sample_*.npz: the real modelPN.py in sampling mode (Low greedy -> latent, High sample='sample', the forward of a
+    PNHigh training step) with Tensor.multinomial routed to the counter-based stream.  The oracle's sampled forward
+    reproduces picks, action_probs and R; the draws really differ from the argmax."""
+    from parity import TAU_DRAW, assert_R_parity, prefix_parity
+    from pn_inputs import pn_inputs
+    fx = golden(f"pn_sample_{name}.npz")
+    torch.set_num_threads(1)
+    H, T, K, B = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
+    out = opn.two_level_greedy(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])), x, T, K,
+                               sample_high_seed=int(fx["sample_seed"]))
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, name, x, tau_high=TAU_DRAW)
+    assert rec["identical_problems"] >= B - 1
+    s = rec["same_mask"]
+    assert np.allclose(out["action_probs"].numpy()[s], fx["action_probs"][s], rtol=0, atol=1e-6)
+    assert_R_parity(out["R"], fx["R"], name, s)
+    greedy = opn.two_level_greedy(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])), x, T, K)
+    assert float((greedy["idx_high"].numpy() != fx["idx_high"]).mean()) > 0.3
+    u = [float(opn.stream_uniform24(7, c)) for c in range(4000)]
+    assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.02      # the stream is a sane uniform

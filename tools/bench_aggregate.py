@@ -1,55 +1,78 @@
-"""HBM roofline of the CSR gather-aggregate kernel on the reference's own batching of the service
-graph: a PyG batch of B problems holds B block-diagonal copies of the service graph
-(trainML.py:109-114, modelML.py:145-156), i.e. one GCN aggregate over B*S rows.  The product path
-evaluates the service branch once per forward; this "replicated" mode exists only to
-load the kernel to the point where HBM, not launch latency, is the bound.
+"""HBM roofline of the CSR gather-aggregate on the reference's own batching of the service graph: a PyG batch of B problems
+holds B copies of the service table (trainML.py:109-114, modelML.py:145-156), i.e. one GCN aggregate over B*S rows per
+layer.  Times both forms on the same operands and checks that they agree bit for bit:
+  gather : gnnpn_csr_aggregate_f32        (one wave per destination row, source rows gathered from L2)
+  lds    : gnnpn_csr_aggregate_blocks_f32 (north star "node features staged in LDS": one workgroup per (copy, channel slice))
 
-    python tools/bench_aggregate.py [--S 2507] [--copies 256] [--degree 32]
+    python tools/bench_aggregate.py [--configs S:copies,...] [--degree 32]
 
-Algorithmic bytes per launch (SURVEY §8d): 2*N*C*4 + E*(4+4) + (N+1)*4, N = copies*S, C = 256.
+Algorithmic bytes per launch (SURVEY.md section 8d): 2*N*C*4 + E*(4+4) + (N+1)*4, N = copies*S, C = 256.
 """
 import argparse, json, os, sys
-import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gnnpn_sc_amd import graph, ops, synth
+from gnnpn_sc_amd import _lib, graph, ops, synth
+from gnnpn_sc_amd._lib import check, dev_ptr, stream_ptr
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--S", type=int, default=2507)
-ap.add_argument("--copies", type=int, default=256)
+ap.add_argument("--configs", default="2507:256,2507:64,5000:128,5000:32,10000:32,20000:8")
 ap.add_argument("--degree", type=int, default=32)
 ap.add_argument("--reps", type=int, default=20)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-table = synth.make_service_table(47, a.S, 0, degree=a.degree)
-csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), a.S)
-nnz = csr.col.numel()
-# block-diagonal replication: rowptr/col offset per copy
-rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(a.copies)] + [torch.tensor([a.copies * nnz])]).int()
-col = torch.cat([csr.col.long() + c * a.S for c in range(a.copies)]).int()
-w = csr.w.repeat(a.copies)
-N, C = a.copies * a.S, 256
-rp, col, w = rp.to(dev), col.to(dev), w.to(dev)
-norm = ops.gcn_norm(rp, col, w)
-x = torch.randn(N, C, device=dev)
-bias = torch.randn(C, device=dev)
-scale, shift = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
-for _ in range(3):
-    y = ops.csr_aggregate(rp, col, norm, x, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(a.reps):
-    y = ops.csr_aggregate(rp, col, norm, x, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / a.reps
-alg = 2 * N * C * 4 + col.numel() * 8 + (N + 1) * 4
-# one copy checked against the single-graph result (bit-exact: same CSR order)
-y1 = ops.csr_aggregate(csr.rowptr.to(dev), csr.col.to(dev), norm[:nnz].contiguous(), x[:a.S].contiguous(), bias=bias,
-                       scale=scale, shift=shift, act=ops.ACT_RELU)
-assert torch.equal(y[:a.S], y1)
-print(json.dumps({"kernel": "csr_aggregate_kernel<true> (GCN layer, bias+BN+ReLU epilogue)", "rows": N, "channels": C,
-                  "nnz": int(col.numel()), "ms": round(ms, 4), "algorithmic_bytes": alg,
-                  "achieved_GBps": round(alg / ms / 1e6, 1), "peak_GBps": 8000.0,
-                  "frac_of_spec": round(alg / ms / 1e6 / 8000.0, 4), "frac_of_measured_copy_6290": round(alg / ms / 1e6 / 6290.0, 4)}))
+F32, I32 = torch.float32, torch.int32
+
+
+def blocks_form(rp, col, w, x, bias, scale, shift, S):
+    n, C = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
+        dev_ptr(rp, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w"), dev_ptr(x, F32, "x"), C, None,
+        dev_ptr(bias, F32, "b"), dev_ptr(scale, F32, "s"), dev_ptr(shift, F32, "t"), ops.ACT_RELU, dev_ptr(y, F32, "y"), C, n, C,
+        S, stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
+    return y
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+out = []
+for cfg in a.configs.split(","):
+    S, copies = (int(v) for v in cfg.split(":"))
+    table = synth.make_service_table(47, S, 0, degree=a.degree)
+    csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
+    nnz = csr.col.numel()
+    rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
+    col = torch.cat([csr.col.long() + c * S for c in range(copies)]).int().to(dev)
+    w = csr.w.repeat(copies).to(dev)
+    N, C = copies * S, 256
+    norm = ops.gcn_norm(rp, col, w)
+    g = torch.Generator(device=dev).manual_seed(S + copies)
+    x = torch.randn(N, C, device=dev, generator=g)
+    bias = torch.randn(C, device=dev, generator=g)
+    scale, shift = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
+    gather = lambda: ops.csr_aggregate(rp, col, norm, x, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)   # noqa: E731
+    alg = 2 * N * C * 4 + nnz * copies * 8 + (N + 1) * 4
+    rec = {"S": S, "copies": copies, "rows": N, "channels": C, "nnz": nnz * copies, "algorithmic_bytes": alg}
+    ms_g = timed(gather, a.reps)
+    rec["gather"] = {"ms": round(ms_g, 4), "GBps": round(alg / ms_g / 1e6, 1), "frac_of_8TBps": round(alg / ms_g / 8e9, 4)}
+    if S <= ops.LDS_BLOCK_ROWS_MAX:
+        lds = lambda: blocks_form(rp, col, norm, x, bias, scale, shift, S)   # noqa: E731
+        assert torch.equal(lds(), gather()), f"LDS-staged form differs from the gather form at S={S}"
+        ms_l = timed(lds, a.reps)
+        rec["lds"] = {"ms": round(ms_l, 4), "GBps": round(alg / ms_l / 1e6, 1), "frac_of_8TBps": round(alg / ms_l / 8e9, 4),
+                      "slice_channels": next(4 * c for c in (4, 2, 1) if S * 16 * c <= 160 * 1024), "bit_identical_to_gather": True}
+    out.append(rec)
+    print(json.dumps(rec), flush=True)
+    del rp, col, w, x, norm
+    torch.cuda.empty_cache()
