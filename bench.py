@@ -188,7 +188,8 @@ def self_launch(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    share = os.environ.get("GNNPN_BENCH_SHARE_GPU") == "1"    # launch-path check on a box with fewer GPUs: ranks share
+    if have < n and not share:                                 # GPU (rank % count) and the collective runs over gloo
         raise SystemExit(f"--gpus {n}: this node has {have} GPU(s)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -269,7 +270,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ML+2PN hot path has no CPU implementation")
-    dev = torch.device("cuda", local_rank)
+    share = os.environ.get("GNNPN_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
 
     import gnnpn_sc_amd.synth as synth
@@ -280,7 +282,7 @@ def main():
     force_dist = os.environ.get("GNNPN_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
     use_dist = world > 1 or force_dist
     if use_dist:
-        gdist.init_process_group("nccl", dev)
+        gdist.init_process_group("gloo" if share else "nccl", None if share else dev)
 
     w = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -369,6 +371,10 @@ def main():
     gc.disable()                     # no collector pauses inside the timed region or the timing pass
     for i in range(args.warmup):
         step(i)
+    if os.environ.get("GNNPN_BENCH_DEBUG") and runner is not None:
+        torch.cuda.synchronize()
+        print("[debug] after warm-up:", [(int(x.status[0]), int(x.encode()[:4].view(torch.int32).item())) for x in runner.workspaces],
+              file=sys.stderr, flush=True)
     timers.enabled = not args.graph
     rounds, (idx, R) = timed_rounds(step)
     timers.enabled = False
@@ -485,7 +491,9 @@ def main():
                                      "other in-flight step)"),
                    "service_embedding": "problem-independent GCN branch evaluated once per (weights, service table), "
                                         "outside the step (SURVEY.md section 7)",
-                   "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}"},
+                   "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}",
+                   **({"NOT_A_MEASUREMENT": "GNNPN_BENCH_SHARE_GPU=1: all ranks share one GPU over gloo (launch-path check)"}
+                      if share else {})},
         "roofline": roof, "kernels": kernels,
     }
     if agreement is not None:

@@ -21,17 +21,26 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
     if (sticky) atomicOr(sticky, code);
 }
 
-// ---- same-XCD fast path --------------------------------------------------------------------------
-// The CUs of one XCD share its L2, so a granule stored WITHOUT sc bits (it stays in that L2) is found
-// there by a same-XCD reader's sc1 (L1-bypassing) load ~0.2 us sooner than a write-through store that
-// has to come back from the memory side (measured: 4.87 -> 4.47 us per encoder step).  Across XCDs it
-// would never become visible, and workgroup -> XCD placement is not a contract — so each group
-// ESTABLISHES it at kernel start: every member publishes its HW_REG_XCC_ID through the
-// placement-independent sc1 path, every member reads all G ids, and only if they are all equal does
-// the group use L2-resident stores.  All members read the same G values, so they decide alike.
-constexpr int COOP_STATUS_BYTES = 8192;      // [0,256) status + stamps, [1024, 5120) hello granules
-constexpr int COOP_HELLO_OFFSET = 1024;
-constexpr unsigned COOP_HELLO_TAG = 0x48454c4fu;
+// ---- placement by CLAIM: one workgroup per CU, groups inside one XCD, whatever the dispatcher does ------------------
+// A group's members exchange data every step, so all of them must be resident at once, on different CUs (two members
+// on one CU run at half speed and every peer waits for them) and — for the L2-resident hand-off — on ONE XCD.  HIP promises
+// nothing about where a workgroup lands, and a CU has room for two of these 256-register workgroups: launched on an idle
+// chip, or beside another cooperative launch, the dispatcher puts two workgroups of the SAME launch on some CUs and none on
+// others (round 1 steered it with LDS-footprint padding, which works only while the larger-footprint launch is already
+// resident: a 56 KB launch that starts first still doubles up, and the 100 KB launch after it then waits for CUs that
+// stay full for the whole run of the first — measured: bounded-spin aborts at kernels longer than the spin bound).
+// So placement is ESTABLISHED at run time instead: the launch is over-subscribed (COOP_OVERSUB x the workgroups it needs);
+// every workgroup reads its XCC id and the CU bits of HW_REG_HW_ID (bits [8,16): CU, SH and SE ids — 256 distinct
+// (xcc, bits) keys on the 256 CUs, tools/probes/hwid_census.hip) and claims that CU for this launch with one atomic; a
+// workgroup that finds its CU already claimed, or its XCD already fully staffed, exits at once and frees the slot for the
+// next one.  The k-th claimant of an XCD becomes member k % G of the XCD's group k / G: groups sit on one XCD by
+// construction and no CU holds two members of a launch.  Two such launches on two streams then share every CU one
+// workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
+constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD claim counters, [2048,10240) CU claims
+constexpr int COOP_XCDCNT_OFFSET = 1024;
+constexpr int COOP_CLAIM_OFFSET = 2048;
+constexpr int COOP_OVERSUB = 3;              // launched workgroups per needed workgroup
+constexpr unsigned COOP_SURPLUS_WAIT_TICKS = 1600;   // 16 us of s_memrealtime (100 MHz): how long a surplus workgroup keeps its slot
 
 __device__ __forceinline__ unsigned xcc_id() {
     return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;   // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -45,7 +54,8 @@ __device__ __forceinline__ void granule_publish(u64* p, unsigned tag, float v, b
     else granule_store(p, tag, v);
 }
 
-// Host side: bytes of (unused) dynamic LDS that bring `func`'s footprint to the "coop_lds_kb" option.
+// Host side: bytes of (unused) dynamic LDS that bring `func`'s footprint to gnnpn_launch_opts_t.lds_kb (an extra placement
+// constraint callers may still ask for; not needed for correctness any more).
 inline unsigned coop_lds_padding(const void* func, int target_kb) {
     if (target_kb <= 0) return 0;
     hipFuncAttributes a;
@@ -56,34 +66,55 @@ inline unsigned coop_lds_padding(const void* func, int target_kb) {
     return (unsigned)dyn;
 }
 
-// Called by every thread of the workgroup.  Returns 1 (group on one XCD), 0 (not), -1 (a member did
-// not show up within the spin bound).  `flag` is one int of LDS.
+// Called by every thread of the workgroup.  false: surplus workgroup (leave at once).  `slot` is two ints of LDS.
+// A surplus workgroup that lands on an already claimed CU while the launch is not fully staffed keeps its slot for up to
+// 16 us (or until staffing completes) before it exits: while it sits there the dispatcher can only place the launch's
+// remaining workgroups on CUs that still have room — the unclaimed ones, as soon as whatever fills them (a short kernel
+// of the other stream) has gone — instead of burning them one after the other on the same free slots.  The wait is
+// bounded, so two launches staffing at the same time cannot hold each other's slots for good.
 template <int G>
-__device__ __forceinline__ int group_same_xcd(unsigned* status, int group, int member, int* flag, unsigned spin_limit) {
-    u64* hello = reinterpret_cast<u64*>(reinterpret_cast<char*>(status) + COOP_HELLO_OFFSET) + (size_t)group * G;
+__device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        const unsigned mine = xcc_id();
-        if (lane == 0)
-            __hip_atomic_store(hello + member, ((u64)COOP_HELLO_TAG << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int res = -1;
-        for (unsigned spins = 0; spins <= spin_limit; ++spins) {
-            bool ok = true, same = true;
-            if (lane < G) {
-                const u64 x = granule_load(hello + lane);
-                ok = (unsigned)(x >> 32) == COOP_HELLO_TAG;
-                same = (unsigned)x == mine;
+        const unsigned xcc = xcc_id();
+        unsigned* count = status + COOP_XCDCNT_OFFSET / 4;
+        const unsigned target = (unsigned)(gpx * G);
+        auto staffed = [&]() {
+            bool ok = true;
+            if (lane < 8) ok = __hip_atomic_load(count + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+            return __all(ok);
+        };
+        int g = -1, m = 0;
+        if (!staffed()) {
+            unsigned prev = 0;
+            if (lane == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+                prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + ((xcc << 8) | ((hw >> 8) & 0xffu)), 1u);
+                if (prev == 0u) {                                // the first workgroup of this launch on this CU
+                    const unsigned k = atomicAdd(count + xcc, 1u);
+                    if (k < target) {
+                        g = (int)xcc * gpx + (int)(k / G);
+                        m = (int)(k % G);
+                    }
+                }
             }
-            if (__all(ok)) {
-                res = __all(same) ? 1 : 0;
-                break;
+            g = __shfl(g, 0, 64);
+            m = __shfl(m, 0, 64);
+            if (g < 0) {                                         // surplus: hold the slot briefly (see above)
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (!staffed() && __builtin_amdgcn_s_memrealtime() - t0 < COOP_SURPLUS_WAIT_TICKS)
+                    __builtin_amdgcn_s_sleep(8);
             }
-            __builtin_amdgcn_s_sleep(2);
         }
-        if (lane == 0) *flag = res;
+        if (lane == 0) {
+            slot[0] = g;
+            slot[1] = m;
+        }
     }
     __syncthreads();
-    return *flag;
+    group = slot[0];
+    member = slot[1];
+    return group >= 0;
 }
 
 // value of lane (l ^ 8) within each row of 16 lanes, as a DPP row rotate (no LDS round trip)

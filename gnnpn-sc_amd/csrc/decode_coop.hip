@@ -59,7 +59,7 @@ template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 :
 __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
-                                                                     int n_nets, int groups_per_net, int ablate_arg) {
+                                                                     int n_nets, int groups_per_net, int gpx, int ablate_arg) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
@@ -72,20 +72,15 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, c = lane & 15;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int gpx = (gridDim.x >> 3) / G;
-    const int group = xcd * gpx + slot / G, member = slot % G;
+    __shared__ int place[2];
+    int group, member;
+    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];
     if (tid == 0) abort_flag = 0;
-    __shared__ int xcd_flag;
-    const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
-    if (same < 0) {
-        if (tid == 0) coop_raise(err, sticky, 4u);
-        return;
-    }
-    const bool same_xcd = same == 1 && !(ablate & 128);   // h and partial-dot granules stay inside the group
+    __syncthreads();
+    const bool same_xcd = !(ablate & 128);   // h and partial-dot granules stay inside the group's XCD
     if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
@@ -544,18 +539,18 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
     const int lds_kb = opts.lds_kb;
 #define GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, EVH_)                                                                   \
-    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(groups * G), dim3(256),     \
+    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(COOP_OVERSUB * groups * G), dim3(256),     \
                        coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
-                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, abl)
+                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl)
 #define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
     bool any_sample = false;
     for (int n = 0; n < n_nets; ++n) any_sample |= args.net[n].sample != 0;
     if (any_sample) {
         if (!fold || split || (abl & 32))
             GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the sampling build exists for the folded fp32 input side only");
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false, 1, 1, true>), dim3(groups * G), dim3(256),
+        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false, 1, 1, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),
                            coop_lds_padding((const void*)pointer_decode_coop_kernel<true, false, false, 1, 1, true>, lds_kb), s,
-                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, abl);
+                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl);
         return GNNPN_OK;
     }
     if (shared_cu && (!fold || (abl & 32)))

@@ -41,30 +41,25 @@ template <int NP, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                       u64* __restrict__ xp, u64* __restrict__ xl,
                                                                       unsigned* __restrict__ err, unsigned* __restrict__ sticky,
-                                                                      int n_nets, int groups_per_net, int ablate) {
+                                                                      int n_nets, int groups_per_net, int gpx, int ablate) {
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
     __shared__ float lat[ROWS][KMAX];
     __shared__ int sel[ROWS];
     __shared__ int abort_flag;
-    __shared__ int xcd_flag;
+    __shared__ int place[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, c = lane & 15, gate = c >> 2;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int gpx = (gridDim.x >> 3) / G;
-    const int group = xcd * gpx + slot / G, member = slot % G;
+    int group, member;
+    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];
     if (tid == 0) abort_flag = 0;
-    const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
-    if (same < 0) {
-        if (tid == 0) coop_raise(err, sticky, 4u);
-        return;
-    }
-    const bool same_xcd = same == 1 && !(ablate & 128);
+    __syncthreads();
+    const bool same_xcd = !(ablate & 128);
     if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
@@ -387,13 +382,13 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
 #define GNNPN_DEC2(NP_)                                                                                          \
     do {                                                                                                         \
         if (split)                                                                                               \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(groups * G), dim3(256),           \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),           \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, true>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl);                                 \
         else                                                                                                     \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(groups * G), dim3(256),          \
+            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(COOP_OVERSUB * groups * G), dim3(256),          \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, false>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl);                                 \
     } while (0)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);

@@ -98,7 +98,7 @@ template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                   int32_t B, int32_t L, int n_nets, int groups_per_net,
-                                                                  int ablate_arg) {
+                                                                  int gpx, int ablate_arg) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi tile + lo tile (stride LDH16 halfs)
@@ -107,20 +107,15 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, c = lane & 15;
-    // XCD-aware placement (speed only): blocks with equal blockIdx%8 share an XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int gpx = (gridDim.x >> 3) / G;                 // groups per XCD
-    const int group = xcd * gpx + slot / G, member = slot % G;
+    // placement by claim (coop_common.h): one member per CU, a group's members on one XCD
+    __shared__ int place[2];
+    int group, member;
+    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
-    __shared__ int xcd_flag;
-    const int same = group_same_xcd<G>(err, group, member, &xcd_flag, SPIN_LIMIT);
-    if (same < 0) {
-        if (threadIdx.x == 0) coop_raise(err, sticky, 4u);
-        return;
-    }
-    const bool same_xcd = same == 1 && !(ablate & 128);
+    __syncthreads();
+    const bool same_xcd = !(ablate & 128);
     if (threadIdx.x == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the fast path
 
     const float* __restrict__ pre = PRE ? nets.pregates[net] : nullptr;
@@ -379,9 +374,9 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
-    hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(groups * G), dim3(256),              \
+    hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(COOP_OVERSUB * groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
-                       p_e, p_s, B, L, n_nets, groups_per_net, abl)
+                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl)
     if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
         if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
         GNNPN_ENC(0, false, true);

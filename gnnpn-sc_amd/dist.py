@@ -37,6 +37,8 @@ def all_gather_indices(idx_local, sizes=None):
     """idx_local [b_r, T] int32 -> [sum b_r, T] on every rank, rank order = problem order.
     Equal shards use one all_gather_into_tensor; ragged shards pad to the largest."""
     world = td.get_world_size()
+    if idx_local.is_cuda and td.get_backend() == "gloo":      # launch-path checks without RCCL: stage through the host
+        return all_gather_indices(idx_local.cpu(), sizes).to(idx_local.device)
     if sizes is None or len(set(sizes)) == 1:
         out = torch.empty((world * idx_local.shape[0],) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype,
                           device=idx_local.device)
@@ -58,7 +60,7 @@ def barrier(world):
 def max_over_ranks(value, device, world):
     if world <= 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if td.get_backend() == "gloo" else device)
     td.all_reduce(t, op=td.ReduceOp.MAX)
     return float(t.item())
 

@@ -231,8 +231,10 @@ class Workspaces:
         word = int(self.status[0].item())
         if word != 0:
             self.status.zero_()
+            last = [int(b[:4].view(torch.int32).item()) if b is not None else None for b in (self._encode, self._decode)]
             raise GnnpnError(f"{what}: status {word:#x} — an inter-workgroup hand-off timed out in at least one launch "
-                             "since the last check (its outputs are invalid)")
+                             f"since the last check (its outputs are invalid); bits: 1 encoder sweep, 2 decoder sweep, 4 a "
+                             f"group member never showed up; last launches' own words (encoder, decoder) = {last}")
 
 
 _default_ws = {}

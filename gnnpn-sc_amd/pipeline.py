@@ -185,13 +185,11 @@ class PipelinedRunner:
         # 228 k vs 221 k problems/s in fp32, 353 k vs 316 k with the split precision.
         shared = 4
         self.decode_impl = int(os.environ.get("GNNPN_PIPE_DECODE_IMPL", shared if self.n_slots > 1 else 0))
-        # Placement control for two slots: a CU holds two of the big (256-register) workgroups.  Left to the
-        # dispatcher, two workgroups of the SAME launch can land on one CU (and none on another); whichever kernel
-        # follows on that stream inherits the lopsided slots, so the imbalance persists (measured: 1.15 vs
-        # 1.27-1.42 ms/step, chosen at every restart).  Slot 0's cooperative kernels are padded to 100 KB of LDS
-        # and slot 1's to 56 KB: 100 + 56 fits a CU's 160 KB, 100 + 100 does not.
+        # Placement: the cooperative kernels claim one CU per workgroup at run time (csrc/coop_common.h, coop_place), so
+        # the two slots' launches share every CU one workgroup each whatever the dispatcher does; the LDS-footprint
+        # padding round 1 steered the dispatcher with (100 / 56 KB) is no longer needed and stays as an option only.
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
-        self.lds_kb = [int(v) for v in env.split(",")] if env else ([100, 56] if self.n_slots == 2 else [0] * self.n_slots)
+        self.lds_kb = [int(v) for v in env.split(",")] if env else [0] * self.n_slots
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(self.n_slots)]
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],

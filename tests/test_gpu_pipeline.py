@@ -358,3 +358,35 @@ def test_infer_writes_artifacts_that_check_scores(dev, tmp_path, monkeypatch):
     line = r.stdout.strip().splitlines()[-1].split()
     assert line[0] == "-1" and abs(float(line[1]) - got) < 1e-9                   # same weights, same data -> same score
     assert os.path.exists(p_rank) and os.path.exists(p_act)
+
+
+def test_two_slots_whichever_starts_first(dev):
+    """Placement by claim (csrc/coop_common.h): every cooperative launch staffs all its groups one workgroup per CU no
+    matter what else is resident.  Round 1's LDS-footprint steering only held while slot 0 led; here the two-slot runner
+    is started with slot 1 first, then with slot 0 first, on an idle chip: every launch reports all its members placed
+    (workspace word 1), no hand-off failure, and the results equal the single-stream run."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=4, tasks_per_problem=10), dev)
+    runner = PipelinedRunner(pipe, svc, batch, slots=2)
+    assert runner.lds_kb == [0, 0]                               # no footprint steering
+    ref = pipe.run(svc, batch, decode_impl=runner.decode_impl)
+    for first in (1, 0, 1):
+        torch.cuda.synchronize()
+        runner.count = first
+        for _ in range(6):
+            runner.submit()
+        runner.synchronize(check=True)
+        for s in range(2):
+            o = runner.graphs[s].outputs
+            assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
+            w = runner.workspaces[s]
+            placed = int(w.encode()[4:8].view(torch.int32).item())
+            assert placed == 256, placed                         # 32 groups x 8 members, one per CU
