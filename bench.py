@@ -325,20 +325,36 @@ def main():
     n_slots = max(1, args.inflight) if args.graph else 1
     runner = PipelinedRunner(pipe, svc, batch, slots=n_slots) if args.graph else None
     last = {}                                                   # slot -> index of the batch its outputs belong to
+    gathers = {}                                                # (runner, slot) -> (gathered tensor, pending work)
 
     def step(i, runner=runner):
+        """One step.  At N > 1 the single collective of the path — the all-gather of the selected indices — is issued
+        asynchronously behind the slot's decode: the process group's own stream carries it over xGMI while the slot's
+        stream goes straight on to its next step; the slot only waits for it (stream-side) right before the replay that
+        would overwrite the gathered buffer, two steps later."""
         j = i % len(batches)
         if runner is not None:
+            s = runner.count % runner.n_slots
+            key = (id(runner), s)
+            if use_dist and gathers.get(key, (None, None))[1] is not None:
+                with torch.cuda.stream(runner.stream(s)):
+                    gathers[key][1].wait()                      # the previous gather out of this slot's index buffer is done
             out, s = runner.submit(batches[j])
             stream = runner.stream(s)
-            last[(id(runner), s)] = j
+            last[key] = j
         else:
-            out, stream = pipe.run(svc, batches[j]), torch.cuda.current_stream()
+            out, stream, key = pipe.run(svc, batches[j]), torch.cuda.current_stream(), (0, 0)
         step.last = out
         if use_dist:
             with torch.cuda.stream(stream):
-                return gdist.all_gather_indices(out["idx_high"]), out["R"]
+                gathers[key] = gdist.all_gather_indices_async(out["idx_high"], gathers.get(key, (None, None))[0])
+            return gathers[key][0], out["R"]
         return out["idx_high"], out["R"]
+
+    def finish_gathers():
+        for g, work in gathers.values():
+            if work is not None:
+                work.wait()
 
     def timed_rounds(run_step):
         """The contract's timed region — barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks —
@@ -351,6 +367,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 res = run_step(i0 + i)
+            finish_gathers()                  # every step's all-gather has landed before the clock stops
             torch.cuda.synchronize()
             gdist.barrier(world)
             dt = gdist.max_over_ranks(time.perf_counter() - t0, dev, world)

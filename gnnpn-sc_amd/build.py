@@ -38,9 +38,29 @@ def _compile(src):
     return obj
 
 
+# The same-XCD hand-off of the cooperative kernels (coop_common.h: granule_store_l2) publishes with workgroup-scope
+# relaxed atomic stores that the toolchain lowers to plain global stores (no sc bits) — what the measurements and the
+# both-paths tests were made with.  A different compiler may lower them differently: say so loudly, and use
+# gnnpn_launch_opts_t.write_through = 1 (agent-scope stores, placement independent) until the tests have been re-run.
+MEASURED_WITH = "HIP version: 7.2"
+
+
+def _check_compiler():
+    try:
+        out = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError):
+        return
+    with open(os.path.join(HERE, "build", "compiler.txt"), "w") as f:
+        f.write(out)
+    if MEASURED_WITH not in out:
+        print(f"[gnnpn build] WARNING: this hipcc is not the one the L2-resident hand-off was validated with ({MEASURED_WITH}); "
+              "re-run `pytest -m gpu` (both hand-off forms are tested) or pass write_through=True", file=sys.stderr)
+
+
 def build(force=False):
     """Compile every HIP source for gfx950 and link libgnnpn_hip.so.  Returns the library path."""
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    _check_compiler()
     if force:
         for f in os.listdir(os.path.join(HERE, "build")):
             os.remove(os.path.join(HERE, "build", f))

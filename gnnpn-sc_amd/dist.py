@@ -52,6 +52,22 @@ def all_gather_indices(idx_local, sizes=None):
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
 
 
+def all_gather_indices_async(idx_local, out=None):
+    """Equal-shard all-gather that does NOT make the calling stream wait for the collective: returns (out, work).  torch's
+    RCCL process group runs collectives on its own stream, ordered after the work already queued on the calling stream;
+    with ``async_op`` the caller's stream is free to go on (the next pipelined step) while the 48 KB gather crosses xGMI.
+    Call ``work.wait()`` (a stream-side wait, not a host block) on whatever stream next reads ``out`` or overwrites
+    ``idx_local``.  Backends without device collectives (gloo launch-path checks) fall back to the blocking form."""
+    if idx_local.is_cuda and td.get_backend() == "gloo":
+        return all_gather_indices(idx_local), None
+    world = td.get_world_size()
+    if out is None:
+        out = torch.empty((world * idx_local.shape[0],) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype,
+                          device=idx_local.device)
+    work = td.all_gather_into_tensor(out, idx_local.contiguous(), async_op=True)
+    return out, work
+
+
 def barrier(world):
     if world > 1:
         td.barrier()

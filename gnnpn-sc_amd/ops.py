@@ -46,18 +46,20 @@ def embed_concat(x, table):
 
 LDS_BLOCK_ROWS_MAX = 10240      # block_rows * 16 B <= 160 KB
 LDS_MIN_WORKGROUPS = 128        # below this many (block, slice) workgroups the one-wave-per-row gather fills the chip better
+PREFER_LDS_AGGREGATE = False    # the LDS-staged form is bit-identical but measured slower than the gather form on MI355X
+#                                 (profiles/r02_csr_aggregate_roofline.json): opt-in
 
 
 def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
     """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
     ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
-    records it): the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a block fits the LDS and there
-    are enough (block, slice) workgroups to fill the chip; the results are bit-identical either way."""
+    records it): with ``ops.PREFER_LDS_AGGREGATE`` the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a
+    block fits the LDS and there are enough (block, slice) workgroups to fill the chip; bit-identical either way."""
     x = _rows2d(x, "csr_aggregate.x")
     n = rowptr.numel() - 1
     C = x.shape[1]
     y = torch.empty((n, C), dtype=F32, device=x.device)
-    if 0 < block_rows <= LDS_BLOCK_ROWS_MAX and C % 4 == 0:
+    if PREFER_LDS_AGGREGATE and 0 < block_rows <= LDS_BLOCK_ROWS_MAX and C % 4 == 0:
         lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and block_rows * 16 * c <= 160 * 1024)
         if -(-n // block_rows) * (C // (4 * lpr)) >= LDS_MIN_WORKGROUPS:
             check(_lib.load().gnnpn_csr_aggregate_blocks_f32(

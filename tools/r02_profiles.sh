@@ -9,7 +9,7 @@ timeout 300 python bench.py > $O/bench_qws.json 2> $O/bench_qws.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_qws_driver_flags.json 2> /dev/null
 timeout 400 python bench.py --workload normal --steps 20 --warmup 4 --no-cpu-baseline > $O/bench_normal.json 2> /dev/null
 timeout 400 python bench.py --workload synth4 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_synth4.json 2> /dev/null
-timeout 600 python bench.py --workload synth4 --scaling strong --steps 3 --warmup 1 --batches 2 --no-cpu-baseline --no-split-line > $O/bench_synth4_strong_g4096_n1.json 2> $O/bench_synth4_strong.err
+timeout 900 python bench.py --workload synth4 --scaling strong --steps 3 --warmup 1 --batches 2 --no-cpu-baseline --no-split-line > $O/bench_synth4_strong_g4096_n1.json 2> $O/bench_synth4_strong.err
 timeout 400 python bench.py --workload synth5 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_synth5.json 2> /dev/null
 timeout 400 python bench.py --workload synth5 --precision f16 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_synth5_f16.json 2> /dev/null
 timeout 300 python bench.py --precision f16 --no-cpu-baseline > $O/bench_qws_f16.json 2> /dev/null
