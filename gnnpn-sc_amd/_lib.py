@@ -42,6 +42,15 @@ _SIGNATURES = {
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
+    "gnnpn_gemm_f32": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int64, c_int, c_int, _P]),
+    "gnnpn_lstm_train_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_decode_train_forward_f32": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
+    "gnnpn_decode_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
+    "gnnpn_lstm_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_colsum_f32": (c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
+    "gnnpn_scatter_dx_f32": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_sumsq_f32": (c_int, [_P, c_int64, _P, _P]),
+    "gnnpn_adam_step_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int32, _P]),
     "gnnpn_eswoa_f64": (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, _P, _P, _P]),
     "gnnpn_debug_cell_activations": (c_int, [_P, _P, _P, c_int64, _P]),
 }
@@ -65,6 +74,12 @@ class GinLayer(ctypes.Structure):
     """gnnpn_gin_layer_t of include/gnnpn_hip.h."""
     _fields_ = [(n, _P) for n in ("w0_packed", "b0", "bn1_scale", "bn1_shift", "w3_packed", "b3", "bn2_scale", "bn2_shift",
                                   "eps")]
+
+
+class DecodeTrain(ctypes.Structure):
+    """gnnpn_decode_train_t of include/gnnpn_hip.h."""
+    _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih", "whh", "bih", "bhh", "latent_win", "idx",
+                                  "x_all", "gates_pre", "c_all", "h_all", "z0", "probs", "logp")]
 
 
 class EncodeNet(ctypes.Structure):

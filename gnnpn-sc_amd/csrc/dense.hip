@@ -197,3 +197,82 @@ extern "C" int gnnpn_embed_concat_f32(const float* x, const float* table, int vo
     GNNPN_CHECK_LAUNCH("embed_concat_f32");
     return GNNPN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// General fp32 GEMM for the training path (weight gradients and the gradient of the input projection):
+//   C[m,n] = sum_k Aop[m,k] * Bop[n,k],   Aop[m,k] = a_kmajor ? A[k*lda + m] : A[m*lda + k]  (same for B)
+// so that dW = dG^T . X (both operands k-major: the reduction runs over the B*L rows of the saved activations) and
+// dX = dG . W (B given k-major) need no transposed copies.  Same 64x64x32 tile, LDS layout and k-ordered fp32 MFMA chain as
+// linear_f32_kernel; a k-major operand is already in the LDS layout and is copied straight in.
+template <int BM, bool KMAJOR>
+__device__ __forceinline__ void gemm_tile_to_lds(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t n_rows, int k0,
+                                                 int K, float* S) {
+    constexpr int LD = BM + 1;
+    if constexpr (KMAJOR) {   // P[k*ld + r]: 32 k-rows of BM consecutive floats
+        for (int f = threadIdx.x; f < 32 * BM; f += 256) {
+            const int kk = f / BM, r = f - kk * BM;
+            const int64_t row = r0 + r;
+            const int k = k0 + kk;
+            S[kk * LD + r] = (row < n_rows && k < K) ? P[(int64_t)k * ld + row] : 0.0f;
+        }
+    } else {                  // P[r*ld + k]
+        for (int f = threadIdx.x; f < 32 * BM; f += 256) {
+            const int r = f >> 5, kk = f & 31;
+            const int64_t row = r0 + r;
+            const int k = k0 + kk;
+            S[kk * LD + r] = (row < n_rows && k < K) ? P[row * ld + k] : 0.0f;
+        }
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+                                                       int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                       int K) {
+    constexpr int BM = 64, BN = 64;
+    __shared__ float As[32 * (BM + 1)];
+    __shared__ float Bs[32 * (BN + 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int half = lane >> 5, l32 = lane & 31;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        gemm_tile_to_lds<BM, A_KMAJOR>(A, lda, m0, M, k0, K, As);
+        gemm_tile_to_lds<BN, B_KMAJOR>(Bm, ldb, n0, N, k0, K, Bs);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            const float a = As[(kk + half) * (BM + 1) + wm * 32 + l32];
+            const float b = Bs[(kk + half) * (BN + 1) + wn * 32 + l32];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + l32;
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M) C[row * ldc + col] = acc[r];
+    }
+}
+
+extern "C" int gnnpn_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                              int64_t ldc, int64_t M, int N, int K, void* stream) {
+    GNNPN_REQUIRE(A && B && C, "gemm: null operand");
+    GNNPN_REQUIRE(M >= 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    GNNPN_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K), "gemm: leading dimension too small");
+    if (M == 0) return GNNPN_OK;
+    dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    GNNPN_CHECK_LAUNCH("gemm_f32");
+    return GNNPN_OK;
+}

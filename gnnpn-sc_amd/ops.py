@@ -469,3 +469,117 @@ def eswoa(cand_ptr, len_init, cand, bounds, start_pos, pop, max_iter, seeds, n_c
                                       dev_ptr(best_pos, I32, "best_pos"), dev_ptr(history, torch.float64, "history"),
                                       dev_ptr(draws, I64, "draws"), stream_ptr()), "gnnpn_eswoa_f64")
     return best_fit, best_pos, history[:, :int(max_iter)], draws
+
+
+# ---- REINFORCE training step of the High-level pointer network (csrc/train.hip; include/gnnpn_hip.h) -----------------
+
+def gemm(a, b, a_kmajor=False, b_kmajor=False):
+    """C[m,n] = sum_k Aop[m,k] * Bop[n,k]; an operand given k-major is [K, M] (resp. [K, N])   (gnnpn_gemm_f32)."""
+    a, b = _rows2d(a, "gemm.a"), _rows2d(b, "gemm.b")
+    M, K = (a.shape[1], a.shape[0]) if a_kmajor else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if b_kmajor else b.shape
+    if K != Kb:
+        raise GnnpnError(f"gemm: K mismatch {tuple(a.shape)} x {tuple(b.shape)}")
+    c = torch.empty((M, N), dtype=F32, device=a.device)
+    check(_lib.load().gnnpn_gemm_f32(dev_ptr(a, F32, "a"), a.shape[1], int(a_kmajor), dev_ptr(b, F32, "b"), b.shape[1],
+                                     int(b_kmajor), dev_ptr(c, F32, "c"), N, M, N, K, stream_ptr()), "gnnpn_gemm_f32")
+    return c
+
+
+def colsum(x, rows=None, cols=None, ld=None):
+    """out[c] = sum_r x[r, c] (bias gradients; with rows/cols/ld a strided view of a larger buffer)   (gnnpn_colsum_f32)."""
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[-1] if cols is None else cols
+    ld = x.shape[-1] if ld is None else ld
+    out = torch.empty(cols, dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_colsum_f32(dev_ptr(x, F32, "x"), ld, rows, cols, dev_ptr(out, F32, "out"), stream_ptr()),
+          "gnnpn_colsum_f32")
+    return out
+
+
+def lstm_train_forward(pregates, whh, bhh):
+    """Encoder recurrence that also saves the pre-activation gates and cell states: -> (enc_out, gates_pre, c_all)."""
+    B, L, H4 = pregates.shape
+    H = H4 // 4
+    dev = pregates.device
+    enc, gp, ca = (torch.empty(s, dtype=F32, device=dev) for s in ((B, L, H), (B, L, 4 * H), (B, L, H)))
+    check(_lib.load().gnnpn_lstm_train_forward_f32(dev_ptr(pregates, F32, "pregates"), dev_ptr(whh, F32, "whh"),
+                                                   dev_ptr(bhh, F32, "bhh"), dev_ptr(enc, F32, "enc"), dev_ptr(gp, F32, "gp"),
+                                                   dev_ptr(ca, F32, "c"), B, L, H, stream_ptr()), "gnnpn_lstm_train_forward_f32")
+    return enc, gp, ca
+
+
+def _decode_train_struct(d):
+    t = _lib.DecodeTrain()
+    for name, _ in _lib.DecodeTrain._fields_:
+        v = d.get(name)
+        setattr(t, name, None if v is None else v.data_ptr())
+    return t
+
+
+def decode_train_forward(embedded, enc_out, h0, c0, start, wih, whh, bih, bhh, latent_win, idx, n_cat, n_per, tanh_c=10.0,
+                         use_tanh=True):
+    """Teacher-forced decode (picks ``idx`` [B,T] int32 given) that saves what the backward needs; returns the dict of
+    operands + saves that decode_train_backward takes, with ``logp`` [B,T] = log-probability of every pick."""
+    B, L, H = enc_out.shape
+    dev = enc_out.device
+    d = {"embedded": embedded, "enc_out": enc_out, "h0": h0, "c0": c0, "start": start, "wih": wih, "whh": whh, "bih": bih,
+         "bhh": bhh, "latent_win": latent_win, "idx": idx}
+    for name, shape in (("x_all", (B, n_cat, H)), ("gates_pre", (B, n_cat, 4 * H)), ("c_all", (B, n_cat, H)),
+                        ("h_all", (B, n_cat, H)), ("z0", (B, n_cat, n_per)), ("probs", (B, n_cat, n_per)), ("logp", (B, n_cat))):
+        d[name] = torch.empty(shape, dtype=F32, device=dev)
+    for k, v in d.items():
+        if v is not None:
+            dev_ptr(v, I32 if k == "idx" else F32, k)        # validation (device, dtype, contiguity)
+    check(_lib.load().gnnpn_decode_train_forward_f32(_lib.ctypes.byref(_decode_train_struct(d)), B, n_cat, n_per, H,
+                                                     float(tanh_c), int(bool(use_tanh)), stream_ptr()),
+          "gnnpn_decode_train_forward_f32")
+    d.update(n_cat=n_cat, n_per=n_per, tanh_c=float(tanh_c), use_tanh=bool(use_tanh))
+    return d
+
+
+def decode_train_backward(d, gscale):
+    """-> (d_enc_out [B,L,H], dgates [B,T,4H], dx [B,T,H], dh0, dc0 [B,H])."""
+    B, L, H = d["enc_out"].shape
+    T, K = d["n_cat"], d["n_per"]
+    dev = d["enc_out"].device
+    de, dg, dx, dh0, dc0 = (torch.empty(s, dtype=F32, device=dev) for s in ((B, L, H), (B, T, 4 * H), (B, T, H), (B, H), (B, H)))
+    tensors = {k: v for k, v in d.items() if isinstance(v, torch.Tensor) or v is None}
+    check(_lib.load().gnnpn_decode_train_backward_f32(
+        _lib.ctypes.byref(_decode_train_struct(tensors)), dev_ptr(gscale, F32, "gscale"), dev_ptr(de, F32, "d_enc_out"),
+        dev_ptr(dg, F32, "dgates"), dev_ptr(dx, F32, "dx"), dev_ptr(dh0, F32, "dh0"), dev_ptr(dc0, F32, "dc0"), B, T, K, H,
+        d["tanh_c"], int(d["use_tanh"]), stream_ptr()), "gnnpn_decode_train_backward_f32")
+    return de, dg, dx, dh0, dc0
+
+
+def lstm_train_backward(whh, gates_pre, c_all, d_enc_out, dh0, dc0):
+    B, L, H = c_all.shape
+    dg = torch.empty((B, L, 4 * H), dtype=F32, device=c_all.device)
+    check(_lib.load().gnnpn_lstm_train_backward_f32(dev_ptr(whh, F32, "whh"), dev_ptr(gates_pre, F32, "gates_pre"),
+                                                    dev_ptr(c_all, F32, "c_all"), dev_ptr(d_enc_out, F32, "d_enc_out"),
+                                                    dev_ptr(dh0, F32, "dh0"), dev_ptr(dc0, F32, "dc0"), dev_ptr(dg, F32, "dgates"),
+                                                    B, L, H, stream_ptr()), "gnnpn_lstm_train_backward_f32")
+    return dg
+
+
+def scatter_dx(dx, idx, d_embedded):
+    B, T, H = dx.shape
+    L = d_embedded.shape[1]
+    check(_lib.load().gnnpn_scatter_dx_f32(dev_ptr(dx, F32, "dx"), dev_ptr(idx, I32, "idx"), dev_ptr(d_embedded, F32, "d_embedded"),
+                                           B, T, L, H, stream_ptr()), "gnnpn_scatter_dx_f32")
+
+
+def grad_sumsq(grads):
+    """Squared L2 norm over a list of gradient tensors, accumulated on the device in float64 -> tensor [1] f64."""
+    acc = torch.zeros(1, dtype=F64, device=grads[0].device)
+    for g in grads:
+        check(_lib.load().gnnpn_sumsq_f32(dev_ptr(g, F32, "grad"), g.numel(), dev_ptr(acc, F64, "acc"), stream_ptr()),
+              "gnnpn_sumsq_f32")
+    return acc
+
+
+def adam_step(p, g, m, v, sumsq, max_grad_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """clip_grad_norm_ + torch.optim.Adam (defaults) on one parameter tensor, in place   (gnnpn_adam_step_f32)."""
+    check(_lib.load().gnnpn_adam_step_f32(dev_ptr(p, F32, "p"), dev_ptr(g, F32, "g"), dev_ptr(m, F32, "m"), dev_ptr(v, F32, "v"),
+                                          p.numel(), dev_ptr(sumsq, F64, "sumsq"), float(max_grad_norm), float(lr), float(beta1),
+                                          float(beta2), float(eps), int(step), stream_ptr()), "gnnpn_adam_step_f32")

@@ -1,0 +1,158 @@
+"""REINFORCE training of the High-level pointer network behind the reference's driver
+(/root/reference/src/models/trainPNHigh.py): ``TrainModel`` (:43-150) — same constructor arguments, ``train_and_validate``
+— with the step of :81-110 running on the GPU: Low greedy -> latent, High sampled (picks drawn inside the decode kernel),
+then the backward pass, gradient clipping and Adam of csrc/train.hip.
+
+No autograd: the gradient of  mean_b( advantage_b * sum_k log p_{b,k} )  wrt every actor parameter is computed by the
+hand-written backward kernels with the picks as constants; weights are updated in place.
+"""
+import os
+
+import torch
+
+from . import evalPN, ops
+
+ACTOR_KEYS = ("decoder_start_input", "embedding2.weight", "embedding2.bias",
+              "encoder.weight_ih_l0", "encoder.weight_hh_l0", "encoder.bias_ih_l0", "encoder.bias_hh_l0",
+              "decoder.weight_ih_l0", "decoder.weight_hh_l0", "decoder.bias_ih_l0", "decoder.bias_hh_l0")
+
+
+def _params(actor):
+    return {k: p for k, p in actor.named_parameters()}
+
+
+@torch.no_grad()
+def actor_gradients(actor, inputs, idx, latent_win, gscale):
+    """Gradient of sum_b gscale[b] * sum_k log p_{b,k}(picks) wrt every parameter of ``actor`` (a modelPN.PointerNet):
+    -> (dict name -> gradient tensor, logp [B,T]).  inputs [B,L,8]; idx [B,T] int32 picks (global positions); latent_win
+    [B,T,K] the Low net's window logits (constants) or None."""
+    p = {k: v.detach().float().contiguous() for k, v in _params(actor).items()}
+    B, L, F = inputs.shape
+    H, T, K = actor.hidden_size, actor.serCategory, actor.serNumber
+    flat = inputs.reshape(B * L, F).contiguous()
+    embedded = ops.linear(flat, p["embedding2.weight"], p["embedding2.bias"])                          # modelPN.py:190
+    pregates = ops.linear(embedded, p["encoder.weight_ih_l0"], p["encoder.bias_ih_l0"]).view(B, L, 4 * H)
+    enc_out, gates_e, c_e = ops.lstm_train_forward(pregates, p["encoder.weight_hh_l0"], p["encoder.bias_hh_l0"])   # :191
+    h0, c0 = enc_out[:, L - 1].contiguous(), c_e[:, L - 1].contiguous()
+    d = ops.decode_train_forward(embedded.view(B, L, H), enc_out, h0, c0, p["decoder_start_input"],
+                                 p["decoder.weight_ih_l0"], p["decoder.weight_hh_l0"], p["decoder.bias_ih_l0"],
+                                 p["decoder.bias_hh_l0"], latent_win, idx, T, K, actor.C, actor.use_tanh)   # :204-239
+    d_enc_out, dg_d, dx, dh0, dc0 = ops.decode_train_backward(d, gscale)
+    dg_e = ops.lstm_train_backward(p["encoder.weight_hh_l0"], gates_e, c_e, d_enc_out, dh0, dc0)
+    g = {}
+    dgd = dg_d.view(B * T, 4 * H)
+    hprev_d = torch.cat([h0.unsqueeze(1), d["h_all"][:, :-1]], 1).reshape(B * T, H).contiguous()      # h_{k-1} of every step
+    g["decoder.weight_hh_l0"] = ops.gemm(dgd, hprev_d, True, True)
+    g["decoder.weight_ih_l0"] = ops.gemm(dgd, d["x_all"].view(B * T, H), True, True)
+    g["decoder.bias_ih_l0"] = ops.colsum(dgd)
+    g["decoder.bias_hh_l0"] = g["decoder.bias_ih_l0"]
+    g["decoder_start_input"] = ops.colsum(dx, rows=B, cols=H, ld=T * H)                               # x_0 = the start input (:202)
+    dge = dg_e.view(B * L, 4 * H)
+    hprev_e = torch.cat([torch.zeros_like(enc_out[:, :1]), enc_out[:, :-1]], 1).reshape(B * L, H).contiguous()
+    g["encoder.weight_hh_l0"] = ops.gemm(dge, hprev_e, True, True)
+    g["encoder.weight_ih_l0"] = ops.gemm(dge, embedded, True, True)
+    g["encoder.bias_ih_l0"] = ops.colsum(dge)
+    g["encoder.bias_hh_l0"] = g["encoder.bias_ih_l0"]
+    d_emb = ops.gemm(dge, p["encoder.weight_ih_l0"], False, True).view(B, L, H)                        # dG . W_ih
+    ops.scatter_dx(dx, idx, d_emb)                                                                     # + the decoder inputs (:235)
+    d_emb2 = d_emb.view(B * L, H)
+    g["embedding2.weight"] = ops.gemm(d_emb2, flat, True, True)
+    g["embedding2.bias"] = ops.colsum(d_emb2)
+    return g, d["logp"]
+
+
+class ActorAdam:
+    """torch.optim.Adam(model.actor.parameters(), lr) (trainPNHigh.py:62) + clip_grad_norm_ (:105-106), state on the device."""
+
+    def __init__(self, actor, lr=0.5e-4, max_grad_norm=2.0):
+        self.actor, self.lr, self.max_grad_norm, self.steps = actor, lr, max_grad_norm, 0
+        self.state = {k: (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32))
+                      for k, p in _params(actor).items()}
+
+    @torch.no_grad()
+    def step(self, grads):
+        """-> gradient norm before clipping (device tensor [1], float64)."""
+        self.steps += 1
+        uniq = [grads[k] for k in ACTOR_KEYS]                      # b_ih and b_hh share a tensor but both count (two parameters)
+        sumsq = ops.grad_sumsq(uniq)
+        for k, p in _params(self.actor).items():
+            if p.data.dtype != torch.float32 or not p.data.is_contiguous():
+                raise ops.GnnpnError(f"ActorAdam: parameter {k} must be contiguous fp32")
+            m, v = self.state[k]
+            ops.adam_step(p.data, grads[k].contiguous(), m, v, sumsq, self.max_grad_norm, self.lr, self.steps)
+        self.actor._packed = None                                  # the inference kernels re-pack the new weights
+        return sumsq.sqrt()
+
+
+class TrainModel:
+    """TrainModel (trainPNHigh.py:43-150).  ``train_step`` is the body of the batch loop (:81-110)."""
+
+    def __init__(self, model, train_dataset, val_dataset, epochDiv, beta, USE_CUDA, dataset, serCategory, lr=0.5e-4,
+                 batch_size=128, threshold=None, max_grad_norm=2., low_model=None, device="cuda:0"):
+        self.model, self.low_model = model, low_model
+        self.train_dataset, self.val_dataset = train_dataset, val_dataset
+        self.batch_size, self.threshold, self.epochDiv, self.beta = batch_size, threshold, epochDiv, beta
+        self.USE_CUDA, self.dataset, self.serCategory = USE_CUDA, dataset, serCategory
+        self.actor_optim = ActorAdam(model.actor, lr, float(max_grad_norm))
+        self.max_grad_norm = float(max_grad_norm)
+        self.train_tour, self.val_tour, self.epochs = [], [], 0
+        self.device = torch.device(device)
+        self.critic_exp_mvg_avg = None
+
+    @torch.no_grad()
+    def train_step(self, inputs, sample_seed=None):
+        """One batch: -> dict(R [B], loss, grad_norm, idx_high, logp).  ``sample_seed`` fixes the draws (tests); by default
+        they follow the High actor's own stream (modelPN.PointerNet.next_sample_seed)."""
+        from .modelPN import two_level_greedy
+        inputs = inputs.to(self.device).contiguous()
+        ha = self.model.actor
+        seed = ha.next_sample_seed() if sample_seed is None else int(sample_seed)
+        out = two_level_greedy(self.low_model, self.model, inputs, sample_high_seed=seed)          # :83-84
+        R = out["R"]
+        if self.critic_exp_mvg_avg is None:                                                        # :87-90
+            self.critic_exp_mvg_avg = R.mean()
+        else:
+            self.critic_exp_mvg_avg = self.critic_exp_mvg_avg * self.beta + (1.0 - self.beta) * R.mean()
+        advantage = R - self.critic_exp_mvg_avg                                                    # :92
+        B = inputs.shape[0]
+        # the gradient wrt log p is advantage/B (mean over the batch, :100-101); it needs the log-prob sums only for the
+        # reference's "logprobs[logprobs < -1000] = 0" (:98), so the teacher-forced forward runs first with unit scale
+        grads, logp = actor_gradients(ha, inputs, out["idx_high"], out["win_low"], (advantage / B).contiguous())
+        logprobs = logp.sum(1)
+        dead = logprobs < -1000
+        if bool(dead.any()):                                                                       # rare: redo without those problems
+            gscale = torch.where(dead, torch.zeros_like(advantage), advantage / B).contiguous()
+            grads, logp = actor_gradients(ha, inputs, out["idx_high"], out["win_low"], gscale)
+            logprobs = torch.where(dead, torch.zeros_like(logprobs), logprobs)
+        loss = (advantage * logprobs).mean()
+        norm = self.actor_optim.step(grads)                                                        # :103-108
+        self.critic_exp_mvg_avg = self.critic_exp_mvg_avg.detach()
+        self.train_tour.append(float(R.mean().item()))                                             # :112
+        ops.check_status(self.device)
+        return {"R": R, "loss": loss, "grad_norm": norm, "idx_high": out["idx_high"], "idx_low": out["idx_low"], "logp": logp,
+                "grads": grads}
+
+    def train_and_validate(self, n_epochs, epochDiv):
+        """trainPNHigh.py:68-150 without the plotting: epochs over the training set, the evaluation block and the
+        checkpoints / allActions artefacts of every ``epochDiv``-th epoch."""
+        import json
+        loader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=0)
+        for epoch in range(1, n_epochs + 1):
+            for sample_batch, _labs in loader:
+                self.train_step(sample_batch)
+            if self.threshold and self.train_tour[-1] < self.threshold:
+                print("EARLY STOPPAGE!")
+                break
+            if epoch % epochDiv == 0:
+                n = self.epochs // epochDiv
+                os.makedirs(f"./solutions/PNHigh/{self.dataset}", exist_ok=True)
+                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": {}},
+                           f"./solutions/PNHigh/{self.dataset}/epoch{n}.model")                    # :118-123
+                torch.save({"epoch": epoch, "model": self.low_model.state_dict(), "optimizer": {}},
+                           f"./solutions/PNHigh/{self.dataset}/epoch{n}_low.model")                # :124-129
+                acts, tour = evalPN.evaluate(self.low_model, self.model, self.val_dataset, self.serCategory, 128,
+                                             str(self.device))                                     # :131-141
+                with open(f"./solutions/PNHigh/{self.dataset}/allActions{n}.txt", "w") as f:       # :143-144
+                    json.dump(acts, f)
+                self.val_tour.append(sum(tour) / max(len(tour), 1))
+            self.epochs += 1

@@ -333,6 +333,67 @@ int gnnpn_attention_logits_f32(const float* enc_out, const float* queries, int64
 int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, int level,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * REINFORCE training step of the High-level pointer network.  Replaces the autograd graph of
+ * src/models/trainPNHigh.py:84-108 over src/models/modelPN.py:175-306: actor_loss.backward() (:103-104), clip_grad_norm_
+ * (:105-106) and actor_optim.step() (:108).  The picks of the step come from the sampled forward (gnnpn_pointer_decode_f32
+ * with sample = 1) and are constants of the differentiated graph.  All weights here are the PLAIN row-major [4H,H]
+ * matrices of the state_dict (not the packed inference layout).  H must be 256 or 32.
+ *
+ * gnnpn_gemm_f32: C[m,n] = sum_k Aop[m,k]*Bop[n,k], Aop[m,k] = a_kmajor ? A[k*lda+m] : A[m*lda+k] (same for B): weight
+ *   gradients dW = dG^T . X (both operands k-major, k = the B*L rows of saved activations) and dX = dG . W (B k-major).
+ * gnnpn_lstm_train_forward_f32: the encoder recurrence from pregates [B,L,4H] (= embedded . W_ih^T + b_ih), saving the full
+ *   pre-activation gates [B,L,4H] and the cell states [B,L,H] besides enc_out.
+ * gnnpn_decode_train_forward_f32: the decode loop with the picks idx [B,T] GIVEN (teacher forcing), saving decoder inputs,
+ *   pre-activation gates, c_k, h_k, the window logits z0 = C*tanh(dot) and probabilities, and log p(pick) [B,T].
+ * gnnpn_decode_train_backward_f32: T steps in reverse.  gscale[b] = dLoss/dlog p of every step of problem b
+ *   (advantage_b / B; 0 where the reference zeroes the sum, :98).  Writes d_enc_out [B,L,H] (every element exactly once:
+ *   the step windows partition the L rows), the gate gradients dgates [B,T,4H], the decoder-input gradients dx [B,T,H] and
+ *   the gradient wrt the initial state (dh0, dc0 [B,H]) that continues into the encoder.
+ * gnnpn_lstm_train_backward_f32: L steps in reverse from (dh0, dc0) and d_enc_out; writes dgates [B,L,4H].
+ * gnnpn_colsum_f32 (bias gradients, the start-input gradient), gnnpn_scatter_dx_f32 (dx_k into the embedded row the step's
+ *   input was gathered from, :235), gnnpn_sumsq_f32 (accumulates into a device double: the squared gradient norm),
+ * gnnpn_adam_step_f32: p -= lr * mhat / (sqrt(vhat) + eps) on g * min(1, max_grad_norm / (sqrt(*grad_sumsq) + 1e-6)) —
+ *   torch.nn.utils.clip_grad_norm_ followed by torch.optim.Adam with its defaults. */
+typedef struct {
+    const float* embedded;   /* [B,L,H] */
+    const float* enc_out;    /* [B,L,H] */
+    const float* h0;         /* [B,H] encoder final h */
+    const float* c0;         /* [B,H] encoder final c */
+    const float* start;      /* [H] decoder_start_input */
+    const float* wih;        /* decoder LSTM, row-major [4H,H] */
+    const float* whh;
+    const float* bih;
+    const float* bhh;
+    const float* latent_win; /* [B,T,K] or NULL */
+    const int32_t* idx;      /* [B,T] picks (global positions) */
+    float* x_all;            /* [B,T,H] */
+    float* gates_pre;        /* [B,T,4H] */
+    float* c_all;            /* [B,T,H] */
+    float* h_all;            /* [B,T,H] */
+    float* z0;               /* [B,T,K] */
+    float* probs;            /* [B,T,K] */
+    float* logp;             /* [B,T] */
+} gnnpn_decode_train_t;
+int gnnpn_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                   int64_t ldc, int64_t M, int N, int K, void* stream);
+int gnnpn_lstm_train_forward_f32(const float* pregates, const float* whh, const float* bhh, float* enc_out,
+                                 float* gates_pre, float* c_all, int32_t B, int32_t L, int32_t H, void* stream);
+int gnnpn_decode_train_forward_f32(const gnnpn_decode_train_t* t, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                   float tanh_c, int use_tanh, void* stream);
+int gnnpn_decode_train_backward_f32(const gnnpn_decode_train_t* t, const float* gscale, float* d_enc_out, float* dgates,
+                                    float* dx, float* dh0, float* dc0, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                    float tanh_c, int use_tanh, void* stream);
+int gnnpn_lstm_train_backward_f32(const float* whh, const float* gates_pre, const float* c_all, const float* d_enc_out,
+                                  const float* dh0, const float* dc0, float* dgates, int32_t B, int32_t L, int32_t H,
+                                  void* stream);
+int gnnpn_colsum_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, float* out, void* stream);
+int gnnpn_scatter_dx_f32(const float* dx, const int32_t* idx, float* d_embedded, int32_t B, int32_t T, int32_t L, int32_t H,
+                         void* stream);
+int gnnpn_sumsq_f32(const float* x, int64_t n, double* accum, void* stream);
+int gnnpn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, const double* grad_sumsq,
+                        float max_grad_norm, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
 /* Test hook: the sigmoid / tanh the LSTM cells use (hardware exp2/rcp based, |error| ~1e-7),
  * evaluated on an array so that tests can measure them against the CPU's libm-grade functions. */
 int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t n, void* stream);

@@ -152,6 +152,94 @@ def gen_pn_sample(modelPN, name, H, T, K, B, seed, sample_seed):
           f"min draw margin {float(orc['margin_high'].min()):.2e}")
 
 
+def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
+    """ONE REINFORCE step of the PNHigh trainer run on the REAL modules (trainPNHigh.py:83-108; the driver class itself
+    imports IPython/matplotlib and is not importable here, so its loop body is driven by hand, line for line):
+    Low greedy -> latent, High sampled (multinomial routed to the stream), advantage against the first-batch critic,
+    sum of log-probs, backward through the reference's own autograd graph, clip_grad_norm_, Adam(lr=0.5e-4).
+    Stores every actor gradient (before clipping) and the weights after the step — in full for the small case, as norms,
+    seeded samples and seeded projections for H = 256 (4 MB per set otherwise) — after checking that oracle/pn_train.py
+    reproduces them."""
+    from oracle import pn_train as optr
+    sd_low, sd_high = opn.make_state_dict(H, seed), opn.make_state_dict(H, seed + 1)
+    L = T * K
+
+    def build(level, sd):
+        m = modelPN.CombinatorialRL(0, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
+        m.load_state_dict(sd, strict=True)
+        return m
+
+    low, high = build("Low", sd_low), build("High", sd_high)
+    x = pn_inputs(B, T, K, seed + 2)
+    state = {"k": 0}
+    real = torch.Tensor.multinomial
+
+    def routed(self, num_samples=1, replacement=False, generator=None):
+        idx, _ = opn.multinomial_from_stream(self.detach(), state["k"], T, K, sample_seed)
+        state["k"] += 1
+        return idx.view(-1, 1)
+
+    torch.Tensor.multinomial = routed
+    optim = torch.optim.Adam(high.actor.parameters(), lr=0.5e-4)                     # trainPNHigh.py:62
+    try:
+        low.train(), high.train()                                                    # :79-80
+        with contextlib.redirect_stdout(io.StringIO()):
+            with torch.no_grad():
+                _, _, _, _, latent = low(x, None, sample="greedy", training="SL")    # :83
+            R, probs, actions, idxs, _ = high(x, None, latent)                       # :84
+        critic = R.mean()                                                            # :87-88 (batch_id == 0)
+        advantage = R - critic                                                       # :92
+        logprobs = 0
+        for prob in probs:                                                           # :94-97
+            logprobs = logprobs + torch.log(prob)
+        logprobs[logprobs < -1000] = 0.                                              # :98
+        actor_loss = (advantage * logprobs).mean()                                   # :100-101
+        optim.zero_grad()
+        actor_loss.backward()                                                        # :103-104
+        grads = {"actor." + n: p.grad.clone() for n, p in high.actor.named_parameters()}
+        norm = torch.nn.utils.clip_grad_norm_(high.actor.parameters(), 2.0, norm_type=2)   # :105-106
+        optim.step()                                                                 # :108
+    finally:
+        torch.Tensor.multinomial = real
+    new_params = {"actor." + n: p.detach().clone() for n, p in high.actor.named_parameters()}
+    idx_high = torch.stack(idxs, 1)
+    orc = optr.train_step(sd_low, sd_high, x, T, K, sample_seed)
+    assert torch.equal(orc["idx_high"], idx_high) and torch.equal(orc["R"], R.detach())
+    worst = 0.0
+    for k in optr.PARAM_KEYS:
+        g, og = grads[k], orc["grads"][k]
+        rel = float((g - og).norm() / (g.norm() + 1e-20))
+        worst = max(worst, rel)
+        assert rel < 2e-4, f"oracle gradient of {k} differs from the reference's: rel {rel:.2e} ({name})"
+        # Adam's first step is lr * g / (|g| + eps): for gradients near the 1e-8 eps it is ill-conditioned (a sign flip
+        # of a 1e-9 gradient moves the weight by 1e-4 * ...), so weights are compared where |g| is clear of it
+        clear = g.abs() > 1e-5
+        assert float(((new_params[k] - orc["new_params"][k]).abs() * clear).max()) < 2e-6, k
+        assert float((new_params[k] - orc["new_params"][k]).abs().max()) <= 1.01e-4, k
+    assert abs(float(norm) - float(orc["grad_norm"])) < 1e-4 * max(1.0, float(norm))
+    out = {"hidden": H, "n_cat": T, "n_per": K, "B": B, "seed_low": seed, "seed_high": seed + 1, "seed_inputs": seed + 2,
+           "sample_seed": sample_seed, "idx_low": orc["idx_low"].numpy(), "idx_high": idx_high.numpy(), "R": R.detach().numpy(),
+           "loss": float(actor_loss), "grad_norm": float(norm), "margin_low": orc["margin_low"].numpy(),
+           "margin_high": orc["margin_high"].numpy(), "win_low": orc["win_low"].numpy()}
+    g = torch.Generator().manual_seed(seed)
+    for k in optr.PARAM_KEYS:
+        short = k.replace("actor.", "").replace(".", "_")
+        gk, pk = grads[k].flatten(), new_params[k].flatten()
+        if full:
+            out["grad_" + short], out["new_" + short] = grads[k].numpy(), new_params[k].numpy()
+        else:
+            pos = torch.randint(0, gk.numel(), (64,), generator=g)
+            vec = torch.randn(gk.numel(), generator=g)
+            out["gradnorm_" + short] = float(gk.norm())
+            out["gradpos_" + short], out["gradval_" + short] = pos.numpy(), gk[pos].numpy()
+            out["gradproj_" + short] = float((gk.double() * vec.double()).sum())
+            out["newval_" + short] = pk[pos].numpy()
+            out["newproj_" + short] = float((pk.double() * vec.double()).sum())
+    np.savez_compressed(os.path.join(HERE, f"pn_train_{name}.npz"), **out)
+    print(f"pn_train_{name}: B={B} T={T} K={K} H={H}: loss {float(actor_loss):+.5f}, grad norm {float(norm):.4f}, "
+          f"max rel. gradient error oracle vs reference {worst:.1e}")
+
+
 def gen_reward(modelPN):
     """reward/calc known-answer cases (modelPN.py:15-72)."""
     rng = np.random.default_rng(7)
@@ -351,6 +439,8 @@ def main():
     gen_pn(modelPN, "saturated", H=256, T=12, K=5, B=8, seed=51, weight_scale=6.0)
     gen_pn_sample(modelPN, "small", H=32, T=6, K=3, B=8, seed=91, sample_seed=12345)
     gen_pn_sample(modelPN, "qws", H=256, T=47, K=5, B=64, seed=95, sample_seed=987654321)
+    gen_pn_train(modelPN, "small", H=32, T=6, K=3, B=8, seed=101, sample_seed=4242, full=True)
+    gen_pn_train(modelPN, "qws", H=256, T=47, K=5, B=32, seed=105, sample_seed=777, full=False)
     gen_reward(modelPN)
     gen_data(loadData_mod, ML2PN_mod)
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)

@@ -1,0 +1,132 @@
+"""-m gpu: the REINFORCE training step of the High-level pointer network (reference
+src/models/trainPNHigh.py:76-112) — hand-written backward, clipping and Adam — against fixtures produced by the REAL
+reference modules and their autograd (tests/golden/make_golden.py::gen_pn_train) and against the live autograd oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import pn as opn
+from oracle import pn_train as optr
+from pn_inputs import pn_inputs
+
+pytestmark = pytest.mark.gpu
+GRAD_RTOL = 2e-4        # per parameter: ||g - g_ref|| / ||g_ref||
+
+
+def _nets(fx, dev):
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    nets = []
+    for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
+        m = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed), strict=True)
+        nets.append(m.to(dev))
+    return nets
+
+
+def _short(k):
+    return k.replace("actor.", "").replace(".", "_")
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_actor_gradients_golden(dev, name):
+    """Backward with the fixture's picks given (teacher forcing): every actor gradient against the reference's autograd —
+    in full at H = 32, as norm, 64 seeded entries and a seeded projection per parameter at H = 256 — then clip + Adam."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.trainPNHigh import ActorAdam, actor_gradients
+    fx = golden(f"pn_train_{name}.npz")
+    low, high = _nets(fx, dev)
+    T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"])).to(dev)
+    R = torch.from_numpy(fx["R"]).to(dev)
+    gscale = ((R - R.mean()) / B).contiguous()                     # first batch: critic = R.mean() (trainPNHigh.py:87-92)
+    idx = torch.from_numpy(fx["idx_high"]).int().to(dev)
+    win_low = torch.from_numpy(fx["win_low"]).to(dev)
+    grads, logp = actor_gradients(high.actor, x, idx, win_low, gscale)
+    ops.check_status(dev)
+    loss = float(((R - R.mean()) * logp.sum(1)).mean())
+    assert abs(loss - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"]))), (loss, float(fx["loss"]))
+    worst = 0.0
+    g = torch.Generator().manual_seed(int(fx["seed_low"]))         # the generator's seed = `seed` of gen_pn_train
+    for k in optr.PARAM_KEYS:
+        got = grads[k.replace("actor.", "")].detach().cpu()
+        s = _short(k)
+        if f"grad_{s}" in fx.files:
+            want = torch.from_numpy(fx[f"grad_{s}"])
+            rel = float((got - want).norm() / (want.norm() + 1e-20))
+        else:
+            flat = got.flatten()
+            pos = torch.randint(0, flat.numel(), (64,), generator=g)          # the generator's draws, in its order
+            vec = torch.randn(flat.numel(), generator=g)
+            assert np.array_equal(pos.numpy(), fx[f"gradpos_{s}"])
+            want_n = float(fx[f"gradnorm_{s}"])
+            rel = abs(float(flat.norm()) - want_n) / (want_n + 1e-20)
+            assert float((flat[pos] - torch.from_numpy(fx[f"gradval_{s}"])).abs().max()) < GRAD_RTOL * want_n + 1e-7, k
+            proj = float((flat.double() * vec.double()).sum())                # a seeded random projection of the whole tensor
+            assert abs(proj - float(fx[f"gradproj_{s}"])) < 2 * GRAD_RTOL * want_n * float(vec.norm()) / np.sqrt(flat.numel()) * 4 + 1e-7, k
+        worst = max(worst, rel)
+        assert rel < GRAD_RTOL, f"{k}: relative gradient error {rel:.2e}"
+    # clip_grad_norm_ + Adam (first step)
+    opt = ActorAdam(high.actor, lr=0.5e-4, max_grad_norm=2.0)
+    norm = float(opt.step(grads))
+    assert abs(norm - float(fx["grad_norm"])) < 2e-4 * float(fx["grad_norm"])
+    for k in optr.PARAM_KEYS:
+        s = _short(k)
+        new = dict(high.actor.named_parameters())[k.replace("actor.", "")].detach().cpu()
+        if f"new_{s}" in fx.files:
+            want, gref = torch.from_numpy(fx[f"new_{s}"]), torch.from_numpy(fx[f"grad_{s}"])
+            clear = gref.abs() > 1e-5                               # Adam's first step is ill-conditioned near g = 0
+            assert float(((new - want).abs() * clear).max()) < 3e-6, k
+            assert float((new - want).abs().max()) <= 1.01e-4, k
+        else:
+            pos = torch.from_numpy(fx[f"gradpos_{s}"])
+            clear = torch.from_numpy(np.abs(fx[f"gradval_{s}"]) > 1e-5)
+            assert float(((new.flatten()[pos] - torch.from_numpy(fx[f"newval_{s}"])).abs() * clear).max()) < 3e-6, k
+
+
+def test_actor_gradients_vs_live_autograd(dev):
+    """A shape that is not a stored fixture (T=9, K=4, B=12, H=256, one dummy category): gradients against the oracle's
+    torch-autograd restatement run live, including the seeded projection check on the big matrices."""
+    from gnnpn_sc_amd.trainPNHigh import actor_gradients
+    cfg = {"hidden": 256, "n_cat": 9, "n_per": 4, "seed_low": 301, "seed_high": 302}
+    low, high = _nets(cfg, dev)
+    T, K, B = 9, 4, 12
+    x = pn_inputs(B, T, K, 303, dummy_every=4)
+    sd_low, sd_high = opn.make_state_dict(256, 301), opn.make_state_dict(256, 302)
+    ref = optr.train_step(sd_low, sd_high, x, T, K, sample_seed=99)
+    gscale = (ref["advantage"] / B).contiguous().to(dev)
+    grads, logp = actor_gradients(high.actor, x.to(dev), ref["idx_high"].int().to(dev), ref["win_low"].to(dev), gscale)
+    assert float((logp.cpu().exp() - ref["pick_prob"]).abs().max()) < 1e-5
+    for k in optr.PARAM_KEYS:
+        got, want = grads[k.replace("actor.", "")].cpu(), ref["grads"][k]
+        rel = float((got - want).norm() / (want.norm() + 1e-20))
+        assert rel < GRAD_RTOL, f"{k}: {rel:.2e}"
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_train_step_end_to_end(dev, name):
+    """TrainModel.train_step (trainPNHigh.py:81-110 in one call): sampled forward with the fixture's stream, backward, clip,
+    Adam.  Where the drawn picks equal the reference's (they do unless a draw is fragile) loss and gradient norm match, the
+    weights move, the inference kernels see the new weights, and a second step runs from the updated critic."""
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    from gnnpn_sc_amd.trainPNHigh import TrainModel
+    fx = golden(f"pn_train_{name}.npz")
+    low, high = _nets(fx, dev)
+    T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
+    tm = TrainModel(high, None, None, 1, 0.9, True, "QWS", T, lr=0.5e-4, batch_size=B, max_grad_norm=2., low_model=low, device=str(dev))
+    before = {k: p.detach().clone() for k, p in high.actor.named_parameters()}
+    greedy_before = two_level_greedy(low, high, x.to(dev))
+    out = tm.train_step(x, sample_seed=int(fx["sample_seed"]))
+    same = np.array_equal(out["idx_high"].cpu().numpy(), fx["idx_high"])
+    if same:
+        assert abs(float(out["loss"]) - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"])))
+        assert abs(float(out["grad_norm"]) - float(fx["grad_norm"])) < 2e-4 * float(fx["grad_norm"])
+    assert float((out["R"].cpu() - torch.from_numpy(fx["R"])).abs().max()) < 1e-4 or not same
+    moved = max(float((p.detach() - before[k]).abs().max()) for k, p in high.actor.named_parameters())
+    assert 1e-5 < moved <= 1.01e-4                                  # Adam's first step: lr-sized moves (lr = 0.5e-4 ... bias-corrected)
+    greedy_after = two_level_greedy(low, high, x.to(dev))           # the inference path re-packs the updated weights
+    assert not torch.equal(greedy_after["win_high_raw"], greedy_before["win_high_raw"])
+    out2 = tm.train_step(x)                                         # critic moving average (:89-90), own sampling stream
+    assert np.isfinite(float(out2["loss"])) and tm.actor_optim.steps == 2 and len(tm.train_tour) == 2

@@ -215,3 +215,37 @@ def test_pn_oracle_sampling_mode_reproduces_reference(name):
     assert float((greedy["idx_high"].numpy() != fx["idx_high"]).mean()) > 0.3
     u = [float(opn.stream_uniform24(7, c)) for c in range(4000)]
     assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.02      # the stream is a sane uniform
+
+
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_training_oracle_reproduces_reference_autograd(name):
+    """pn_train_*.npz: one REINFORCE step of the PNHigh trainer on the REAL reference modules and their autograd
+    (trainPNHigh.py:83-108).  The oracle's restatement (oracle/pn_train.py) reproduces picks, loss, every gradient (2e-4
+    relative per parameter; measured 4e-6) and the clipped-Adam weights (where |g| is clear of Adam's eps)."""
+    from oracle import pn_train as optr
+    from pn_inputs import pn_inputs
+    fx = golden(f"pn_train_{name}.npz")
+    torch.set_num_threads(4)
+    H, T, K, B = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
+    out = optr.train_step(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])), x, T, K,
+                          int(fx["sample_seed"]))
+    assert np.array_equal(out["idx_high"].numpy(), fx["idx_high"])
+    assert abs(float(out["loss"]) - float(fx["loss"])) < 1e-6 and abs(float(out["grad_norm"]) - float(fx["grad_norm"])) < 1e-5
+    g = torch.Generator().manual_seed(int(fx["seed_low"]))
+    for k in optr.PARAM_KEYS:
+        s = k.replace("actor.", "").replace(".", "_")
+        got = out["grads"][k]
+        if f"grad_{s}" in fx.files:
+            want = torch.from_numpy(fx[f"grad_{s}"])
+            assert float((got - want).norm() / (want.norm() + 1e-20)) < 2e-4, k
+            clear = want.abs() > 1e-5
+            assert float(((out["new_params"][k] - torch.from_numpy(fx[f"new_{s}"])).abs() * clear).max()) < 2e-6, k
+        else:
+            pos = torch.randint(0, got.numel(), (64,), generator=g)
+            vec = torch.randn(got.numel(), generator=g)
+            assert np.array_equal(pos.numpy(), fx[f"gradpos_{s}"])
+            n = float(fx[f"gradnorm_{s}"])
+            assert abs(float(got.norm()) - n) < 2e-4 * n, k
+            assert float((got.flatten()[pos] - torch.from_numpy(fx[f"gradval_{s}"])).abs().max()) < 2e-4 * n + 1e-8, k
+            assert abs(float((got.flatten().double() * vec.double()).sum()) - float(fx[f"gradproj_{s}"])) < 2e-3 * n + 1e-7, k
