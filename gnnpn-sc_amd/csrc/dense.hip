@@ -228,7 +228,7 @@ __device__ __forceinline__ void gemm_tile_to_lds(const float* __restrict__ P, in
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                        int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                       int K) {
+                                                       int K, int k_chunk) {
     constexpr int BM = 64, BN = 64;
     __shared__ float As[32 * (BM + 1)];
     __shared__ float Bs[32 * (BN + 1)];
@@ -240,9 +240,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int half = lane >> 5, l32 = lane & 31;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        gemm_tile_to_lds<BM, A_KMAJOR>(A, lda, m0, M, k0, K, As);
-        gemm_tile_to_lds<BN, B_KMAJOR>(Bm, ldb, n0, N, k0, K, Bs);
+    // split-K: slice blockIdx.z reduces k in [z*k_chunk, (z+1)*k_chunk) into its own partial matrix C[z] (the caller sums the
+    // partials in slice order: deterministic, no atomics) — the weight-gradient GEMMs have K = B*L >> M, N
+    const int k_begin = blockIdx.z * k_chunk, k_end = min(K, k_begin + k_chunk);
+    C += (int64_t)blockIdx.z * M * ldc;
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        gemm_tile_to_lds<BM, A_KMAJOR>(A, lda, m0, M, k0, k_end, As);
+        gemm_tile_to_lds<BN, B_KMAJOR>(Bm, ldb, n0, N, k0, k_end, Bs);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 2) {
@@ -262,17 +266,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 extern "C" int gnnpn_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
-                              int64_t ldc, int64_t M, int N, int K, void* stream) {
+                              int64_t ldc, int64_t M, int N, int K, int split_k, void* stream) {
     GNNPN_REQUIRE(A && B && C, "gemm: null operand");
     GNNPN_REQUIRE(M >= 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     GNNPN_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K), "gemm: leading dimension too small");
+    GNNPN_REQUIRE(split_k >= 1 && split_k <= 1024, "gemm: split_k must be 1..1024");
     if (M == 0) return GNNPN_OK;
-    dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
+    const int k_chunk = ((K + split_k - 1) / split_k + 31) / 32 * 32;
+    dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64), (unsigned)split_k);
     hipStream_t s = (hipStream_t)stream;
-    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
-    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
-    else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk);
     GNNPN_CHECK_LAUNCH("gemm_f32");
     return GNNPN_OK;
 }

@@ -22,21 +22,16 @@ namespace {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// acc[g] += sum_k W[g*H + j][k] * v[k]  (forward product, W row-major [4H,H]: thread j reads 4 rows)
+// acc[g] += sum_k W[g*H + j][k] * v[k]  (forward product) from the TRANSPOSED matrix Wt[k][g*H + j] (k-major [H,4H]): for a
+// fixed k the threads j of a wave read consecutive floats; k-ascending fma chain per gate
 template <int H>
-__device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* v, int j, float (&acc)[4]) {
+__device__ __forceinline__ void matvec_rows(const float* __restrict__ Wt, const float* v, int j, float (&acc)[4]) {
+#pragma unroll 4
+    for (int k = 0; k < H; ++k) {
+        const float vk = v[k];
+        const float* row = Wt + (size_t)k * (4 * H) + j;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4* row = reinterpret_cast<const float4*>(W + (size_t)(g * H + j) * H);
-        float a = acc[g];
-        for (int k4 = 0; k4 < H / 4; ++k4) {
-            const float4 w = row[k4];
-            a = fmaf(w.x, v[4 * k4 + 0], a);
-            a = fmaf(w.y, v[4 * k4 + 1], a);
-            a = fmaf(w.z, v[4 * k4 + 2], a);
-            a = fmaf(w.w, v[4 * k4 + 3], a);
-        }
-        acc[g] = a;
+        for (int g = 0; g < 4; ++g) acc[g] = fmaf(row[g * H], vk, acc[g]);
     }
 }
 // sum_gu W[gu][j] * d[gu]  (transposed product: column j of W, coalesced across the threads of a wave)
@@ -106,7 +101,7 @@ struct DecTrain {
     const float* h0;         // [B,H]  encoder final h (= enc_out[:, L-1])
     const float* c0;         // [B,H]
     const float* start;      // [H]
-    const float* wih;        // [4H,H] row-major (not packed)
+    const float* wih;        // TRANSPOSED [H,4H] (forward products); the backward takes the plain [4H,H]
     const float* whh;
     const float* bih;
     const float* bhh;
@@ -306,6 +301,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     __syncthreads();
     if (ry == 0 && c < cols) out[c] = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
 }
+__global__ __launch_bounds__(256) void colsum_chunks_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int cols,
+                                                            int64_t per, float* __restrict__ partial) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+    float acc = 0.0f;
+    if (c < cols)
+        for (int64_t r = r0 + ry; r < r1; r += 4) acc += X[r * ld + c];
+    part[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+}
 // dst[idx[b*T + k], :] += src[b*T + k, :] for k >= 1 ... see the launcher: scatter of the decoder-input gradients into
 // d_embedded (the rows a problem picks are distinct: one window per step) and of step 0 into the start-input sum buffer
 __global__ void scatter_dx_kernel(const float* __restrict__ dx, const int32_t* __restrict__ idx, float* __restrict__ d_embedded,
@@ -417,6 +425,17 @@ extern "C" int gnnpn_colsum_f32(const float* X, int64_t ld, int64_t rows, int32_
     GNNPN_REQUIRE(X && out && rows >= 0 && cols > 0 && ld >= cols, "colsum: bad argument");
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ld, rows, cols, out);
     GNNPN_CHECK_LAUNCH("colsum_f32");
+    return GNNPN_OK;
+}
+
+extern "C" int gnnpn_colsum_chunks_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, int64_t rows_per_chunk,
+                                       float* partial, void* stream) {
+    GNNPN_REQUIRE(X && partial && rows >= 0 && cols > 0 && ld >= cols && rows_per_chunk > 0, "colsum_chunks: bad argument");
+    const int64_t chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+    if (chunks == 0) return GNNPN_OK;
+    hipLaunchKernelGGL(colsum_chunks_kernel, dim3((cols + 63) / 64, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, X, ld,
+                       rows, cols, rows_per_chunk, partial);
+    GNNPN_CHECK_LAUNCH("colsum_chunks_f32");
     return GNNPN_OK;
 }
 

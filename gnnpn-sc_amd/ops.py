@@ -480,9 +480,13 @@ def gemm(a, b, a_kmajor=False, b_kmajor=False):
     N, Kb = (b.shape[1], b.shape[0]) if b_kmajor else b.shape
     if K != Kb:
         raise GnnpnError(f"gemm: K mismatch {tuple(a.shape)} x {tuple(b.shape)}")
-    c = torch.empty((M, N), dtype=F32, device=a.device)
+    tiles = -(-M // 64) * -(-N // 64)
+    split = 1 if tiles >= 256 or K < 2048 else max(1, min(64, 512 // tiles, K // 512))   # fill the chip when K >> M, N
+    c = torch.empty((split, M, N) if split > 1 else (M, N), dtype=F32, device=a.device)
     check(_lib.load().gnnpn_gemm_f32(dev_ptr(a, F32, "a"), a.shape[1], int(a_kmajor), dev_ptr(b, F32, "b"), b.shape[1],
-                                     int(b_kmajor), dev_ptr(c, F32, "c"), N, M, N, K, stream_ptr()), "gnnpn_gemm_f32")
+                                     int(b_kmajor), dev_ptr(c, F32, "c"), N, M, N, K, split, stream_ptr()), "gnnpn_gemm_f32")
+    if split > 1:                                         # the partial matrices summed in slice order
+        c = colsum(c.view(split, M * N)).view(M, N)
     return c
 
 
@@ -491,6 +495,13 @@ def colsum(x, rows=None, cols=None, ld=None):
     rows = x.shape[0] if rows is None else rows
     cols = x.shape[-1] if cols is None else cols
     ld = x.shape[-1] if ld is None else ld
+    if rows >= 4096:                                      # two passes: the first fills the chip
+        per = -(-rows // min(128, rows // 256))
+        chunks = -(-rows // per)
+        partial = torch.empty((chunks, cols), dtype=F32, device=x.device)
+        check(_lib.load().gnnpn_colsum_chunks_f32(dev_ptr(x, F32, "x"), ld, rows, cols, per, dev_ptr(partial, F32, "partial"),
+                                                  stream_ptr()), "gnnpn_colsum_chunks_f32")
+        x, rows, ld = partial, chunks, cols
     out = torch.empty(cols, dtype=F32, device=x.device)
     check(_lib.load().gnnpn_colsum_f32(dev_ptr(x, F32, "x"), ld, rows, cols, dev_ptr(out, F32, "out"), stream_ptr()),
           "gnnpn_colsum_f32")

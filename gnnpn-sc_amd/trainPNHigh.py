@@ -32,11 +32,13 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     flat = inputs.reshape(B * L, F).contiguous()
     embedded = ops.linear(flat, p["embedding2.weight"], p["embedding2.bias"])                          # modelPN.py:190
     pregates = ops.linear(embedded, p["encoder.weight_ih_l0"], p["encoder.bias_ih_l0"]).view(B, L, 4 * H)
-    enc_out, gates_e, c_e = ops.lstm_train_forward(pregates, p["encoder.weight_hh_l0"], p["encoder.bias_hh_l0"])   # :191
+    tr = lambda w: w.t().contiguous()                                                                  # noqa: E731  [4H,H] -> k-major [H,4H]
+    enc_out, gates_e, c_e = ops.lstm_train_forward(pregates, tr(p["encoder.weight_hh_l0"]), p["encoder.bias_hh_l0"])   # :191
     h0, c0 = enc_out[:, L - 1].contiguous(), c_e[:, L - 1].contiguous()
     d = ops.decode_train_forward(embedded.view(B, L, H), enc_out, h0, c0, p["decoder_start_input"],
-                                 p["decoder.weight_ih_l0"], p["decoder.weight_hh_l0"], p["decoder.bias_ih_l0"],
+                                 tr(p["decoder.weight_ih_l0"]), tr(p["decoder.weight_hh_l0"]), p["decoder.bias_ih_l0"],
                                  p["decoder.bias_hh_l0"], latent_win, idx, T, K, actor.C, actor.use_tanh)   # :204-239
+    d.update(wih=p["decoder.weight_ih_l0"], whh=p["decoder.weight_hh_l0"])                             # the backward's layout
     d_enc_out, dg_d, dx, dh0, dc0 = ops.decode_train_backward(d, gscale)
     dg_e = ops.lstm_train_backward(p["encoder.weight_hh_l0"], gates_e, c_e, d_enc_out, dh0, dc0)
     g = {}

@@ -337,11 +337,14 @@ int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, i
  * REINFORCE training step of the High-level pointer network.  Replaces the autograd graph of
  * src/models/trainPNHigh.py:84-108 over src/models/modelPN.py:175-306: actor_loss.backward() (:103-104), clip_grad_norm_
  * (:105-106) and actor_optim.step() (:108).  The picks of the step come from the sampled forward (gnnpn_pointer_decode_f32
- * with sample = 1) and are constants of the differentiated graph.  All weights here are the PLAIN row-major [4H,H]
- * matrices of the state_dict (not the packed inference layout).  H must be 256 or 32.
+ * with sample = 1) and are constants of the differentiated graph.  Weights: the two FORWARD entry points take the LSTM
+ * matrices TRANSPOSED ([H,4H], k-major: coalesced forward products), the two BACKWARD entry points the plain row-major
+ * [4H,H] matrices of the state_dict (coalesced transposed products).  H must be 256 or 32.
  *
  * gnnpn_gemm_f32: C[m,n] = sum_k Aop[m,k]*Bop[n,k], Aop[m,k] = a_kmajor ? A[k*lda+m] : A[m*lda+k] (same for B): weight
  *   gradients dW = dG^T . X (both operands k-major, k = the B*L rows of saved activations) and dX = dG . W (B k-major).
+ *   split_k > 1: C holds split_k partial matrices [split_k][M][ldc], slice s reducing its own k range; the caller adds them
+ *   in slice order (gnnpn_colsum_f32 over rows = split_k): deterministic, and K = B*L >> M, N fills the chip.
  * gnnpn_lstm_train_forward_f32: the encoder recurrence from pregates [B,L,4H] (= embedded . W_ih^T + b_ih), saving the full
  *   pre-activation gates [B,L,4H] and the cell states [B,L,H] besides enc_out.
  * gnnpn_decode_train_forward_f32: the decode loop with the picks idx [B,T] GIVEN (teacher forcing), saving decoder inputs,
@@ -361,7 +364,7 @@ typedef struct {
     const float* h0;         /* [B,H] encoder final h */
     const float* c0;         /* [B,H] encoder final c */
     const float* start;      /* [H] decoder_start_input */
-    const float* wih;        /* decoder LSTM, row-major [4H,H] */
+    const float* wih;        /* decoder LSTM: forward: transposed [H,4H]; backward: row-major [4H,H] */
     const float* whh;
     const float* bih;
     const float* bhh;
@@ -376,7 +379,7 @@ typedef struct {
     float* logp;             /* [B,T] */
 } gnnpn_decode_train_t;
 int gnnpn_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
-                   int64_t ldc, int64_t M, int N, int K, void* stream);
+                   int64_t ldc, int64_t M, int N, int K, int split_k, void* stream);
 int gnnpn_lstm_train_forward_f32(const float* pregates, const float* whh, const float* bhh, float* enc_out,
                                  float* gates_pre, float* c_all, int32_t B, int32_t L, int32_t H, void* stream);
 int gnnpn_decode_train_forward_f32(const gnnpn_decode_train_t* t, int32_t B, int32_t T, int32_t n_per, int32_t H,
@@ -388,6 +391,9 @@ int gnnpn_lstm_train_backward_f32(const float* whh, const float* gates_pre, cons
                                   const float* dh0, const float* dc0, float* dgates, int32_t B, int32_t L, int32_t H,
                                   void* stream);
 int gnnpn_colsum_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, float* out, void* stream);
+/* first pass of a two-pass column sum over many rows: partial[c][col] = sum of rows [c*rows_per_chunk, (c+1)*rows_per_chunk) */
+int gnnpn_colsum_chunks_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, int64_t rows_per_chunk, float* partial,
+                            void* stream);
 int gnnpn_scatter_dx_f32(const float* dx, const int32_t* idx, float* d_embedded, int32_t B, int32_t T, int32_t L, int32_t H,
                          void* stream);
 int gnnpn_sumsq_f32(const float* x, int64_t n, double* accum, void* stream);

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import golden, record_agreement
 from oracle import pn as opn
 from oracle import pn_train as optr
 from pn_inputs import pn_inputs
@@ -67,6 +67,8 @@ def test_actor_gradients_golden(dev, name):
             assert abs(proj - float(fx[f"gradproj_{s}"])) < 2 * GRAD_RTOL * want_n * float(vec.norm()) / np.sqrt(flat.numel()) * 4 + 1e-7, k
         worst = max(worst, rel)
         assert rel < GRAD_RTOL, f"{k}: relative gradient error {rel:.2e}"
+    record_agreement(f"train_gradients_{name}", {"worst_relative_gradient_error": worst, "loss": loss, "loss_reference": float(fx["loss"]),
+                                                 "parameters": len(optr.PARAM_KEYS), "B": B, "T": T, "K": K})
     # clip_grad_norm_ + Adam (first step)
     opt = ActorAdam(high.actor, lr=0.5e-4, max_grad_norm=2.0)
     norm = float(opt.step(grads))
