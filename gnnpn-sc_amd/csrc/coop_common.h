@@ -66,6 +66,25 @@ inline unsigned coop_lds_padding(const void* func, int target_kb) {
     return (unsigned)dyn;
 }
 
+// Zeroing of the hand-off workspace before every launch (status words, claim table, every granule tag).  A kernel of our
+// own rather than hipMemsetAsync: with two captured graphs replaying on two streams, the memset NODES of one graph were
+// observed to fill with a 16-byte pattern made of another launch's kernel arguments (tools/soak_pipeline.py: persistent
+// garbage in the status area after a few hundred steps, results wrong from then on) — the fill pattern of a captured
+// memset lives in runtime-managed memory that gets recycled; a kernel node carries its arguments by value.
+namespace {   // one copy per translation unit
+__global__ __launch_bounds__(256) void coop_zero_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+}  // namespace
+inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t s) {   // bytes: a multiple of 16
+    const size_t n16 = bytes / 16;
+    unsigned blocks = (unsigned)((n16 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(coop_zero_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint4*>(workspace), n16);
+    return hipGetLastError();
+}
+
 // Called by every thread of the workgroup.  false: surplus workgroup (leave at once).  `slot` is two ints of LDS.
 // A surplus workgroup that lands on an already claimed CU while the launch is not fully staffed keeps its slot for up to
 // 16 us (or until staffing completes) before it exits: while it sits there the dispatcher can only place the launch's

@@ -525,7 +525,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
+    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
     char* base = static_cast<char*>(workspace);
     u64* p_h = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES);

@@ -369,7 +369,7 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     const int64_t l_bytes = (int64_t)n_tiles * args.T * ROWS * args.K * 8;
     const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256)) return GNNPN_E_UNSUP;
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return GNNPN_E_UNSUP;
+    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess) return GNNPN_E_UNSUP;
     char* base = static_cast<char*>(workspace);
     u64* p_h = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES);
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);

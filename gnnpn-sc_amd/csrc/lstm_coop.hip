@@ -361,7 +361,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
     // zero the status word and every tag before each launch (tags start at 1)
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
+    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
     u64* p_x = reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES);
     unsigned* p_e = reinterpret_cast<unsigned*>(workspace);

@@ -390,3 +390,40 @@ def test_two_slots_whichever_starts_first(dev):
             w = runner.workspaces[s]
             placed = int(w.encode()[4:8].view(torch.int32).item())
             assert placed == 256, placed                         # 32 groups x 8 members, one per CU
+
+
+@pytest.mark.parametrize("precision", ["f32", "split"])
+def test_soak_two_slots(dev, precision):
+    """2,000 pipelined steps, a different batch every step, eager work on the default stream in between (what recycled the
+    runtime's staging memory under the captured memset nodes this used to rely on): every output of every step equals
+    the single-stream run of the same batch, bit for bit, and no launch reports a failed hand-off.
+    (tools/soak_pipeline.py is the 20,000-step form.)"""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 64
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K, precision=precision)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=200 + i, tasks_per_problem=10), dev)
+               for i in range(6)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    keys = ("idx_low", "idx_high", "R", "actions")
+    pending, bad = [], 0
+    for i in range(2000):
+        v = (i * 5 + i // 7) % len(batches)
+        out, s = runner.submit(batches[v])
+        ev = torch.cuda.Event()
+        ev.record(runner.stream(s))
+        pending.append((v, ev, out))
+        if len(pending) == 2:
+            vj, evj, oj = pending.pop(0)
+            evj.synchronize()
+            bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
+    for vj, evj, oj in pending:
+        evj.synchronize()
+        bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
+    runner.synchronize(check=True)
+    assert bad == 0, f"{bad} of 2000 pipelined steps differ from the single-stream run"
