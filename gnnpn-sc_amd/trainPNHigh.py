@@ -109,7 +109,12 @@ class TrainModel:
         inputs = inputs.to(self.device).contiguous()
         ha = self.model.actor
         seed = ha.next_sample_seed() if sample_seed is None else int(sample_seed)
-        out = two_level_greedy(self.low_model, self.model, inputs, sample_high_seed=seed)          # :83-84
+        if self.low_model is not None:
+            out = two_level_greedy(self.low_model, self.model, inputs, sample_high_seed=seed)      # :83-84
+        else:                                   # the PNLow trainer (trainPNLow.py:80-84): one net, no latent
+            o = ha.run(inputs, None, sample_seed=seed)
+            out = {"idx_high": o["idx"], "idx_low": o["idx"], "win_low": None,
+                   "R": torch.ops.gnnpn.qos_reward(o["actions"], 0 if self.model.level == "Low" else 1)}
         R = out["R"]
         if self.critic_exp_mvg_avg is None:                                                        # :87-90
             self.critic_exp_mvg_avg = R.mean()
@@ -139,8 +144,12 @@ class TrainModel:
         checkpoints / allActions artefacts of every ``epochDiv``-th epoch."""
         import json
         loader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=0)
+        if self.low_model is None:
+            return self._train_and_validate_low(loader, n_epochs, epochDiv)
         for epoch in range(1, n_epochs + 1):
-            for sample_batch, _labs in loader:
+            for batch_id, (sample_batch, _labs) in enumerate(loader):
+                if batch_id == 0:
+                    self.critic_exp_mvg_avg = None                                                 # :87-88 restarts every epoch
                 self.train_step(sample_batch)
             if self.threshold and self.train_tour[-1] < self.threshold:
                 print("EARLY STOPPAGE!")
@@ -158,3 +167,103 @@ class TrainModel:
                     json.dump(acts, f)
                 self.val_tour.append(sum(tour) / max(len(tour), 1))
             self.epochs += 1
+
+    def _train_and_validate_low(self, loader, n_epochs, epochDiv):
+        """trainPNLow.py:71-147 (the Low net alone): checkpoints, allActions / allR / val artefacts of every epochDiv-th epoch."""
+        import json
+        for epoch in range(1, n_epochs + 1):
+            for batch_id, (sample_batch, _labs) in enumerate(loader):
+                if batch_id == 0:
+                    self.critic_exp_mvg_avg = None
+                self.train_step(sample_batch)
+            if self.threshold and self.train_tour[-1] < self.threshold:
+                print("EARLY STOPPAGE!")
+                break
+            if epoch % epochDiv == 0:
+                n = self.epochs // epochDiv
+                os.makedirs(f"./solutions/PNLow/{self.dataset}", exist_ok=True)
+                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": {}},
+                           f"./solutions/PNLow/{self.dataset}/epoch{n}.model")                     # trainPNLow.py:112-117
+                all_actions = [[] for _ in range(self.serCategory + 2)]                            # :122
+                all_r = {"quality": [], "averageQ": 0}
+                for lo in range(0, len(self.val_dataset), 128):                                    # :127-135 (default sample="sample")
+                    x = torch.stack([self.val_dataset[i][0] for i in range(lo, min(len(self.val_dataset), lo + 128))])
+                    R, _, actions, _, _ = self.model(x.to(self.device), None)
+                    all_r["quality"] += R.cpu().numpy().tolist()
+                    for a in range(len(actions)):
+                        all_actions[a] += actions[a].cpu().numpy().tolist()
+                    self.val_tour.append(float(R.mean().item()))
+                ops.check_status(self.device)
+                with open(f"./solutions/PNLow/{self.dataset}/allActions{n}.txt", "w") as f:
+                    json.dump(all_actions, f)
+                with open(f"./solutions/PNLow/{self.dataset}/allR{n}.txt", "w") as f:
+                    if all_r["quality"]:
+                        all_r["averageQ"] = sum(all_r["quality"]) / len(all_r["quality"])
+                        json.dump(all_r, f)
+                with open(f"./solutions/PNLow/{self.dataset}/val{n}.txt", "w") as f:
+                    json.dump(self.val_tour, f)
+            self.epochs += 1
+
+
+def _pointer_model(level, hidden_size, n_glimpses, tanh_exploration, use_tanh, serNumber, serCategory, use_cuda):
+    from .modelPN import CombinatorialRL, reward
+    return CombinatorialRL(0, hidden_size, serCategory * serNumber, n_glimpses, tanh_exploration, use_tanh, reward,
+                           attention="Dot", level=level, use_cuda=use_cuda, sNumber=serNumber, sCategory=serCategory)
+
+
+class PNHigh:
+    """PNHigh (trainPNHigh.py:175-251): same constructor; ``start`` loads the candidate rows (loadDataPN), the trained Low
+    net (./solutions/PNLow/<ds>/epoch{n}.model or ./solutions/pretrained/<ds>-PNLow.model) and trains the High net."""
+
+    def __init__(self, dataset, embeddingTag, USE_CUDA, serCategory, epochDiv, serNumber, hidden_size, n_glimpses,
+                 tanh_exploration, use_tanh, beta, max_grad_norm, lr, epochML, epochPNLow):
+        if embeddingTag:
+            raise NotImplementedError("embeddingTag=1 is outside the shipped configuration (environment.ini:50,66)")
+        self.dataset = dataset + "/"
+        self.USE_CUDA, self.serCategory, self.epochDiv, self.serNumber = USE_CUDA, serCategory, epochDiv, serNumber
+        self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh = hidden_size, n_glimpses, tanh_exploration, use_tanh
+        self.beta, self.max_grad_norm, self.lr, self.epochML, self.epochPNLow = beta, max_grad_norm, lr, epochML, epochPNLow
+
+    def start(self, n_epochs=100, device="cuda:0", batch_size=128):
+        from .loadData import loadDataPN
+        rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :196
+        n_train = len(rows) // 4 * 3
+        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], False)
+        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], False)
+        args = (self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber, self.serCategory, self.USE_CUDA)
+        low, high = _pointer_model("Low", *args), _pointer_model("High", *args)
+        root = (f"./solutions/PNLow/{self.dataset}/epoch{self.epochPNLow}.model" if self.epochPNLow >= 0 else
+                f"./solutions/pretrained/{self.dataset[:-1]}-PNLow.model")                          # :237-240
+        low.load_state_dict(torch.load(root, map_location="cpu")["model"])                         # :241-242
+        dev = torch.device(device)
+        tm = TrainModel(high.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, self.dataset[:-1], self.serCategory,
+                        self.lr, batch_size, None, self.max_grad_norm, low_model=low.to(dev), device=device)
+        tm.train_and_validate(n_epochs, self.epochDiv)                                             # :251
+        return tm
+
+
+class PNLow:
+    """PNLow (trainPNLow.py:172-223): same constructor; trains the Low net (reward = number of violated constraints)."""
+
+    def __init__(self, dataset, embeddingTag, USE_CUDA, serCategory, epochDiv, serNumber, hidden_size, n_glimpses,
+                 tanh_exploration, use_tanh, beta, max_grad_norm, lr, epochML):
+        if embeddingTag:
+            raise NotImplementedError("embeddingTag=1 is outside the shipped configuration (environment.ini:20)")
+        self.dataset = dataset + "/"
+        self.USE_CUDA, self.serCategory, self.epochDiv, self.serNumber = USE_CUDA, serCategory, epochDiv, serNumber
+        self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh = hidden_size, n_glimpses, tanh_exploration, use_tanh
+        self.beta, self.max_grad_norm, self.lr, self.epochML = beta, max_grad_norm, lr, epochML
+
+    def start(self, n_epochs=50, device="cuda:0", batch_size=128):
+        from .loadData import loadDataPN
+        rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :190-191
+        n_train = len(rows) // 4 * 3
+        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], False)
+        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], False)
+        model = _pointer_model("Low", self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber,
+                               self.serCategory, self.USE_CUDA)
+        dev = torch.device(device)
+        tm = TrainModel(model.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, self.dataset[:-1], self.serCategory,
+                        self.lr, batch_size, None, self.max_grad_norm, low_model=None, device=device)
+        tm.train_and_validate(n_epochs, self.epochDiv)                                             # :223
+        return tm

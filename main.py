@@ -11,7 +11,10 @@
     python main.py QWS WOA [epoch]       # ES-WOA fine-tuning of the ML+2PN solution on the GPU (reference main.py:86-104,
                                          # mode ML2PNWOATest of [<ds>-WOA]); --seed N makes the run reproducible
 
-Every other approach of the reference (training, the other WOA modes, GA/DQN baselines) is out of scope and
+    python main.py QWS PNLow [epochML]   # REINFORCE training of the Low pointer net on the GPU (reference main.py:40-52)
+    python main.py QWS PNHigh [epochML [epochPNLow]]   # ... of the High net against the trained Low net (:66-84); --epochs=N
+
+Every other approach of the reference (ML training, the other WOA modes, GA/DQN baselines) is out of scope and
 answers with the reference's own message.
 """
 import configparser
@@ -46,7 +49,7 @@ def main(argv):
         return 1
     dataset, approach = argv[1], argv[2]
     ds = {"QWS": "QWS", "qws": "QWS", "Normal": "Normal"}.get(dataset)
-    if ds is None or approach not in ("ML+2PN", "WOA"):
+    if ds is None or approach not in ("ML+2PN", "WOA", "PNLow", "PNHigh"):
         print("Please check the parameters!")                       # reference main.py:231
         return 1
     here = os.path.dirname(os.path.abspath(__file__))
@@ -66,6 +69,25 @@ def main(argv):
         WOA.WOA(ds, int(sec["serCategory"]), int(sec["MLESWOAtest"]), int(sec["ML2PNWOATest"]), int(sec["MLWOATest"]),
                 int(sec["ESWOAtest"]), int(sec["serviceNumber"]), reduct, epoch, int(sec["MAX_Iter"]), int(sec["popSize"]),
                 seed=seed).start()
+        return 0
+    if approach in ("PNLow", "PNHigh"):                             # reference main.py:40-84: REINFORCE training on the GPU
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from gnnpn_sc_amd import trainPNHigh
+        sec = cfg[f"{ds}-{approach}"]
+        pos = [a for a in argv[3:] if not a.startswith("--")]
+        n_epochs = next((int(a.split("=")[1]) for a in argv[3:] if a.startswith("--epochs=")), None)
+        common = (ds, int(sec["embeddingTag"]), int(sec["USE_CUDA"]), int(sec["serCategory"]), int(sec["epochDiv"]),
+                  int(sec["serNumber"]), int(sec["hidden_size"]), int(sec["n_glimpses"]), float(sec["tanh_exploration"]),
+                  int(sec["use_tanh"]), float(sec["beta"]), float(sec["max_grad_norm"]), float(sec["lr"]))
+        epoch_ml = int(pos[0]) if pos else int(sec["epochML"])      # argv[3] overrides epochML (reference main.py:37-38,59-60)
+        if approach == "PNLow":
+            drv = trainPNHigh.PNLow(*common, epoch_ml)
+            drv.start(**({"n_epochs": n_epochs} if n_epochs else {}))
+        else:
+            epoch_low = int(pos[1]) if len(pos) > 1 and epoch_ml != -1 else int(sec["epochPNLow"])   # :61-64
+            drv = trainPNHigh.PNHigh(*common, epoch_ml, epoch_low)
+            drv.start(**({"n_epochs": n_epochs} if n_epochs else {}))
         return 0
     sec = cfg[f"{ds}-ML+2PN"]
     flags = [a for a in argv[3:] if a.startswith("--")]
