@@ -337,3 +337,29 @@ def test_csr_aggregate_lds_staged_equals_gather(dev, S, copies, C, weighted, sel
         dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), None, dev_ptr(x, torch.float32, "x"), C, None, None, None,
         None, 0, dev_ptr(y, torch.float32, "y"), C, n, C, 20000, stream_ptr())
     assert rc == -2                                               # a block that cannot fit the LDS is refused (GNNPN_E_UNSUP)
+
+
+def test_gcn_layer_against_dense_fp64_formula(dev):
+    """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
+    D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation
+    (torch_geometric 1.7.0) is not available to pin against."""
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    n, e, cin, cout = 300, 4000, 24, 256
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = ei[:, ei[0] != ei[1]]
+    w = torch.rand(ei.shape[1], generator=g) + 0.1
+    x = torch.randn(n, cin, generator=g)
+    W = torch.randn(cin, cout, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((ei[1], ei[0]), w.double(), accumulate=True)
+    A += torch.eye(n, dtype=torch.float64)
+    dis = A.sum(1).pow(-0.5)
+    want = (dis[:, None] * A * dis[None, :]) @ (x.double() @ W.double()) + b.double()
+    csr = graph.gcn_csr(ei, w, n).to(dev)
+    norm = ops.gcn_norm(csr.rowptr, csr.col, csr.w)
+    xw = ops.linear(x.to(dev), W.t().contiguous().to(dev))
+    got = ops.csr_aggregate(csr.rowptr, csr.col, norm, xw, bias=b.to(dev))
+    assert float((got.double().cpu() - want).abs().max()) < 5e-5

@@ -249,3 +249,33 @@ def test_training_oracle_reproduces_reference_autograd(name):
             assert abs(float(got.norm()) - n) < 2e-4 * n, k
             assert float((got.flatten()[pos] - torch.from_numpy(fx[f"gradval_{s}"])).abs().max()) < 2e-4 * n + 1e-8, k
             assert abs(float((got.flatten().double() * vec.double()).sum()) - float(fx[f"gradproj_{s}"])) < 2e-3 * n + 1e-7, k
+
+
+def test_gcn_conv_against_dense_fp64_formula():
+    """Independent cross-check of the (unpinnable, third-party) GCNConv arithmetic: the layer written as the dense matrix
+    formula  D^-1/2 (A_w + I) D^-1/2 X W + b  in float64 — weighted adjacency with A[dst, src] = w, unit self loops
+    where none exist, degree = row sums over incoming weights — against oracle.ml.gcn_conv (the edge-list / scatter form
+    restated from PyG 1.7.0).  Random weighted graph with a few self loops and duplicate edges."""
+    g = torch.Generator().manual_seed(5)
+    n, e, cin, cout = 60, 400, 12, 20
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, :5] = torch.arange(5).repeat(2, 1)                       # explicit self loops keep their weight
+    w = torch.rand(e, generator=g) + 0.1
+    x = torch.randn(n, cin, generator=g)
+    W = torch.randn(cin, cout, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    A = torch.zeros(n, n, dtype=torch.float64)
+    for k in range(e):
+        s, d = int(ei[0, k]), int(ei[1, k])
+        if s != d:
+            A[d, s] += float(w[k])                                  # duplicates add up, as scatter_add does
+    loop = torch.ones(n, dtype=torch.float64)
+    for k in range(e):
+        if int(ei[0, k]) == int(ei[1, k]):
+            loop[int(ei[0, k])] = float(w[k])                       # add_remaining_self_loops: an existing loop keeps its weight
+    A += torch.diag(loop)
+    deg = A.sum(1)
+    dis = deg.pow(-0.5)
+    want = (dis[:, None] * A * dis[None, :]) @ (x.double() @ W.double()) + b.double()
+    got = oml.gcn_conv(x, ei, w, W, b)
+    assert float((got.double() - want).abs().max()) < 2e-5
