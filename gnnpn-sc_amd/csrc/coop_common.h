@@ -250,6 +250,25 @@ __device__ __forceinline__ void cell_update_pair2(f32x2 g0, f32x2 g1, bool lo_ha
     cst = fg * cst + ig * gg;          // -ffp-contract=off: two rounded products, one rounded sum
     h = og * cell_act2(cst, true);
 }
+// The same cell update without the duplicated half: of a lane's four rows the lower half-row (lanes c < 8, holding i and g)
+// finishes rows 0,1 and the upper one (c >= 8, holding f and o) rows 2,3.  g0 / g1: the lane's gate pre-activations of
+// rows 0..3 as two packed pairs each.  One DPP exchange per value: a lane sends the gate pair of the rows its PARTNER
+// finishes and receives the partner's gates of its own rows.  Element for element the arithmetic of cell_update_pair2 —
+// five packed activations per step instead of six, two state registers per lane instead of four.
+__device__ __forceinline__ void cell_update_split(const f32x2 (&g0)[2], const f32x2 (&g1)[2], bool lo_half, f32x2& cst, f32x2& h) {
+    f32x2 a0[2], a1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a0[q] = cell_act2(g0[q], false);          // sigmoid(i) | sigmoid(f)   rows 2q, 2q+1
+        a1[q] = cell_act2(g1[q], lo_half);        // tanh(g)    | sigmoid(o)
+    }
+    const f32x2 s0 = lo_half ? a0[1] : a0[0], s1 = lo_half ? a1[1] : a1[0];     // what the partner needs
+    const f32x2 t0 = {swap8(s0.x), swap8(s0.y)}, t1 = {swap8(s1.x), swap8(s1.y)};
+    const f32x2 ig = lo_half ? a0[0] : t0, gg = lo_half ? a1[0] : t1;           // own rows: 0,1 (lower) / 2,3 (upper)
+    const f32x2 fg = lo_half ? t0 : a0[1], og = lo_half ? t1 : a1[1];
+    cst = fg * cst + ig * gg;
+    h = og * cell_act2(cst, true);
+}
 __device__ __forceinline__ void cell_update_pair(float g0, float g1, bool lo_half, float& cst, float& h) {
     const float a0 = cell_act(g0, false);            // sigmoid(i) | sigmoid(f)
     const float a1 = cell_act(g1, lo_half);          // tanh(g)    | sigmoid(o)

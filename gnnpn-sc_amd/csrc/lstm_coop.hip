@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     bool first_tile = true;
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
         const int b0 = tile * ROWS;
-        float cst[4] = {0.f, 0.f, 0.f, 0.f};
-        float hlast[4] = {0.f, 0.f, 0.f, 0.f};
+        // cell state / output of the two rows this lane finishes: rows kq*4 + {0,1} (c < 8) or kq*4 + {2,3} (c >= 8)
+        f32x2 cst = {0.f, 0.f};
+        f32x2 hlast = {0.f, 0.f};
         // Input side, software-pipelined by one step: the loads of step t+1 are issued AFTER step t's
         // hand-off wait (vector-memory operations retire in issue order, so an HBM-latency load issued
         // before the sweep would be waited for by the sweep) and are consumed a whole step later.
@@ -268,38 +269,36 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             if (stamps) s4 = phase_stamp();
 
             u64* out_buf = xg + (step & 1) * (ROWS * H);
-            // all four rows' cells first (straight-line: the compiler interleaves the four dependent chains),
-            // then ONE predicated block of stores
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {   // two rows per pass: packed fp32 arithmetic (cell_act2)
+            // the four rows' gate sums, then ONE cell update per lane for the two rows it finishes (cell_update_split)
+            {
                 // gates = (h.W_hh^T + b_hh) + (x.W_ih^T + b_ih); lanes c<8 hold (i,g), c>=8 hold (f,o)
-                const f32x2 g0 = (f32x2{acc0[r], acc0[r + 1]} + pk_set(bh[0])) + f32x2{pg[0][r], pg[0][r + 1]};
-                const f32x2 g1 = (f32x2{acc1[r], acc1[r + 1]} + pk_set(bh[1])) + f32x2{pg[1][r], pg[1][r + 1]};
-                f32x2 cs = {cst[r], cst[r + 1]}, hh;
-                cell_update_pair2(g0, g1, c < 8, cs, hh);
-                cst[r] = cs.x;
-                cst[r + 1] = cs.y;
-                hlast[r] = hh.x;
-                hlast[r + 1] = hh.y;
+                f32x2 g0[2], g1[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    g0[q] = (f32x2{acc0[2 * q], acc0[2 * q + 1]} + pk_set(bh[0])) + f32x2{pg[0][2 * q], pg[0][2 * q + 1]};
+                    g1[q] = (f32x2{acc1[2 * q], acc1[2 * q + 1]} + pk_set(bh[1])) + f32x2{pg[1][2 * q], pg[1][2 * q + 1]};
+                }
+                cell_update_split(g0, g1, c < 8, cst, hlast);
             }
-            if (c < 8) {
-                u64* dst = out_buf + (kq * 4) * H + unit;
+            {
+                const int r0 = kq * 4 + (c < 8 ? 0 : 2);
+                u64* dst = out_buf + r0 * H + unit;
                 if (!(ablate & 16)) {
                     if (same_xcd) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) granule_store_l2(dst + r * H, step + 1, hlast[r]);
+                        granule_store_l2(dst, step + 1, hlast.x);
+                        granule_store_l2(dst + H, step + 1, hlast.y);
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) granule_store(dst + r * H, step + 1, hlast[r]);
+                        granule_store(dst, step + 1, hlast.x);
+                        granule_store(dst + H, step + 1, hlast.y);
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hst[kq * 4 + r][wave * 8 + (c & 7)] = hlast[r];
+                hst[r0][wave * 8 + (c & 7)] = hlast.x;
+                hst[r0 + 1][wave * 8 + (c & 7)] = hlast.y;
             }
             if (lane == 0 && !(ablate & 16))                    // hint for waiting peers (see sweep_quarter)
                 granule_publish(sent + (step & 1) * (4 * G) + member * 4 + wave, step + 1, 0.0f, same_xcd);
             if (stamps) {
-                asm volatile("" ::"v"(hlast[3]));
+                asm volatile("" ::"v"(hlast.y));
                 s5 = phase_stamp();
                 if (blockIdx.x == 0 && threadIdx.x == 0 && t > 0) {   // sums live in the status area (words 8..)
                     u64* prof = reinterpret_cast<u64*>(err) + 4;
@@ -321,14 +320,12 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                 *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (L - 1)) * H + member * UNITS + 4 * q) =
                     *reinterpret_cast<const float4*>(&hst[row][4 * q]);
         }
-        if (c < 8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = b0 + kq * 4 + r;
-                if (b < B) {
-                    nets.h_n[net][(int64_t)b * H + unit] = hlast[r];
-                    nets.c_n[net][(int64_t)b * H + unit] = cst[r];
-                }
+        for (int r = 0; r < 2; ++r) {
+            const int b = b0 + kq * 4 + (c < 8 ? 0 : 2) + r;
+            if (b < B) {
+                nets.h_n[net][(int64_t)b * H + unit] = r ? hlast.y : hlast.x;
+                nets.c_n[net][(int64_t)b * H + unit] = r ? cst.y : cst.x;
             }
         }
         first_tile = false;
