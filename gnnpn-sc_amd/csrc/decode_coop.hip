@@ -133,13 +133,11 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     unsigned step = 0;   // publish counter: tag = step+1, parity = step&1
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
         const int b0 = tile * ROWS;
-        float cst[4], hl[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + kq * 4 + r;
-            cst[r] = b < B ? net.c0[(int64_t)b * H + unit] : 0.0f;
-            hl[r] = 0.0f;
-        }
+        // cell state / output of the two rows this lane finishes: rows kq*4 + {0,1} (c < 8) or kq*4 + {2,3} (c >= 8)
+        const int own0 = kq * 4 + (c < 8 ? 0 : 2);
+        f32x2 cst, hl = {0.f, 0.f};
+        cst.x = b0 + own0 < B ? net.c0[(int64_t)(b0 + own0) * H + unit] : 0.0f;
+        cst.y = b0 + own0 + 1 < B ? net.c0[(int64_t)(b0 + own0 + 1) * H + unit] : 0.0f;
         __syncthreads();   // previous tile is completely done with the LDS arrays
         for (int j = 0; j < ROWS; ++j) {
             const float h0v = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
@@ -420,35 +418,33 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                 }
             }
             u64* out_h = xh_g + (step & 1) * (ROWS * H);
+            {   // one cell update per lane for the two rows it finishes (coop_common.h: cell_update_split)
+                f32x2 g0[2], g1[2];
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {   // two rows per pass: packed fp32 arithmetic, no stores in between
-                const f32x2 g0 = (f32x2{ah0[r], ah0[r + 1]} + pk_set(bh[0])) + f32x2{gx[0][r], gx[0][r + 1]};
-                const f32x2 g1 = (f32x2{ah1[r], ah1[r + 1]} + pk_set(bh[1])) + f32x2{gx[1][r], gx[1][r + 1]};
-                f32x2 cs = {cst[r], cst[r + 1]}, hh;
-                cell_update_pair2(g0, g1, c < 8, cs, hh);
-                cst[r] = cs.x;
-                cst[r + 1] = cs.y;
-                hl[r] = hh.x;
-                hl[r + 1] = hh.y;
-            }
-            if (c < 8) {
-                u64* dst = out_h + (kq * 4) * H + unit;
-                if (same_xcd) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) granule_store_l2(dst + r * H, step + 1, hl[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) granule_store(dst + r * H, step + 1, hl[r]);
+                for (int q = 0; q < 2; ++q) {
+                    g0[q] = (f32x2{ah0[2 * q], ah0[2 * q + 1]} + pk_set(bh[0])) + f32x2{gx[0][2 * q], gx[0][2 * q + 1]};
+                    g1[q] = (f32x2{ah1[2 * q], ah1[2 * q + 1]} + pk_set(bh[1])) + f32x2{gx[1][2 * q], gx[1][2 * q + 1]};
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = kq * 4 + r;
-                    hsl[row][wave * 8 + (c & 7)] = hl[r];
-                    if (net.queries && b0 + row < B) net.queries[((int64_t)(b0 + row) * T + k) * H + unit] = hl[r];
+                cell_update_split(g0, g1, c < 8, cst, hl);
+            }
+            {
+                u64* dst = out_h + own0 * H + unit;
+                if (same_xcd) {
+                    granule_store_l2(dst, step + 1, hl.x);
+                    granule_store_l2(dst + H, step + 1, hl.y);
+                } else {
+                    granule_store(dst, step + 1, hl.x);
+                    granule_store(dst + H, step + 1, hl.y);
+                }
+                hsl[own0][wave * 8 + (c & 7)] = hl.x;
+                hsl[own0 + 1][wave * 8 + (c & 7)] = hl.y;
+                if (net.queries) {
+                    if (b0 + own0 < B) net.queries[((int64_t)(b0 + own0) * T + k) * H + unit] = hl.x;
+                    if (b0 + own0 + 1 < B) net.queries[((int64_t)(b0 + own0 + 1) * T + k) * H + unit] = hl.y;
                 }
             }
             if (stamps) {
-                asm volatile("" ::"v"(hl[3]));
+                asm volatile("" ::"v"(hl.y));
                 st[6] = phase_stamp();
             }
             __syncthreads();
