@@ -36,6 +36,7 @@ _SIGNATURES = {
     "gnnpn_lstm_encode_f32": (c_int, [c_int, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
+    "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
     "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          _P, _P, c_int64, _P]),
     "gnnpn_pointer_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),

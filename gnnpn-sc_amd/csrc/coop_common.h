@@ -36,11 +36,13 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
 // next one.  The k-th claimant of an XCD becomes member k % G of the XCD's group k / G: groups sit on one XCD by
 // construction and no CU holds two members of a launch.  Two such launches on two streams then share every CU one
 // workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
-constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD claim counters, [2048,10240) CU claims
+constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD seat counters, [1152,1184) arrivals, [2048,10240) CU claims
 constexpr int COOP_XCDCNT_OFFSET = 1024;
+constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;
 constexpr int COOP_OVERSUB = 3;              // launched workgroups per needed workgroup
-constexpr unsigned COOP_SURPLUS_WAIT_TICKS = 1600;   // 16 us of s_memrealtime (100 MHz): how long a surplus workgroup keeps its slot
+constexpr unsigned COOP_SURPLUS_WAIT_TICKS = 1600;   // 16 us of s_memrealtime (100 MHz): how long an early surplus workgroup keeps its slot
+constexpr unsigned COOP_RESERVE_WAIT_TICKS = 200000; // 2 ms: how long the reserve (the last arrivals) waits before it takes the open seats
 
 __device__ __forceinline__ unsigned xcc_id() {
     return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;   // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -86,17 +88,30 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 }
 
 // Called by every thread of the workgroup.  false: surplus workgroup (leave at once).  `slot` is two ints of LDS.
-// A surplus workgroup that lands on an already claimed CU while the launch is not fully staffed keeps its slot for up to
-// 16 us (or until staffing completes) before it exits: while it sits there the dispatcher can only place the launch's
-// remaining workgroups on CUs that still have room — the unclaimed ones, as soon as whatever fills them (a short kernel
-// of the other stream) has gone — instead of burning them one after the other on the same free slots.  The wait is
-// bounded, so two launches staffing at the same time cannot hold each other's slots for good.
+//
+// Workgroup ids go round-robin over the XCDs, so each XCD receives per_xcd = gridDim.x / 8 = COOP_OVERSUB * target
+// workgroups of the launch and needs `target` of them seated.  Every arrival takes an arrival index a (per XCD):
+//   * first workgroup of the launch on its CU, seat open  -> seated (member k % G of the XCD's group k / G);
+//   * otherwise it is surplus, and what it does with its CU slot decides whether the launch gets staffed:
+//     - the early ones (a < per_xcd - target) keep the slot for up to 16 us, or until staffing completes, and exit: while
+//       one sits there the dispatcher can only place the launch's next workgroups on CUs that still have room — the
+//       unclaimed ones, as soon as whatever fills them has gone.  The bound keeps two launches that staff at the same
+//       time from holding each other's slots.
+//     - the LAST `target` arrivals of the XCD are the reserve and are not burned: they keep their slots until staffing
+//       completes (at most one of them fits on each claimed CU, so the ones not yet dispatched stay in the dispatcher's
+//       queue — at least as many as there are open seats — and go to the unclaimed CUs when those free up), and after
+//       COOP_RESERVE_WAIT_TICKS (2 ms) they take the open seats themselves, on whatever CU they are: a group with two
+//       members on one CU is slower, not wrong.
+//   Measured need for the reserve: an ordinary kernel of the other stream whose workgroups fill a CU for longer than
+//   ~50 us (the front end at 5000 candidates x 512 problems) outlasted 64 surplus workgroups of 16 us each, the launch
+//   stayed one or two members short on some XCDs and its groups timed out (tools/repro_synth4.sh, record in DESIGN.md).
 template <int G>
 __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned xcc = xcc_id();
         unsigned* count = status + COOP_XCDCNT_OFFSET / 4;
+        unsigned* arrive = status + COOP_ARRIVE_OFFSET / 4;
         const unsigned target = (unsigned)(gpx * G);
         auto staffed = [&]() {
             bool ok = true;
@@ -105,10 +120,11 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         };
         int g = -1, m = 0;
         if (!staffed()) {
-            unsigned prev = 0;
+            unsigned arrival = 0;
             if (lane == 0) {
+                arrival = atomicAdd(arrive + xcc, 1u);
                 const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-                prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + ((xcc << 8) | ((hw >> 8) & 0xffu)), 1u);
+                const unsigned prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + ((xcc << 8) | ((hw >> 8) & 0xffu)), 1u);
                 if (prev == 0u) {                                // the first workgroup of this launch on this CU
                     const unsigned k = atomicAdd(count + xcc, 1u);
                     if (k < target) {
@@ -119,10 +135,29 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
             }
             g = __shfl(g, 0, 64);
             m = __shfl(m, 0, 64);
-            if (g < 0) {                                         // surplus: hold the slot briefly (see above)
+            arrival = __shfl(arrival, 0, 64);
+            if (g < 0) {                                         // surplus (see above)
+                const unsigned per_xcd = gridDim.x / 8;
+                const bool reserve = arrival + target >= per_xcd;
+                const unsigned long long patience = reserve ? COOP_RESERVE_WAIT_TICKS : COOP_SURPLUS_WAIT_TICKS;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (!staffed() && __builtin_amdgcn_s_memrealtime() - t0 < COOP_SURPLUS_WAIT_TICKS)
+                bool done = staffed();
+                while (!done && __builtin_amdgcn_s_memrealtime() - t0 < patience) {
                     __builtin_amdgcn_s_sleep(8);
+                    done = staffed();
+                }
+                if (!done && reserve) {
+                    if (lane == 0 && __hip_atomic_load(count + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        const unsigned k = atomicAdd(count + xcc, 1u);
+                        if (k < target) {
+                            g = (int)xcc * gpx + (int)(k / G);
+                            m = (int)(k % G);
+                            atomicAdd(status + 2, 1u);           // statistics: seats taken on an already claimed CU
+                        }
+                    }
+                    g = __shfl(g, 0, 64);
+                    m = __shfl(m, 0, 64);
+                }
             }
         }
         if (lane == 0) {

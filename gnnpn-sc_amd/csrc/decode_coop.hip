@@ -39,6 +39,27 @@ constexpr int KMAX = 16;          // candidates per category the cooperative for
 constexpr unsigned SPIN_LIMIT = 400000;
 }  // namespace
 
+// ---- failure record (diagnosis of a timed-out sweep; written only on the failure path, read by gnnpn_decode_diag) ----
+// [0] failures so far (all launches) | per failing wave, first 31 of them, 16 words: group, member, tile, k, wave, tag,
+// mask of members whose h granules are missing, mask of members whose partial dots are missing, missing latent lanes,
+// the 8 per-XCD claim counters of the launch packed as bytes (2 words), realtime lo/hi, gpx, blockIdx.x
+__device__ unsigned g_dec_diag[512];
+__device__ __forceinline__ void decode_diag_record(int group, int member, int tile, const unsigned* err, int gpx) {
+    const unsigned n = atomicAdd(g_dec_diag, 1u);
+    if (n < 31) {
+        unsigned* r = g_dec_diag + 16 * (n + 1);
+        const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
+        unsigned c0 = 0, c1 = 0;
+        for (int x = 0; x < 4; ++x) {
+            c0 |= (cnt[x] & 0xffu) << (8 * x);
+            c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
+        }
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        r[0] = group; r[1] = member; r[2] = tile; r[9] = c0; r[10] = c1; r[11] = (unsigned)t; r[12] = (unsigned)(t >> 32);
+        r[13] = gpx; r[14] = blockIdx.x; r[15] = err[0];
+    }
+}
+
 // max / sum over each row of 16 lanes by DPP rotations (every lane ends with the row's result)
 __device__ __forceinline__ int ror16(int v, int n) {
     switch (n) {
@@ -482,7 +503,10 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
             }
             ++step;
         }
-        if (abort_flag) break;
+        if (abort_flag) {
+            if (tid == 0) decode_diag_record(group, member, tile, err, gpx);
+            break;
+        }
     }
     if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
 }
@@ -493,6 +517,18 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
                        tiles * T * ROWS * (int64_t)n_per * 8;
     const int64_t a16 = gnnpn_decode_coop2_workspace_bytes(B, T, n_per);
     return a8 > a16 ? a8 : a16;
+}
+
+extern "C" int gnnpn_decode_diag(uint32_t* out, int32_t n_words, int32_t clear) {
+    if (!out || n_words < 0 || n_words > 512) GNNPN_FAIL(GNNPN_E_ARG, "decode_diag: up to 512 words");
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_diag), (size_t)n_words * 4) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "decode_diag: copy failed");
+    if (clear) {
+        static const unsigned zeros[512] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_diag), zeros, sizeof(zeros)) != hipSuccess)
+            GNNPN_FAIL(GNNPN_E_LAUNCH, "decode_diag: clear failed");
+    }
+    return GNNPN_OK;
 }
 
 bool gnnpn_decode_coop_supported(int32_t H_, int32_t n_per) { return H_ == H && n_per <= KMAX; }

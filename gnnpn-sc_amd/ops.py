@@ -234,9 +234,24 @@ class Workspaces:
         if word != 0:
             self.status.zero_()
             last = [int(b[:4].view(torch.int32).item()) if b is not None else None for b in (self._encode, self._decode)]
+            detail = ""
+            if word & 2:
+                rec = decode_failure_record()
+                detail = f"; decoder failure record: {rec['failures']} sweeps, first: {rec['records'][:4]}"
             raise GnnpnError(f"{what}: status {word:#x} — an inter-workgroup hand-off timed out in at least one launch "
                              f"since the last check (its outputs are invalid); bits: 1 encoder sweep, 2 decoder sweep, 4 a "
-                             f"group member never showed up; last launches' own words (encoder, decoder) = {last}")
+                             f"group member never showed up; last launches' own words (encoder, decoder) = {last}{detail}")
+
+
+def decode_failure_record(clear=True):
+    """gnnpn_decode_diag as a list of dicts (one per timed-out decoder sweep, the first 31) — diagnosis only."""
+    import ctypes
+    buf = (ctypes.c_uint32 * 512)()
+    _lib.check(_lib.load().gnnpn_decode_diag(ctypes.cast(buf, ctypes.c_void_p), 512, 1 if clear else 0), "gnnpn_decode_diag")
+    names = ("group", "member", "tile", "k", "wave", "tag", "h_missing_members", "p_missing_members", "latent_missing",
+             "claims_xcd0_3", "claims_xcd4_7", "t_lo", "t_hi", "gpx", "workgroup", "launch_status")
+    n = int(buf[0])
+    return {"failures": n, "records": [dict(zip(names, [int(v) for v in buf[16 * (i + 1):16 * (i + 2)]])) for i in range(min(n, 31))]}
 
 
 _default_ws = {}

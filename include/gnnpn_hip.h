@@ -244,6 +244,14 @@ int64_t gnnpn_lstm_encode_workspace_bytes(void);
  * Unknown names / out-of-range values: GNNPN_E_ARG. */
 int gnnpn_set_option(const char* name, int value);
 
+/* Failure record of the cooperative decoder (diagnosis only; host call, synchronises the device): copies the first
+ * n_words (<= 512) uint32 of the record to the HOST buffer `out`, optionally clearing it.  out[0] = timed-out sweeps
+ * since the last clear; then 16 words per failing wave (the first 31): group, member, tile, step k, wave, expected tag,
+ * mask of members whose h granules were missing, mask of members whose partial dots were missing, missing latent
+ * lanes, the launch's eight per-XCD claim counters (one byte each, two words), device realtime (lo, hi), groups per
+ * XCD, workgroup id, the launch's status word. */
+int gnnpn_decode_diag(uint32_t* out, int32_t n_words, int32_t clear);
+
 /* Greedy pointer decode of up to two pointer networks in one call: T steps of {decoder LSTM cell;
  * dot-attention logits over the step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent
  * window (High net); softmax; first-max argmax; next input = embedded row of the pick}.

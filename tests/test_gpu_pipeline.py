@@ -392,6 +392,30 @@ def test_two_slots_whichever_starts_first(dev):
             assert placed == 256, placed                         # 32 groups x 8 members, one per CU
 
 
+def test_two_slots_beside_long_ordinary_kernels(dev):
+    """The staffing reserve of coop_place (csrc/coop_common.h).  At 1000 tasks x 5000 candidates x 512 problems the other
+    slot's front-end kernels fill whole CUs for longer than the early surplus workgroups of a cooperative launch last; before
+    the reserve existed about half of the bench runs at this size ended with decoder groups one or two members short
+    (tools/repro_synth4.sh).  24 pipelined steps: no failed hand-off, results equal to the single-stream run."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 1000, 5000, 5, 512
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=4, tasks_per_problem=T), dev)
+    runner = PipelinedRunner(pipe, svc, batch, slots=2)
+    ref = pipe.run(svc, batch, decode_impl=runner.decode_impl)
+    for _ in range(24):
+        runner.submit()
+    runner.synchronize(check=True)
+    for s in range(2):
+        o = runner.graphs[s].outputs
+        assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
+
+
 @pytest.mark.parametrize("precision", ["f32", "split"])
 def test_soak_two_slots(dev, precision):
     """2,000 pipelined steps, a different batch every step, eager work on the default stream in between (what recycled the
