@@ -40,6 +40,7 @@ _SIGNATURES = {
     "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          _P, _P, c_int64, _P]),
     "gnnpn_pointer_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "gnnpn_pointer_decode_attn_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, _P]),
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
@@ -64,6 +65,13 @@ class DecodeNet(ctypes.Structure):
                                   "bhh", "latent_win", "emb_w", "emb_b", "xw_fold", "xb_fold", "start_fold", "idx", "win_logits", "pick_prob", "actions",
                                   "queries")] + \
                [("latent_from", c_int32), ("sample", c_int32), ("sample_seed", ctypes.c_uint64)]
+
+
+class Attention(ctypes.Structure):
+    """gnnpn_attention_t of include/gnnpn_hip.h."""
+    _fields_ = [("attention", c_int32), ("n_glimpses", c_int32)] + \
+               [(n, _P) for n in ("pointer_wq", "pointer_bq", "pointer_ref", "pointer_v", "glimpse_wq", "glimpse_bq",
+                                  "glimpse_ref", "glimpse_v")]
 
 
 class LaunchOpts(ctypes.Structure):

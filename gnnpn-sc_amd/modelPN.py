@@ -10,7 +10,10 @@ Scope of this build = the configuration the reference ships
 (/root/reference/environment.ini:49-79, src/models/trainPNHigh.py:208-236):
 ``embedding_size=0``, ``n_glimpses=0``, ``attention='Dot'``; ``sample='greedy'`` (the inference path) and the forward of
 the sampling mode (``sample='sample'``: every pick drawn from the window softmax, modelPN.py:227-228 — SURVEY.md §8f
-row 3, forward only).  Anything else raises ``NotImplementedError`` (the REINFORCE backward is the next row).
+row 3; its REINFORCE step is trainPNHigh.py here).  The attention forms those configurations leave switched off —
+``attention='Bahdanau'`` (modelPN.py:80-90,103-109) and ``n_glimpses > 0`` (:208-211), SURVEY.md §8f row 4 — decode through
+the general kernel (gnnpn_pointer_decode_attn_f32: greedy, one net per call).  ``embedding_size != 0`` raises
+``NotImplementedError``.
 """
 import math
 
@@ -54,6 +57,9 @@ class LatentWindows:
             return [self[i] for i in range(*k.indices(len(self)))]
         if k < 0:
             k += len(self)
+        if self._queries is None:
+            raise NotImplementedError("full-length logits of the 'Bahdanau' / glimpse forms are not materialised; the "
+                                      "window logits (.win) are all the High level reads (modelPN.py:216,220-222)")
         return torch.ops.gnnpn.attention_logits(self._enc_out, self._queries, k, self.idx, self._tanh_c, self._use_tanh)
 
     def __iter__(self):
@@ -74,6 +80,28 @@ def _window_tensor(latent, n_cat, n_per):
     return torch.stack([latent[k][:, k * n_per:(k + 1) * n_per] for k in range(n_cat)], 1).contiguous()
 
 
+class Attention(nn.Module):
+    """Parameter container of Attention (modelPN.py:75-90): same names and shapes (``W_query`` Linear, ``W_ref`` 1x1
+    Conv1d, ``V``); 'Dot' has no parameters.  The arithmetic (:92-122) runs in gnnpn_pointer_decode_attn_f32."""
+
+    def __init__(self, hidden_size, use_tanh=False, C=10, name="Bahdanau", use_cuda=True):
+        super().__init__()
+        if name not in ops.ATTENTION_NAMES:
+            raise NotImplementedError(name)                                            # :116-117
+        self.use_tanh, self.C, self.name = use_tanh, C, name
+        if name == "Bahdanau":
+            self.W_query = nn.Linear(hidden_size, hidden_size)                         # :83
+            self.W_ref = nn.Conv1d(hidden_size, hidden_size, 1, 1)                     # :84
+            self.V = nn.Parameter(torch.FloatTensor(hidden_size))                      # :86-90
+            self.V.data.uniform_(-(1. / math.sqrt(hidden_size)), 1. / math.sqrt(hidden_size))
+
+    def side(self):
+        if self.name != "Bahdanau":
+            return None
+        return {"wq": self.W_query.weight, "bq": self.W_query.bias, "wref": self.W_ref.weight, "bref": self.W_ref.bias,
+                "v": self.V}
+
+
 class PointerNet(nn.Module):
     """Parameter container + kernel driver for PointerNet (modelPN.py:126-241)."""
 
@@ -83,18 +111,20 @@ class PointerNet(nn.Module):
         if embedding_size != 0:
             raise NotImplementedError("embedding_size != 0 (embeddingTag=1) is outside the ML+2PN inference "
                                       "configuration (environment.ini:50,66)")
-        if n_glimpses != 0:
-            raise NotImplementedError("n_glimpses != 0 is outside the shipped configuration (environment.ini:56)")
-        if attention != "Dot":
-            raise NotImplementedError(f"attention {attention!r}: only 'Dot' is used on the path "
-                                      "(trainPNHigh.py:216,233)")
+        if n_glimpses < 0:
+            raise ValueError("n_glimpses >= 0")
         self.embedding_size, self.hidden_size, self.n_glimpses = embedding_size, hidden_size, n_glimpses
+        self.attention = attention
+        # general = outside the shipped configuration ('Dot', no glimpses): decoded by gnnpn_pointer_decode_attn_f32
+        self.general = attention != "Dot" or n_glimpses != 0
         self.seq_len, self.use_cuda, self.level = seq_len, use_cuda, level
         self.serNumber, self.serCategory = sNumber, sCategory
         self.C, self.use_tanh, self.mask = float(tanh_exploration), bool(use_tanh), mask
         self.embedding2 = nn.Linear(embedding_size + qosandcons, hidden_size)          # :155
         self.encoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :157 (container)
         self.decoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :158 (container)
+        self.pointer = Attention(hidden_size, use_tanh=use_tanh, C=tanh_exploration, name=attention, use_cuda=use_cuda)   # :159
+        self.glimpse = Attention(hidden_size, use_tanh=False, name=attention, use_cuda=use_cuda)                           # :160
         self.decoder_start_input = nn.Parameter(torch.FloatTensor(hidden_size))        # :162-163
         self.decoder_start_input.data.uniform_(-(1. / math.sqrt(hidden_size)), 1. / math.sqrt(hidden_size))
         self._packed = None
@@ -187,6 +217,16 @@ class PointerNet(nn.Module):
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
         enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
+        if self.general:
+            if sample_seed is not None:
+                raise NotImplementedError("sampling with 'Bahdanau' attention / glimpses: the general decode kernel is greedy")
+            out = ops.pointer_decode_attn(
+                self.decode_args(embedded, enc[0], h_n[0], c_n[0], _window_tensor(latent, self.serCategory, self.serNumber),
+                                 fold=False),
+                inputs, self.serCategory, self.serNumber, self.attention, self.n_glimpses, self.pointer.side(),
+                self.glimpse.side(), self.C, self.use_tanh, want_queries)
+            out["enc_out"] = enc[0]
+            return out
         out = custom_ops.pointer_decode(
             [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
                               _window_tensor(latent, self.serCategory, self.serNumber), fold=fold, sample_seed=sample_seed)],
@@ -199,7 +239,8 @@ class PointerNet(nn.Module):
         are lazily materialised full-length views (see LatentWindows)."""
         out = self.run(inputs, latent, want_queries=True,
                        sample_seed=None if sample == "greedy" else self.next_sample_seed())      # :225-228
-        lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.C, self.use_tanh)
+        lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], None if self.general else out["queries"],
+                            self.C, self.use_tanh)
         idxs = [out["idx"][:, k].long() for k in range(self.serCategory)]
         return _ProbList(out, latent, self.serCategory, self.serNumber), idxs, lat
 
@@ -301,6 +342,14 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
+    if la.general or ha.general:   # 'Bahdanau' attention / glimpses: one net per call of the general kernel
+        if sample_high_seed is not None or precision != "f32":
+            raise NotImplementedError("the general attention forms decode greedily in fp32")
+        dl = la.run(inputs, None, fold=fold)
+        dh = ha.run(inputs, LatentWindows(dl["win_logits"], dl["idx"], None, None, la.C, la.use_tanh), fold=fold)
+        R = torch.ops.gnnpn.qos_reward(dh["actions"], 0 if high.level == "Low" else 1)
+        return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
+                "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}
     # the two decoders run in ONE launch with one (C, use_tanh, window shape): the reference applies each PointerNet's
     # own (modelPN.py:119-122), so nets that differ there cannot take this fused path
     for name in ("C", "use_tanh", "serNumber", "serCategory", "hidden_size", "seq_len"):

@@ -430,6 +430,67 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
     return outs
 
 
+ATTENTION_NAMES = {"Dot": 0, "Bahdanau": 1}
+
+
+def pointer_decode_attn(net, inputs, n_cat, n_per, attention="Dot", n_glimpses=0, pointer=None, glimpse=None, tanh_c=10.0,
+                        use_tanh=True, want_queries=False):
+    """Greedy decode of ONE pointer network with 'Bahdanau' attention and / or glimpse rounds (gnnpn_pointer_decode_attn_f32;
+    modelPN.py:80-122,204-239 — the forms the reference's configurations leave switched off).
+    net: as one entry of pointer_decode's ``nets`` (embedded or emb_w/emb_b, enc_out, h0, c0, start, wih, whh, bih, bhh,
+    latent_win).  pointer / glimpse ('Bahdanau' only): dicts with wq [H,H], bq [H], wref [H,H] or [H,H,1], bref [H], v [H];
+    W_ref(enc_out) is formed here with gnnpn_linear_f32."""
+    if attention not in ATTENTION_NAMES:
+        raise NotImplementedError(attention)                            # modelPN.py:116-117
+    B, L, H = net["enc_out"].shape
+    if L != n_cat * n_per:
+        raise GnnpnError(f"pointer_decode_attn: seq_len {L} != {n_cat}*{n_per}")
+    dev = net["enc_out"].device
+    keep = []
+    emb = net.get("embedded")
+    if emb is None:
+        emb = linear(inputs.reshape(B * L, inputs.shape[2]), net["emb_w"], net["emb_b"]).view(B, L, H)
+    out = {"idx": torch.empty((B, n_cat), dtype=I32, device=dev),
+           "win_logits": torch.empty((B, n_cat, n_per), dtype=F32, device=dev),
+           "pick_prob": torch.empty((B, n_cat), dtype=F32, device=dev),
+           "actions": torch.empty((B, n_cat, 8), dtype=F32, device=dev),
+           "queries": torch.empty((B, n_cat, H), dtype=F32, device=dev) if want_queries else None}
+    a = _lib.DecodeNet()
+    for name, key in (("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"), ("start", "start"), ("wih_packed", "wih"),
+                      ("whh_packed", "whh"), ("bih", "bih"), ("bhh", "bhh")):
+        setattr(a, name, dev_ptr(net[key], F32, f"net.{key}").value)
+    a.embedded = dev_ptr(emb, F32, "net.embedded").value
+    lw = net.get("latent_win")
+    a.latent_win = None if lw is None else dev_ptr(lw, F32, "net.latent_win").value
+    a.latent_from = -1
+    a.idx = dev_ptr(out["idx"], I32, "idx").value
+    a.win_logits = dev_ptr(out["win_logits"], F32, "win").value
+    a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value
+    a.actions = dev_ptr(out["actions"], F32, "actions").value
+    a.queries = None if out["queries"] is None else dev_ptr(out["queries"], F32, "queries").value
+    at = _lib.Attention()
+    at.attention, at.n_glimpses = ATTENTION_NAMES[attention], int(n_glimpses)
+    if attention == "Bahdanau":
+        sides = [("pointer", pointer)] + ([("glimpse", glimpse)] if n_glimpses > 0 else [])
+        for side, d in sides:
+            if d is None:
+                raise GnnpnError(f"pointer_decode_attn: 'Bahdanau' needs the {side} module's parameters")
+            wq = d["wq"].detach().float().contiguous()
+            ref = linear(net["enc_out"].reshape(B * L, H), d["wref"].detach().float().reshape(H, H).contiguous(),
+                         d["bref"].detach().float().contiguous()).view(B, L, H)
+            bq, v = d["bq"].detach().float().contiguous(), d["v"].detach().float().contiguous()
+            keep += [wq, ref, bq, v]
+            setattr(at, f"{side}_wq", dev_ptr(wq, F32, f"{side}.wq").value)
+            setattr(at, f"{side}_bq", dev_ptr(bq, F32, f"{side}.bq").value)
+            setattr(at, f"{side}_ref", dev_ptr(ref, F32, f"{side}.ref").value)
+            setattr(at, f"{side}_v", dev_ptr(v, F32, f"{side}.v").value)
+    check(_lib.load().gnnpn_pointer_decode_attn_f32(_lib.ctypes.byref(a), _lib.ctypes.byref(at), dev_ptr(inputs, F32, "inputs"),
+                                                     float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H, stream_ptr()),
+          "gnnpn_pointer_decode_attn_f32")
+    out["_keep"] = keep + [emb]
+    return out
+
+
 def attention_logits(enc_out, queries, step, idx, tanh_c=10.0, use_tanh=True):
     """Full [B,L] logits of decode step ``step`` with -inf at the ``step`` previously chosen
     positions (API-compat path, see gnnpn_attention_logits_f32)."""

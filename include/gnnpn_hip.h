@@ -318,6 +318,34 @@ int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const f
                              int32_t precision, const gnnpn_launch_opts_t* opts, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* The attention forms the reference's configurations leave switched off:
+ * replaces PointerNet.forward's per-step body (modelPN.py:204-239) with attention 'Bahdanau' (:80-90,103-109) and / or
+ * n_glimpses > 0 (:208-211).  One net per call (chain Low -> High through latent_win), greedy only.
+ *   attention    0 'Dot' | 1 'Bahdanau'
+ *   n_glimpses   glimpse rounds per step (each: logits over all L positions, -inf at the positions chosen so far,
+ *                softmax, query = ref' . softmax)
+ *   *_wq [H,H], *_bq [H]   W_query of the pointer / glimpse Attention module          ('Bahdanau' only)
+ *   *_ref [B,L,H]          W_ref (the 1x1 Conv1d) applied to enc_out, bias included — step-independent, computed by the
+ *                          caller with gnnpn_linear_f32                                  ('Bahdanau' only)
+ *   *_v [H]                V
+ * Uses of gnnpn_decode_net_t: embedded (required), enc_out, h0, c0, start, wih_packed, whh_packed, bih, bhh, latent_win
+ * (optional), idx, win_logits, pick_prob, actions, queries (optional).  H = 256 or 32; L*4 + T*4 bytes of LDS <= 120 KB. */
+typedef struct {
+    int32_t attention;
+    int32_t n_glimpses;
+    const float* pointer_wq;
+    const float* pointer_bq;
+    const float* pointer_ref;
+    const float* pointer_v;
+    const float* glimpse_wq;
+    const float* glimpse_bq;
+    const float* glimpse_ref;
+    const float* glimpse_v;
+} gnnpn_attention_t;
+
+int gnnpn_pointer_decode_attn_f32(const gnnpn_decode_net_t* net, const gnnpn_attention_t* attn, const float* inputs,
+                                  float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H, void* stream);
+
 /* Workspace the cooperative decoder needs for this shape (status words, hand-off buffers, the
  * Low->High latent granules).  Word 0 after synchronisation: as for the encoder. */
 int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per);

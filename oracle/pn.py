@@ -23,7 +23,7 @@ CONS_NUM = 2   # modelPN.py:12
 NEG_INF = float("-inf")
 
 
-def make_state_dict(hidden, seed, in_features=8):
+def make_state_dict(hidden, seed, in_features=8, attention="Dot"):
     """Deterministic weights in the reference's state_dict layout (PyTorch default-init
     ranges: U(-1/sqrt(H), 1/sqrt(H)) for LSTM and decoder_start_input, modelPN.py:163;
     U(-1/sqrt(in), 1/sqrt(in)) for the Linear).  Build-owned generator so that fixtures
@@ -45,6 +45,13 @@ def make_state_dict(hidden, seed, in_features=8):
         sd[f"actor.{name}.weight_hh_l0"] = u((4 * hidden, hidden), kh)
         sd[f"actor.{name}.bias_ih_l0"] = u((4 * hidden,), kh)
         sd[f"actor.{name}.bias_hh_l0"] = u((4 * hidden,), kh)
+    if attention == "Bahdanau":            # Attention.__init__ (modelPN.py:82-90); drawn after everything else
+        for name in ("pointer", "glimpse"):
+            sd[f"actor.{name}.W_query.weight"] = u((hidden, hidden), kh)
+            sd[f"actor.{name}.W_query.bias"] = u((hidden,), kh)
+            sd[f"actor.{name}.W_ref.weight"] = u((hidden, hidden, 1), kh)
+            sd[f"actor.{name}.W_ref.bias"] = u((hidden,), kh)
+            sd[f"actor.{name}.V"] = u((hidden,), kh)
     return sd
 
 
@@ -112,9 +119,31 @@ def multinomial_from_stream(probs, k, n_cat, n_per, seed):
 
 
 @torch.no_grad()
-def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True, sample_seed=None, draw_margins=None):
-    """PointerNet.forward, 'Dot' attention, n_glimpses=0 (modelPN.py:175-241); greedy, or with ``sample_seed`` the sampling
-    mode (:227-228) with the draws taken from the counter-based stream (multinomial_from_stream).
+def attention_forward(sd, which, name, query, ref, use_tanh, C):
+    """Attention.forward (modelPN.py:92-122) of ``actor.<which>`` ('pointer' | 'glimpse'): -> (ref' [B,H,L], logits [B,L]).
+    ref' is what the glimpse loop multiplies the softmax with (:209): W_ref(ref) for 'Bahdanau', ref itself for 'Dot'."""
+    if name == "Bahdanau":
+        refp = ref.permute(0, 2, 1)                                                          # :104
+        q = F.linear(query, sd[f"actor.{which}.W_query.weight"], sd[f"actor.{which}.W_query.bias"]).unsqueeze(2)   # :105
+        refp = F.conv1d(refp, sd[f"actor.{which}.W_ref.weight"], sd[f"actor.{which}.W_ref.bias"])                   # :106
+        expanded = q.repeat(1, 1, refp.shape[2])                                             # :107
+        V = sd[f"actor.{which}.V"].unsqueeze(0).unsqueeze(0).repeat(ref.shape[0], 1, 1)      # :108
+        logits = torch.bmm(V, torch.tanh(expanded + refp)).squeeze(1)                        # :109
+    elif name == "Dot":
+        logits = torch.bmm(ref, query.unsqueeze(2)).squeeze(2)                               # :112-113
+        refp = ref.permute(0, 2, 1)                                                          # :114
+    else:
+        raise NotImplementedError(name)                                                      # :116-117
+    if use_tanh:
+        logits = C * torch.tanh(logits)                                                      # :119-120
+    return refp, logits
+
+
+def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True, sample_seed=None, draw_margins=None,
+                    attention="Dot", n_glimpses=0):
+    """PointerNet.forward (modelPN.py:175-241); greedy, or with ``sample_seed`` the sampling mode (:227-228) with the draws
+    taken from the counter-based stream (multinomial_from_stream).  ``attention`` 'Dot' | 'Bahdanau' (:80-90, 103-114),
+    ``n_glimpses`` glimpse rounds per step (:208-211; the reference's configs run 'Dot' with 0).
 
     inputs  [B, L, 8] fp32 with L = n_cat * n_per (assert at modelPN.py:182)
     latent  None (Low net) or list of n_cat [B, L] tensors = the Low net's returned logits
@@ -139,12 +168,14 @@ def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True
     for k in range(n_cat):                                                                  # :204
         _, (h, c) = dec(x.unsqueeze(1), (h, c))                                             # :205
         query = h.squeeze(0)                                                                # :207
-        logits = torch.bmm(enc_out, query.unsqueeze(2)).squeeze(2)                          # :112-113
-        if use_tanh:
-            logits = C * torch.tanh(logits)                                                 # :119-120
-        if idx is not None:                                                                 # :169-172
+        if idx is not None:                                                                 # :169-172 (the mask of this step)
             chosen[rows, idx] = True
-            logits[chosen] = NEG_INF
+        for _ in range(n_glimpses):                                                         # :208-211
+            refp, glogits = attention_forward(sd, "glimpse", attention, query, enc_out, False, C)
+            glogits[chosen] = NEG_INF
+            query = torch.bmm(refp, F.softmax(glogits, dim=1).unsqueeze(2)).squeeze(2)
+        _, logits = attention_forward(sd, "pointer", attention, query, enc_out, use_tanh, C)   # :213
+        logits[chosen] = NEG_INF                                                            # :214
         biased = logits + latent[k] if latent else logits.clone()                           # :215-218
         biased[:, : k * n_per] = NEG_INF                                                    # :220-222
         biased[:, (k + 1) * n_per:] = NEG_INF
@@ -198,10 +229,11 @@ def reward(actions, level="High", tag=0):
 
 @torch.no_grad()
 def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", training="RL",
-                          C=10.0, use_tanh=True, sample_seed=None, draw_margins=None):
+                          C=10.0, use_tanh=True, sample_seed=None, draw_margins=None, attention="Dot", n_glimpses=0):
     """CombinatorialRL.forward (modelPN.py:282-306), sample='greedy' (or sampled from the stream of ``sample_seed``)."""
     B = inputs.shape[0]
-    probs, idxs, logits = pointer_forward(sd, inputs, n_cat, n_per, latent, C, use_tanh, sample_seed, draw_margins)
+    probs, idxs, logits = pointer_forward(sd, inputs, n_cat, n_per, latent, C, use_tanh, sample_seed, draw_margins,
+                                          attention, n_glimpses)
     rows = torch.arange(B)
     actions = [inputs[rows, i, :] for i in idxs]                                            # :293-295
     action_probs = [p[rows, i] for p, i in zip(probs, idxs)]                                # :297-299
@@ -212,7 +244,8 @@ def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", tr
 
 
 @torch.no_grad()
-def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=True, sample_high_seed=None):
+def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=True, sample_high_seed=None,
+                     attention="Dot", n_glimpses=0):
     """The eval block of trainPNHigh.py:138-139: Low greedy ("SL") -> latent -> High greedy ("RL").
 
     Returns dict with idx_low/idx_high [B,T] int64, R [B] fp32, actions [B,T,8], action_probs [B,T],
@@ -221,10 +254,10 @@ def two_level_greedy(sd_low, sd_high, inputs, n_cat, n_per, C=10.0, use_tanh=Tru
     """
     B, L, _ = inputs.shape
     _, _, _, idx_low, latent = combinatorial_forward(sd_low, inputs, n_cat, n_per, None, "Low", "SL",
-                                                     C, use_tanh)
+                                                     C, use_tanh, attention=attention, n_glimpses=n_glimpses)
     draws = [] if sample_high_seed is not None else None      # trainPNHigh.py:83-84: Low greedy -> latent, High sampled
     R, aprob, actions, idx_high, logits_high = combinatorial_forward(
-        sd_high, inputs, n_cat, n_per, latent, "High", "RL", C, use_tanh, sample_high_seed, draws)
+        sd_high, inputs, n_cat, n_per, latent, "High", "RL", C, use_tanh, sample_high_seed, draws, attention, n_glimpses)
     win_low = torch.stack([latent[k][:, k * n_per:(k + 1) * n_per] for k in range(n_cat)], 1)
     win_high = torch.stack([(logits_high[k] + latent[k])[:, k * n_per:(k + 1) * n_per]
                             for k in range(n_cat)], 1)

@@ -104,6 +104,40 @@ def gen_pn(modelPN, name, H, T, K, B, seed, dummy_every=0, weight_scale=1.0):
           f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
 
 
+def gen_pn_attn(modelPN, name, H, T, K, B, seed, attention, n_glimpses):
+    """the attention forms the reference's configs leave switched off — 'Bahdanau' attention
+    (modelPN.py:80-90,103-109) and glimpse rounds (:208-211) — run through the REAL modules, Low ("SL") -> latent -> High."""
+    sd_low = opn.make_state_dict(H, seed, attention=attention)
+    sd_high = opn.make_state_dict(H, seed + 1, attention=attention)
+    L = T * K
+
+    def build(level, sd):
+        m = modelPN.CombinatorialRL(0, H, L, n_glimpses, 10, 1, modelPN.reward, attention, K, T, use_cuda=False, level=level)
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+
+    low, high = build("Low", sd_low), build("High", sd_high)
+    x = pn_inputs(B, T, K, seed + 2, 0)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        _, _, _, idx_low, latent = low(x, None, sample="greedy", training="SL")
+        R, probs, actions, idx_high, logits_high = high(x, None, latent, sample="greedy")
+    ref = {
+        "idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
+        "actions": torch.stack(actions, 1), "action_probs": torch.stack(probs, 1),
+        "win_low": torch.stack([latent[k][:, k * K:(k + 1) * K] for k in range(T)], 1),
+        "win_high": torch.stack([(logits_high[k] + latent[k])[:, k * K:(k + 1) * K] for k in range(T)], 1),
+    }
+    orc = opn.two_level_greedy(sd_low, sd_high, x, T, K, attention=attention, n_glimpses=n_glimpses)
+    for key in ("idx_low", "idx_high", "R", "actions", "action_probs", "win_low", "win_high"):
+        assert torch.equal(ref[key], orc[key]), f"oracle != reference on {key} ({name})"
+    out = {k: v.numpy() for k, v in ref.items()}
+    out.update(inputs=x.numpy(), hidden=H, n_cat=T, n_per=K, seed_low=seed, seed_high=seed + 1, attention=attention,
+               n_glimpses=n_glimpses, margin_low=orc["margin_low"].numpy(), margin_high=orc["margin_high"].numpy())
+    np.savez_compressed(os.path.join(HERE, f"pn_attn_{name}.npz"), **out)
+    print(f"pn_attn_{name}: {attention} glimpses={n_glimpses} B={B} T={T} K={K} H={H}; min margin low/high = "
+          f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
+
+
 def gen_pn_sample(modelPN, name, H, T, K, B, seed, sample_seed):
     """The sampling mode (modelPN.py:227-228) of the REAL reference — Low greedy -> latent, High with sample='sample', the
     forward of a PNHigh training step (trainPNHigh.py:83-84) — with ``Tensor.multinomial`` routed to the counter-based
@@ -441,6 +475,11 @@ def main():
     gen_pn_sample(modelPN, "qws", H=256, T=47, K=5, B=64, seed=95, sample_seed=987654321)
     gen_pn_train(modelPN, "small", H=32, T=6, K=3, B=8, seed=101, sample_seed=4242, full=True)
     gen_pn_train(modelPN, "qws", H=256, T=47, K=5, B=32, seed=105, sample_seed=777, full=False)
+    gen_pn_attn(modelPN, "dot_g1_small", H=32, T=6, K=3, B=6, seed=111, attention="Dot", n_glimpses=1)
+    gen_pn_attn(modelPN, "bahdanau_g0_small", H=32, T=6, K=3, B=6, seed=113, attention="Bahdanau", n_glimpses=0)
+    gen_pn_attn(modelPN, "bahdanau_g2_small", H=32, T=6, K=3, B=6, seed=115, attention="Bahdanau", n_glimpses=2)
+    gen_pn_attn(modelPN, "dot_g1_qws", H=256, T=47, K=5, B=16, seed=117, attention="Dot", n_glimpses=1)
+    gen_pn_attn(modelPN, "bahdanau_g1_qws", H=256, T=47, K=5, B=16, seed=119, attention="Bahdanau", n_glimpses=1)
     gen_reward(modelPN)
     gen_data(loadData_mod, ML2PN_mod)
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)

@@ -6,7 +6,7 @@ import torch
 
 from conftest import golden
 from oracle import pn as opn
-from parity import LOGIT_ATOL, R_ATOL, assert_index_parity, robust_problems
+from parity import LOGIT_ATOL, R_ATOL, assert_index_parity, assert_R_parity, prefix_parity, robust_problems
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,58 @@ def test_two_level_greedy_golden(dev, name, precision):
     assert np.abs(out["R"].cpu().numpy()[s] - fx["R"][s]).max() <= R_ATOL
     assert np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
     assert np.abs(out["action_probs"].cpu().numpy()[s] - fx["action_probs"][s]).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["dot_g1_small", "bahdanau_g0_small", "bahdanau_g2_small", "dot_g1_qws", "bahdanau_g1_qws"])
+def test_attention_forms_golden(dev, name):
+    """'Bahdanau' attention and glimpse rounds (gnnpn_pointer_decode_attn_f32) against fixtures the real
+    modelPN.py produced with those switches on; same bar as the shipped configuration (per-decision margins)."""
+    from conftest import record_agreement
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
+    fx = golden(f"pn_attn_{name}.npz")
+    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    att, ng = str(fx["attention"]), int(fx["n_glimpses"])
+    nets = []
+    for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
+        m = CombinatorialRL(0, H, T * K, ng, 10, 1, reward, att, K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed, attention=att), strict=True)
+        nets.append(m.to(dev).eval())
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    out = two_level_greedy(nets[0], nets[1], x)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, f"attn/{name}", rows=fx["inputs"])
+    s = rec["same_mask"]
+    assert s.sum() >= 0.7 * len(s), rec
+    assert np.abs(out["win_low"].cpu().numpy()[s] - fx["win_low"][s]).max() < LOGIT_ATOL
+    win_high = (out["win_high_raw"] + out["win_low"]).cpu().numpy()
+    assert np.abs(win_high[s] - fx["win_high"][s]).max() < LOGIT_ATOL
+    assert_R_parity(out["R"], fx["R"], f"attn/{name}", mask=s)
+    assert np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
+    assert np.abs(out["action_probs"].cpu().numpy()[s] - fx["action_probs"][s]).max() < 1e-4
+    rec.update(attention=att, n_glimpses=ng)
+    record_agreement(f"attention_forms/{name}", rec)
+    # reference-style calls give the same picks (CombinatorialRL.forward, Low "SL" -> latent -> High)
+    _, _, _, idx_l, latent = nets[0](x, None, sample="greedy", training="SL")
+    R, _, _, idx_h, _ = nets[1](x, None, latent, sample="greedy")
+    assert torch.equal(torch.stack(idx_l, 1).int(), out["idx_low"]) and torch.equal(torch.stack(idx_h, 1).int(), out["idx_high"])
+    assert torch.equal(R, out["R"])
+
+
+def test_general_kernel_on_the_shipped_configuration_equals_the_streaming_decoder(dev):
+    """'Dot' without glimpses through the general kernel is the streaming decoder's arithmetic: same picks, same window
+    logits bit for bit (the two kernels share the cell, the dot order and the argmax rule)."""
+    from gnnpn_sc_amd import ops
+    fx = golden("pn_qws.npz")
+    low, high = build(fx, dev)
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    T, K = int(fx["n_cat"]), int(fx["n_per"])
+    a = low.actor
+    enc_args, embedded = a.encode_args(x, fold=False)
+    enc, h_n, c_n = ops.lstm_encode([enc_args])
+    d = a.decode_args(embedded, enc[0], h_n[0], c_n[0], fold=False)
+    ref = ops.pointer_decode([d], x, T, K, impl=1)[0]
+    got = ops.pointer_decode_attn(d, x, T, K, "Dot", 0)
+    for key in ("idx", "win_logits", "pick_prob", "actions"):
+        assert torch.equal(ref[key], got[key]), key
 
 
 @pytest.mark.parametrize("name", ["small", "qws"])

@@ -102,6 +102,15 @@ def test_state_dict_layout_is_the_reference_layout():
     assert "actor.alpha" not in pn.state_dict()                                # plain tensor in the reference
     ck = {"epoch": 3, "model": want, "optimizer": {}}                          # trainPNLow.py:112-117
     pn.load_state_dict(ck["model"])
+    # 'Bahdanau': the Attention modules' parameters under the reference's names (modelPN.py:83-90,159-160)
+    bah = CombinatorialRL(0, 32, 18, 2, 10, 1, reward, "Bahdanau", 3, 6)
+    want_b = opn.make_state_dict(32, 0, attention="Bahdanau")
+    assert set(bah.state_dict()) == set(want_b)
+    assert all(bah.state_dict()[k].shape == want_b[k].shape for k in want_b)
+    assert bah.state_dict()["actor.pointer.W_ref.weight"].shape == (32, 32, 1)
+    bah.load_state_dict(want_b, strict=True)
+    with pytest.raises(NotImplementedError):
+        CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Luong", 3, 6)            # modelPN.py:116-117
 
 
 def test_csr_layout_preserves_edge_order():

@@ -35,6 +35,28 @@ def test_pn_oracle_reproduces_reference(name):
     assert np.array_equal(np.isinf(lat1), np.isinf(fx["latent_step1"]))
 
 
+ATTN_FIXTURES = ["dot_g1_small", "bahdanau_g0_small", "bahdanau_g2_small", "dot_g1_qws", "bahdanau_g1_qws"]
+
+
+@pytest.mark.parametrize("name", ATTN_FIXTURES)
+def test_pn_oracle_attention_forms_reproduce_reference(name):
+    """pn_attn_*.npz: the real modelPN.py with attention='Bahdanau' and / or n_glimpses > 0."""
+    fx = golden(f"pn_attn_{name}.npz")
+    torch.set_num_threads(1)
+    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    att, ng = str(fx["attention"]), int(fx["n_glimpses"])
+    sds = [opn.make_state_dict(H, int(fx["seed_low"]), attention=att), opn.make_state_dict(H, int(fx["seed_high"]), attention=att)]
+    out = opn.two_level_greedy(sds[0], sds[1], torch.from_numpy(fx["inputs"]), T, K, attention=att, n_glimpses=ng)
+    for key in ("idx_low", "idx_high", "actions"):
+        assert np.array_equal(out[key].numpy(), fx[key]), key
+    assert np.allclose(out["R"].numpy(), fx["R"], rtol=0, atol=1e-6)
+    assert np.allclose(out["win_low"].numpy(), fx["win_low"], rtol=0, atol=2e-5)
+    assert np.allclose(out["win_high"].numpy(), fx["win_high"], rtol=0, atol=2e-5)
+    # the Bahdanau parameters are drawn after everything else: the 'Dot' weights of the same seed are unchanged
+    plain = opn.make_state_dict(H, int(fx["seed_low"]))
+    assert all(torch.equal(plain[k], sds[0][k]) for k in plain)
+
+
 def test_lstm_cell_explicit_matches_nn_lstm():
     """Documents the cell arithmetic the kernels implement (gate order i,f,g,o)."""
     sd = opn.make_state_dict(32, 3)
