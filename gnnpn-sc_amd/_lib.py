@@ -37,6 +37,11 @@ _SIGNATURES = {
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
+    "gnnpn_bn_train_forward_f32": (c_int, [_P, c_int64, c_int32, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
+    "gnnpn_bn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int, _P, _P, _P, _P]),
+    "gnnpn_bce_sigmoid_f32": (c_int, [_P, _P, c_int64, _P, _P, _P]),
+    "gnnpn_dot_f32": (c_int, [_P, _P, c_int64, _P, _P]),
+    "gnnpn_embed_grad_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P]),
     "gnnpn_pointer_decode_f32": (c_int, [c_int, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          _P, _P, c_int64, _P]),
     "gnnpn_pointer_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),

@@ -240,7 +240,8 @@ class Net(nn.Module):
         (:167-172) then averages row s of every copy.  No layout is assumed and nothing is masked away.  With ONE copy
         (``x_service`` has outChannels rows) this is the problem-independent embedding the device pipeline caches."""
         if self.training:
-            raise NotImplementedError("training mode: this build is the inference path only")
+            raise NotImplementedError("Net.forward is the inference forward; the training step (BatchNorm on batch statistics, "
+                                      "BCE, backward, Adam) is gnnpn_sc_amd.trainML.ml_train_step / TrainML.train")
         x = data.x.squeeze().float().contiguous()
         cache = getattr(data, "_gnnpn_csr", None)
         if cache is None:

@@ -665,6 +665,61 @@ def grad_sumsq(grads):
     return acc
 
 
+# ---- training step of the GNN model (trainML.py; csrc/train_ml.hip) ----------------------------------------------------
+def bn_train_forward(x, gamma, beta, relu, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """BatchNorm1d on batch statistics [+ ReLU]: -> (y, xhat, invstd); the running buffers are updated in place."""
+    x = _rows2d(x, "bn_train_forward.x")
+    y, xhat = torch.empty_like(x), torch.empty_like(x)
+    invstd = torch.empty(x.shape[1], dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_bn_train_forward_f32(
+        dev_ptr(x, F32, "x"), x.shape[0], x.shape[1], dev_ptr(gamma, F32, "gamma"), dev_ptr(beta, F32, "beta"), float(eps),
+        float(momentum), int(bool(relu)), dev_ptr(y, F32, "y"), dev_ptr(xhat, F32, "xhat"), dev_ptr(invstd, F32, "invstd"),
+        dev_ptr(running_mean, F32, "running_mean", True), dev_ptr(running_var, F32, "running_var", True), stream_ptr()),
+        "gnnpn_bn_train_forward_f32")
+    return y, xhat, invstd
+
+
+def bn_train_backward(dy, y, xhat, gamma, invstd, relu):
+    """-> (dx, dgamma, dbeta) of bn_train_forward; dy is the gradient wrt its (post-ReLU) output."""
+    dy = _rows2d(dy, "bn_train_backward.dy")
+    dx = torch.empty_like(dy)
+    dg, db = torch.empty(dy.shape[1], dtype=F32, device=dy.device), torch.empty(dy.shape[1], dtype=F32, device=dy.device)
+    check(_lib.load().gnnpn_bn_train_backward_f32(
+        dev_ptr(dy, F32, "dy"), dev_ptr(y, F32, "y", True), dev_ptr(xhat, F32, "xhat"), dev_ptr(gamma, F32, "gamma"),
+        dev_ptr(invstd, F32, "invstd"), dy.shape[0], dy.shape[1], int(bool(relu)), dev_ptr(dx, F32, "dx"), dev_ptr(dg, F32, "dg"),
+        dev_ptr(db, F32, "db"), stream_ptr()), "gnnpn_bn_train_backward_f32")
+    return dx, dg, db
+
+
+def bce_sigmoid(p, y):
+    """BCELoss(mean)(p, y) for p = sigmoid(z) -> (loss [1], dLoss/dz, same shape as p)."""
+    p = p.contiguous()
+    y = y.reshape(p.shape).contiguous()
+    dz, loss = torch.empty_like(p), torch.empty(1, dtype=F32, device=p.device)
+    check(_lib.load().gnnpn_bce_sigmoid_f32(dev_ptr(p, F32, "p"), dev_ptr(y, F32, "y"), p.numel(), dev_ptr(dz, F32, "dz"),
+                                            dev_ptr(loss, F32, "loss"), stream_ptr()), "gnnpn_bce_sigmoid_f32")
+    return loss, dz
+
+
+def dot(a, b):
+    a, b = a.contiguous(), b.contiguous()
+    if a.numel() != b.numel():
+        raise GnnpnError("dot: sizes differ")
+    out = torch.empty(1, dtype=F32, device=a.device)
+    check(_lib.load().gnnpn_dot_f32(dev_ptr(a, F32, "a"), dev_ptr(b, F32, "b"), a.numel(), dev_ptr(out, F32, "out"), stream_ptr()),
+          "gnnpn_dot_f32")
+    return out
+
+
+def embed_grad(dh, x, c, vocab):
+    """Gradient of the embedding table of embed_concat: dh [N, >= c] (its first c columns), ids in x[:, 0] -> [vocab, c]."""
+    dh, x = _rows2d(dh, "embed_grad.dh"), _rows2d(x, "embed_grad.x")
+    out = torch.empty((vocab, c), dtype=F32, device=dh.device)
+    check(_lib.load().gnnpn_embed_grad_f32(dev_ptr(dh, F32, "dh"), dh.shape[1], dev_ptr(x, F32, "x"), x.shape[1], dh.shape[0], c,
+                                           vocab, dev_ptr(out, F32, "dtable"), stream_ptr()), "gnnpn_embed_grad_f32")
+    return out
+
+
 def adam_step(p, g, m, v, sumsq, max_grad_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     """clip_grad_norm_ + torch.optim.Adam (defaults) on one parameter tensor, in place   (gnnpn_adam_step_f32)."""
     check(_lib.load().gnnpn_adam_step_f32(dev_ptr(p, F32, "p"), dev_ptr(g, F32, "g"), dev_ptr(m, F32, "m"), dev_ptr(v, F32, "v"),

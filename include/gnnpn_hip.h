@@ -460,6 +460,31 @@ int gnnpn_eswoa_f64(int32_t P, int32_t T, const int32_t* cand_ptr, const int32_t
                     int32_t max_cand, double* best_fitness, int32_t* best_pos, double* history, int64_t* draws,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training step of the GNN candidate-ranking model.  Replaces the autograd graph of
+ * src/models/trainML.py:39-45 over src/models/modelML.py:131-176 (model.train(): BatchNorm1d on batch statistics).  The
+ * step is assembled on the host side (gnnpn-sc_amd/trainML.py) from the inference kernels — gnnpn_linear_f32,
+ * gnnpn_csr_aggregate_f32 on the graph and on its transpose, gnnpn_embed_concat_f32 — the generic training kernels above
+ * (gnnpn_gemm_f32, gnnpn_colsum_f32, gnnpn_adam_step_f32) and:
+ * gnnpn_bn_train_forward_f32: y = [relu](gamma * xhat + beta), xhat = (x - mean) / sqrt(var_biased + eps) over the rows
+ *   (BatchNorm1d at modelML.py:79,87,141,154 in training mode); saves xhat [rows,cols] and invstd [cols]; running_mean /
+ *   running_var (optional) move by `momentum` towards the batch mean / unbiased variance.
+ * gnnpn_bn_train_backward_f32: dy wrt the (post-ReLU) output -> dx, dgamma, dbeta.
+ * gnnpn_bce_sigmoid_f32: loss = BCELoss(mean)(p, y) (trainML.py:28,42; log terms clamped at -100) for p = sigmoid(z), and
+ *   dz = dLoss/dz as autograd forms it (BCELoss backward with its 1e-12 clamp, then sigmoid backward).
+ * gnnpn_dot_f32: out = sum a_i b_i (GINConv's d eps = <d out, x>, modelML.py:91 train_eps=True).
+ * gnnpn_embed_grad_f32: d table[v] = sum of dh[n][0:c] over rows with id x[n*ldx] == v, rows ascending (the Embedding
+ *   backward of NodeEncoder, modelML.py:22-29). */
+int gnnpn_bn_train_forward_f32(const float* x, int64_t rows, int32_t cols, const float* gamma, const float* beta, float eps,
+                               float momentum, int relu, float* y, float* xhat, float* invstd, float* running_mean,
+                               float* running_var, void* stream);
+int gnnpn_bn_train_backward_f32(const float* dy, const float* y, const float* xhat, const float* gamma, const float* invstd,
+                                int64_t rows, int32_t cols, int relu, float* dx, float* dgamma, float* dbeta, void* stream);
+int gnnpn_bce_sigmoid_f32(const float* p, const float* y, int64_t n, float* dz, float* loss, void* stream);
+int gnnpn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+int gnnpn_embed_grad_f32(const float* dh, int64_t ldh, const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t vocab,
+                         float* dtable, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,8 +14,10 @@
     python main.py QWS PNLow [epochML]   # REINFORCE training of the Low pointer net on the GPU (reference main.py:40-52)
     python main.py QWS PNHigh [epochML [epochPNLow]]   # ... of the High net against the trained Low net (:66-84); --epochs=N
 
-Every other approach of the reference (ML training, the other WOA modes, GA/DQN baselines) is out of scope and
-answers with the reference's own message.
+    python main.py QWS ML                # training of the GNN candidate-ranking model on the GPU (reference main.py:20-32)
+
+Every other approach of the reference (the other WOA modes, GA/DQN baselines) is out of scope and answers with the
+reference's own message.
 """
 import configparser
 import os
@@ -49,7 +51,7 @@ def main(argv):
         return 1
     dataset, approach = argv[1], argv[2]
     ds = {"QWS": "QWS", "qws": "QWS", "Normal": "Normal"}.get(dataset)
-    if ds is None or approach not in ("ML+2PN", "WOA", "PNLow", "PNHigh"):
+    if ds is None or approach not in ("ML+2PN", "WOA", "PNLow", "PNHigh", "ML"):
         print("Please check the parameters!")                       # reference main.py:231
         return 1
     here = os.path.dirname(os.path.abspath(__file__))
@@ -69,6 +71,16 @@ def main(argv):
         WOA.WOA(ds, int(sec["serCategory"]), int(sec["MLESWOAtest"]), int(sec["ML2PNWOATest"]), int(sec["MLWOATest"]),
                 int(sec["ESWOAtest"]), int(sec["serviceNumber"]), reduct, epoch, int(sec["MAX_Iter"]), int(sec["popSize"]),
                 seed=seed).start()
+        return 0
+    if approach == "ML":                                            # reference main.py:20-32: GNN training on the GPU
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from gnnpn_sc_amd import trainML
+        sec = cfg[f"{ds}-ML"]
+        n_epochs = next((int(a.split("=")[1]) for a in argv[3:] if a.startswith("--epochs=")), None)
+        trainML.TrainML(ds, int(sec["numLayersGIN"]), int(sec["numLayersGCN"]), int(sec["hiddenChannels"]),
+                        int(sec["embeddingChannels"]), float(sec["dropout"]), float(sec["lr"]),
+                        n_epochs or int(sec["epochs"])).start()
         return 0
     if approach in ("PNLow", "PNHigh"):                             # reference main.py:40-84: REINFORCE training on the GPU
         if here not in sys.path:

@@ -439,6 +439,81 @@ def gen_ml_pygbatch(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, n_t=3,
           f"{float((ref - clean).abs().max()):.3f}")
 
 
+def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3, degree=6, steps=2):
+    """``steps`` consecutive batches of TrainML.train (trainML.py:34-47) on the REAL Net glue (stand-in
+    convs) under autograd — model.train(), BCELoss, backward, Adam(lr) — each on a torch_geometric-1.7.0-style batch of two
+    graphs.  Stores, for the first and the last step, the loss, every gradient, the weights after the step and the
+    BatchNorm running statistics; the autograd oracle (oracle/ml_train.py) must reproduce them."""
+    from oracle import ml_train as omt
+    B = 2
+    table = synth.make_service_table(T, S, seed, degree=degree)
+    sd = oml.make_state_dict(hidden, emb, n_gin, n_gcn, seed + 2)
+    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=True, dropout=0.0)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=lr)                                        # trainML.py:130
+    crit = torch.nn.BCELoss()                                                              # :28
+    xs, eis, eas = (torch.from_numpy(a) for a in (table.x_service, table.edge_index, table.edge_attr))
+    keys = omt.trainable_keys(sd, n_gin, n_gcn)
+    cur, st, out = dict(sd), None, {}
+    g = torch.Generator().manual_seed(seed + 7)
+    for step in range(1, steps + 1):
+        batch = synth.make_problem_batch(table, B, seed + 10 * step, tasks_per_problem=n_t)
+        nodes = np.bincount(batch.batch, minlength=B)
+        offsets = np.concatenate([[0], np.cumsum(nodes)[:-1]])
+        ei_b, ea_b = oml.pyg_batch_service_edges(eis, eas, offsets)
+        data = oml.make_data(torch.from_numpy(batch.x), torch.from_numpy(batch.edge_index), torch.from_numpy(batch.batch),
+                             xs.repeat(B, 1), ei_b, ea_b)
+        y = (torch.rand(B * S, generator=g) < 0.02).float()                                # labels: a few services per problem
+        opt.zero_grad()                                                                    # :40
+        x = net(data).squeeze()                                                            # :41
+        loss = crit(x, y.view(x.size(0), x.size(1)))                                       # :42
+        loss.backward()                                                                    # :43
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        assert set(grads) == set(keys), sorted(set(grads) ^ set(keys))
+        opt.step()                                                                         # :45
+        ref_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        orc = omt.train_step(cur, data, y, n_gin, n_gcn, S, lr, st, step)
+        assert abs(float(orc["loss"]) - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))
+        gmax = max(float(grads[k].abs().max()) for k in keys)
+        for k in keys:
+            # a bias in front of a training-mode BatchNorm has an exactly zero gradient: rounding noise on both sides,
+            # so the bound is relative to the parameter's own scale OR 1e-6 of the largest gradient of the step
+            scale = float(grads[k].abs().max())
+            assert float((orc["grads"][k] - grads[k]).abs().max()) <= 2e-5 * scale + 1e-6 * gmax, (k, step)
+            clear = grads[k].abs() > 1e-6       # Adam's step is sign-like near g = 0 (eps = 1e-8): ill-conditioned there
+            if bool(clear.any()):
+                assert float((orc["new_params"][k] - ref_sd[k])[clear].abs().max()) <= 2e-6, (k, step)
+        for pre, (rm, rv) in orc["running"].items():
+            assert float((rm - ref_sd[pre + ".running_mean"]).abs().max()) <= 1e-5, pre
+            assert float((rv - ref_sd[pre + ".running_var"]).abs().max()) <= 1e-5 * max(1.0, float(rv.abs().max())), pre
+        for tag in (["first"] if step == 1 else []) + (["last"] if step == steps and steps > 1 else []):
+            out.update({f"{tag}_x": batch.x, f"{tag}_edge_index": batch.edge_index, f"{tag}_batch": batch.batch,
+                        f"{tag}_offsets": offsets, f"{tag}_y": y.numpy(), f"{tag}_loss": float(loss.detach()), f"{tag}_scores": x.detach().numpy()})
+            for k in keys:
+                out[f"{tag}_grad/{k}"] = grads[k].numpy()
+                out[f"{tag}_param/{k}"] = ref_sd[k].numpy()
+            for pre in orc["running"]:
+                out[f"{tag}_running_mean/{pre}"] = ref_sd[pre + ".running_mean"].numpy()
+                out[f"{tag}_running_var/{pre}"] = ref_sd[pre + ".running_var"].numpy()
+        if step == steps - 1:
+            # the state the LAST step starts from (so that a test can replay that step alone)
+            for k, v in ref_sd.items():
+                if v.dtype.is_floating_point:
+                    out[f"before_last/{k}"] = v.numpy()
+            for k in keys:
+                m, v = opt.state[dict(net.named_parameters())[k]]["exp_avg"], opt.state[dict(net.named_parameters())[k]]["exp_avg_sq"]
+                out[f"before_last_m/{k}"], out[f"before_last_v/{k}"] = m.clone().numpy(), v.clone().numpy()
+        # carry on from the REFERENCE's state (not the oracle's) so that errors cannot accumulate unnoticed
+        cur = {k: v.clone() for k, v in ref_sd.items()}
+        named = dict(net.named_parameters())
+        st = {k: (opt.state[named[k]]["exp_avg"].clone(), opt.state[named[k]]["exp_avg_sq"].clone()) for k in keys}
+    np.savez_compressed(os.path.join(HERE, f"ml_train_{name}.npz"), hidden=hidden, emb=emb, n_gin=n_gin, n_gcn=n_gcn, T=T, S=S,
+                        B=B, seed=seed, lr=lr, steps=steps, x_service=table.x_service, edge_index_service=table.edge_index,
+                        edge_attr_service=table.edge_attr, **out)
+    print(f"ml_train_{name}: {steps} steps, loss first/last = {out['first_loss']:.6f} / {out.get('last_loss', out['first_loss']):.6f}")
+
+
 def gen_hand_graph():
     """G6: a 5-node hand-checkable graph for the aggregate ops (expected values by oracle, which
     the stand-in cross-checks)."""
@@ -486,6 +561,8 @@ def main():
     gen_ml(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, B=2, seed=61, n_t=10, degree=8)
     gen_ml(modelML, "normal", hidden=128, emb=20, n_gin=2, n_gcn=4, T=50, S=250, B=1, seed=71, n_t=10, degree=8)
     gen_ml_pygbatch(modelML, "pygbatch", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=81, n_t=10, degree=8)
+    gen_ml_train(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, seed=121, lr=1e-3, steps=3)
+    gen_ml_train(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=131, lr=1e-3, n_t=10, degree=8, steps=1)
     gen_hand_graph()
 
 

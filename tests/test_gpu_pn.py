@@ -138,9 +138,10 @@ def test_unsupported_modes_fail_loudly(dev):
     with pytest.raises(NotImplementedError):
         CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6)
     with pytest.raises(NotImplementedError):
-        CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Dot", 3, 6)
+        CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Luong", 3, 6)             # modelPN.py:116-117
+    g = CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Bahdanau", 3, 6).to(dev)  # the general forms decode greedily only
     with pytest.raises(NotImplementedError):
-        CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Bahdanau", 3, 6)
+        g(torch.rand(2, 18, 8, device=dev), None)                               # default sample="sample"
     m = CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)
     R, probs, actions, idxs, _ = m(torch.rand(2, 18, 8, device=dev), None)   # default sample="sample": the sampling forward
     assert R.shape == (2,) and len(idxs) == 6 and probs[0].shape == (2,)

@@ -273,6 +273,35 @@ def test_training_oracle_reproduces_reference_autograd(name):
             assert abs(float((got.flatten().double() * vec.double()).sum()) - float(fx[f"gradproj_{s}"])) < 2e-3 * n + 1e-7, k
 
 
+@pytest.mark.parametrize("name", ["tiny", "qws"])
+def test_ml_training_oracle_reproduces_reference_autograd(name):
+    """ml_train_*.npz: TrainML.train's loop body (trainML.py:39-45) on the reference's own Net glue under autograd (stand-in
+    convs); the autograd restatement oracle/ml_train.py gives the same loss, gradients, post-Adam weights and BatchNorm
+    running statistics for the first step."""
+    from oracle import ml_train as omt
+    fx = golden(f"ml_train_{name}.npz")
+    torch.set_num_threads(1)
+    n_gin, n_gcn, S, B = int(fx["n_gin"]), int(fx["n_gcn"]), int(fx["S"]), int(fx["B"])
+    sd = oml.make_state_dict(int(fx["hidden"]), int(fx["emb"]), n_gin, n_gcn, int(fx["seed"]) + 2)
+    t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
+    ei, ea = oml.pyg_batch_service_edges(t("edge_index_service"), t("edge_attr_service"), fx["first_offsets"])
+    data = oml.make_data(t("first_x"), t("first_edge_index"), t("first_batch"), t("x_service").repeat(B, 1), ei, ea)
+    out = omt.train_step(sd, data, t("first_y"), n_gin, n_gcn, S, float(fx["lr"]))
+    assert abs(float(out["loss"]) - float(fx["first_loss"])) <= 1e-6
+    assert float((out["scores"] - t("first_scores")).abs().max()) <= 1e-6
+    keys = omt.trainable_keys(sd, n_gin, n_gcn)
+    gmax = max(float(np.abs(fx[f"first_grad/{k}"]).max()) for k in keys)
+    for k in keys:
+        want = t(f"first_grad/{k}")
+        assert float((out["grads"][k] - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6 * gmax, k
+        clear = want.abs() > 1e-6
+        if bool(clear.any()):
+            assert float((out["new_params"][k] - t(f"first_param/{k}"))[clear].abs().max()) <= 2e-6, k
+    for pre, (rm, rv) in out["running"].items():
+        assert float((rm - t(f"first_running_mean/{pre}")).abs().max()) <= 1e-5
+        assert float((rv - t(f"first_running_var/{pre}")).abs().max()) <= 1e-5 * max(1.0, float(rv.abs().max()))
+
+
 def test_gcn_conv_against_dense_fp64_formula():
     """Independent cross-check of the (unpinnable, third-party) GCNConv arithmetic: the layer written as the dense matrix
     formula  D^-1/2 (A_w + I) D^-1/2 X W + b  in float64 — weighted adjacency with A[dst, src] = w, unit self loops
