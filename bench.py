@@ -53,8 +53,8 @@ WORKLOADS = {
                    desc="Normal shape: T=50 K=10 L=500 S=5000(assumed) H=256, batch=1024 (configs[2])"),
     "synth4": dict(T=1000, K=5, S=5000, B=512, n_t=1000, n_gcn=2, G=4096,
                    desc="synthetic 1000-task/5000-candidate, batch=512 per GPU (configs[3] = 4096 over 8)"),
-    "synth5": dict(T=2000, K=10, S=20000, B=64, n_t=2000, n_gcn=2,
-                   desc="synthetic 2000-task/20000-candidate, batch=64 per GPU (configs[4]; its 'fp16 encoder MFMA path' "
+    "synth5": dict(T=2000, K=10, S=20000, B=256, n_t=2000, n_gcn=2,
+                   desc="synthetic 2000-task/20000-candidate, batch=256 per GPU (configs[4]; its 'fp16 encoder MFMA path' "
                         "is --precision f16)"),
 }
 

@@ -23,7 +23,7 @@ def cp_json(src, dst):
 for src, dst in (("bench_qws.json", "r02_qws_b256_bench.json"), ("bench_qws_driver_flags.json", "r02_qws_b256_bench_steps20.json"),
                  ("bench_normal.json", "r02_normal_b1024_bench.json"), ("bench_synth4.json", "r02_synth4_b512_bench.json"),
                  ("bench_synth4_strong_g4096_n1.json", "r02_synth4_strong_g4096_n1_bench.json"),
-                 ("bench_synth5.json", "r02_synth5_b64_bench.json"), ("bench_synth5_f16.json", "r02_synth5_b64_fp16_encoder_bench.json"),
+                 ("bench_synth5.json", "r02_synth5_b256_bench.json"), ("bench_synth5_f16.json", "r02_synth5_b256_fp16_encoder_bench.json"),
                  ("bench_qws_f16.json", "r02_qws_b256_fp16_encoder_bench.json"),
                  ("bench_force_dist_rccl_world1.json", "r02_qws_b256_rccl_world1_bench.json"),
                  ("bench_selflaunch_2ranks_shared_gpu.json", "r02_selflaunch_2ranks_shared_gpu_gloo_NOT_A_MEASUREMENT.json"),
