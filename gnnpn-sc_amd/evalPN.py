@@ -1,8 +1,8 @@
 """The two-level evaluation harness of the reference's PNHigh driver
 (/root/reference/src/models/trainPNHigh.py): ``SCDataset`` (:15-41) and the eval block of
 ``TrainModel.train_and_validate`` (:131-144) — Low greedy -> latent -> High greedy per batch of 128,
-actions accumulated as ``allActions[T][nTest][8]`` (the artefact ``ML2PN.check`` reads).  Training
-(:76-112) is out of scope.
+actions accumulated as ``allActions[T][nTest][8]`` (the artefact ``ML2PN.check`` reads).  The training
+loop (:76-112) is gnnpn_sc_amd/trainPNHigh.py.
 """
 import torch
 
