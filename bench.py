@@ -181,6 +181,9 @@ def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
                       f"{cores} threads of {os.cpu_count()} host CPUs, {el:.1f} s"}
 
 
+REAL_STDOUT = 1
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) and relay their status.
     Runs BEFORE this process touches a GPU (torch.cuda.device_count() does not initialise one on this image) and never
@@ -263,6 +266,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                                 # never returns
+    # stdout carries ONE line, the JSON: the libraries initialised below write to the C stdout (RCCL's version banner, gloo's
+    # connection notes), so fd 1 is pointed at stderr for the run and the real one is kept for the line
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -519,13 +528,13 @@ def main():
         line["split_operands"] = split_line
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, table, pb, net, low, high)
-    # RCCL writes a version banner to the C stdout buffer, which would otherwise come out at exit, AFTER this line
-    try:
+    try:                   # whatever the libraries buffered on the C stdout goes where fd 1 points now: stderr
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:      # noqa: BLE001
         pass
-    print(json.dumps(line), flush=True)
+    sys.stdout.flush()
+    os.write(REAL_STDOUT, (json.dumps(line) + "\n").encode())
     gdist.destroy(2 if force_dist else world)
 
 

@@ -451,3 +451,42 @@ def test_soak_two_slots(dev, precision):
         bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
     runner.synchronize(check=True)
     assert bad == 0, f"{bad} of 2000 pipelined steps differ from the single-stream run"
+
+
+def test_bench_line_contract(dev):
+    """bench.py as the driver runs it (a child process, `--gpus 1 --steps K --warmup W`): exit 0, exactly ONE JSON line on
+    stdout with the contract's keys, the BASELINE metric / config, a roofline object for the dominant kernel and the CPU
+    baseline; and the self-launching `--gpus 2` entry (two ranks on this one GPU over gloo: launch path only)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--min-time", "0",
+                        "--no-split-line"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert base["metric"].startswith(d["metric"].split(" (")[0]) and d["unit"] == "problems/s"
+    assert d["dtype"] == "f32" and d["vs_baseline"] is None and d["value"] > 0                 # BASELINE.md publishes no number
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    env2 = dict(env, GNNPN_BENCH_SHARE_GPU="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--min-time", "0",
+                         "--no-cpu-baseline", "--no-split-line", "--no-kernel-timers"], capture_output=True, text=True, timeout=600,
+                        env=env2, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = [ln for ln in r2.stdout.splitlines() if ln.strip()]
+    assert len(out2) == 1
+    d2 = json.loads(out2[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 2 * d2["config"]["batch_per_gpu"]
