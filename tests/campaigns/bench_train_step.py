@@ -1,10 +1,11 @@
 """Time of one REINFORCE training step of the High pointer network (trainPNHigh.py:81-110) at the reference's batch size
 (128, :248) on the QWS / Normal shapes, with the breakdown sampled-forward / backward / optimiser, next to the CPU oracle
-(torch autograd restatement of the same step).   python tools/bench_train_step.py [--cpu]"""
+(torch autograd restatement of the same step).   python tests/campaigns/bench_train_step.py [--cpu]   (under tests/: it times the oracle beside the HIP path)"""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from pn_inputs import pn_inputs
 from oracle import pn as opn, pn_train as optr
 from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
