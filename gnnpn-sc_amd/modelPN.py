@@ -128,6 +128,7 @@ class PointerNet(nn.Module):
         self.decoder_start_input = nn.Parameter(torch.FloatTensor(hidden_size))        # :162-163
         self.decoder_start_input.data.uniform_(-(1. / math.sqrt(hidden_size)), 1. / math.sqrt(hidden_size))
         self._packed = None
+        self.fold_on_device = False
         # sampling mode: the reference draws from torch's global generator; here the draws of forward call n come from
         # the counter-based stream seeded (sample_seed, n) — reproducible, and a function of nothing but the two numbers
         self.sample_seed = int(torch.initial_seed()) & 0x7FFFFFFF
@@ -157,26 +158,32 @@ class PointerNet(nn.Module):
                 "dec_whh": ops.pack_lstm_weight(f(self.decoder.weight_hh_l0)), "dec_bhh": f(self.decoder.bias_hh_l0),
                 "start": f(self.decoder_start_input),
             }
-            # folded input projection, formed in fp64 on the host and rounded once
-            w_ih, w_e = self.encoder.weight_ih_l0.detach().double().cpu(), self.embedding2.weight.detach().double().cpu()
-            b = w_ih @ self.embedding2.bias.detach().double().cpu() + self.encoder.bias_ih_l0.detach().double().cpu()
+            # folded input projection, formed in fp64 and rounded once.  Weights loaded for inference fold on the host (the
+            # arithmetic every committed parity record was measured with); while a trainer steps the weights
+            # (``fold_on_device``, set by trainPNHigh.ActorAdam) the same fp64 products run on the device instead of a
+            # 1 MB round trip through the host per step.
+            where = (lambda t: t.detach().double()) if self.fold_on_device else (lambda t: t.detach().double().cpu())
             dev = self.embedding2.weight.device
-            self._packed["enc_wfold"] = (w_ih @ w_e).float().contiguous().to(dev)
-            self._packed["enc_bfold"] = b.float().contiguous().to(dev)
+            back = lambda t: t.float().contiguous().to(dev)   # noqa: E731
+            w_ih, w_e, b_e = where(self.encoder.weight_ih_l0), where(self.embedding2.weight), where(self.embedding2.bias)
+            self._packed["enc_wfold"] = back(w_ih @ w_e)
+            self._packed["enc_bfold"] = back(w_ih @ b_e + where(self.encoder.bias_ih_l0))
             # the same for the decoder cell's input side, plus its step-0 gates W_ih.start + b_ih
-            d_ih, d_b = self.decoder.weight_ih_l0.detach().double().cpu(), self.decoder.bias_ih_l0.detach().double().cpu()
-            self._packed["dec_wfold"] = (d_ih @ w_e).float().contiguous().to(dev)
-            self._packed["dec_bfold"] = (d_ih @ self.embedding2.bias.detach().double().cpu() + d_b).float().contiguous().to(dev)
-            self._packed["dec_sfold"] = (d_ih @ self.decoder_start_input.detach().double().cpu() + d_b).float().contiguous().to(dev)
-            # largest |W_hh|: the fp16-operand precisions ("split", "f16") need it inside fp16's range
-            self._packed["whh_absmax"] = float(max(self.encoder.weight_hh_l0.detach().abs().max(),
-                                                   self.decoder.weight_hh_l0.detach().abs().max()))
+            d_ih, d_b = where(self.decoder.weight_ih_l0), where(self.decoder.bias_ih_l0)
+            self._packed["dec_wfold"] = back(d_ih @ w_e)
+            self._packed["dec_bfold"] = back(d_ih @ b_e + d_b)
+            self._packed["dec_sfold"] = back(d_ih @ where(self.decoder_start_input) + d_b)
+            self._packed["whh_absmax"] = None      # on demand (check_precision): it costs two device-to-host reads
         return self._packed
 
     def check_precision(self, precision):
         """fp16-operand modes hold W_hh as fp16 (pairs): refuse weights outside fp16's finite range."""
         if precision != "f32":
-            m = self.packed()["whh_absmax"]
+            w = self.packed()
+            if w["whh_absmax"] is None:          # largest |W_hh|: the fp16-operand precisions need it inside fp16's range
+                w["whh_absmax"] = float(max(self.encoder.weight_hh_l0.detach().abs().max(),
+                                            self.decoder.weight_hh_l0.detach().abs().max()))
+            m = w["whh_absmax"]
             if not m < 6.0e4:
                 raise ops.GnnpnError(f"precision={precision!r}: max |W_hh| = {m:g} does not fit fp16 operands; use 'f32'")
 

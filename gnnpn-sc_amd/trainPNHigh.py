@@ -83,6 +83,7 @@ class ActorAdam:
             m, v = self.state[k]
             ops.adam_step(p.data, grads[k].contiguous(), m, v, sumsq, self.max_grad_norm, self.lr, self.steps)
         self.actor._packed = None                                  # the inference kernels re-pack the new weights
+        self.actor.fold_on_device = True                           # ... forming the folded input matrices on the device
         return sumsq.sqrt()
 
 
