@@ -462,7 +462,9 @@ def test_bench_line_contract(dev):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root)
+    env = {k: v for k, v in os.environ.items()                 # an earlier test's process group left RANK / WORLD_SIZE behind
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "GNNPN_FORCE_DIST")}
+    env["PYTHONPATH"] = root
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--min-time", "0",
                         "--no-split-line"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
