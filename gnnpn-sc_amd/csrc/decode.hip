@@ -182,6 +182,8 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
                                         float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
                                         int32_t precision, const gnnpn_launch_opts_t* opts_in, void* workspace,
                                         int64_t workspace_bytes, void* stream) {
+    GNNPN_REQUIRE(B >= 0 && T > 0, "pointer_decode: bad shape");
+    if (B == 0) return GNNPN_OK;                    // empty batch: its buffers may be NULL
     GNNPN_REQUIRE(nets && inputs, "pointer_decode: null input");
     const CoopOpts opts = coop_opts(opts_in);
     GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 4, "pointer_decode: opts.impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups), 3 (16-CU groups) or 4 (8-CU groups, 256-register build)");
@@ -302,8 +304,9 @@ extern "C" int gnnpn_attention_logits_f32(const float* enc_out, const float* que
                                           const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits,
                                           int32_t B, int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx,
                                           void* stream) {
-    GNNPN_REQUIRE(enc_out && queries && logits, "attention_logits: null operand");
     GNNPN_REQUIRE(B >= 0 && L > 0 && H > 0 && H % 4 == 0 && ld_q >= H && ld_q % 4 == 0, "attention_logits: bad shape");
+    if (B == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(enc_out && queries && logits, "attention_logits: null operand");
     GNNPN_REQUIRE(n_masked == 0 || (masked_idx && ld_idx >= n_masked), "attention_logits: bad mask list");
     GNNPN_REQUIRE(gnnpn_aligned(enc_out, 16) && gnnpn_aligned(queries, 16), "attention_logits: 16-byte alignment");
     if (B == 0) return GNNPN_OK;
@@ -366,9 +369,9 @@ __global__ void qos_reward_kernel(const float* __restrict__ actions, float* __re
 
 extern "C" int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, int32_t T, int level,
                                     void* stream) {
-    GNNPN_REQUIRE(actions && R, "qos_reward: null operand");
     GNNPN_REQUIRE(B >= 0 && T > 0 && (level == 0 || level == 1), "qos_reward: bad argument");
     if (B == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(actions && R, "qos_reward: null operand");
     hipLaunchKernelGGL(qos_reward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, actions, R, B, T,
                        level);
     GNNPN_CHECK_LAUNCH("qos_reward_f32");

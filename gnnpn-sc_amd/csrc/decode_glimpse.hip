@@ -251,8 +251,9 @@ int launch_glimpse(const DecodeNet& net, const AttnSide& ptr, const AttnSide& gl
 extern "C" int gnnpn_pointer_decode_attn_f32(const gnnpn_decode_net_t* net_in, const gnnpn_attention_t* attn,
                                              const float* inputs, float tanh_c, int use_tanh, int32_t B, int32_t T,
                                              int32_t n_per, int32_t H, void* stream) {
-    GNNPN_REQUIRE(net_in && attn && inputs, "pointer_decode_attn: null argument");
     GNNPN_REQUIRE(B >= 0 && T >= 1 && n_per >= 1 && n_per <= 64, "pointer_decode_attn: B >= 0, T >= 1, 1 <= n_per <= 64");
+    if (B == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(net_in && attn && inputs, "pointer_decode_attn: null argument");
     GNNPN_REQUIRE(H == 256 || H == 32, "pointer_decode_attn: built for H = 256 and H = 32, got %d", H);
     GNNPN_REQUIRE(attn->attention == 0 || attn->attention == 1, "pointer_decode_attn: attention 0 ('Dot') or 1 ('Bahdanau')");
     GNNPN_REQUIRE(attn->n_glimpses >= 0, "pointer_decode_attn: n_glimpses >= 0");

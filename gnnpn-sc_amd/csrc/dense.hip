@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(
 extern "C" int gnnpn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
                                 const float* bias, const float* scale, const float* shift, int act,
                                 float* C, int64_t ldc, int64_t M, int N, int K, void* stream) {
-    GNNPN_REQUIRE(A && W && C, "linear: null operand");
     GNNPN_REQUIRE(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return GNNPN_OK;                    // empty batch: its buffers may be NULL
+    GNNPN_REQUIRE(A && W && C, "linear: null operand");
     GNNPN_REQUIRE(lda >= K && ldw >= K && ldc >= N, "linear: leading dimension too small");
     GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "linear: scale and shift go together");
     GNNPN_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
@@ -186,9 +187,9 @@ __global__ void embed_concat_kernel(const float* __restrict__ x, const float* __
 
 extern "C" int gnnpn_embed_concat_f32(const float* x, const float* table, int vocab, int emb, int nfeat,
                                       float* out, int64_t n_rows, void* stream) {
-    GNNPN_REQUIRE(x && table && out, "embed_concat: null operand");
     GNNPN_REQUIRE(vocab > 0 && emb > 0 && nfeat >= 0 && n_rows >= 0, "embed_concat: bad shape");
     if (n_rows == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(x && table && out, "embed_concat: null operand");
     const int64_t total = n_rows * (emb + nfeat);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -267,8 +268,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 extern "C" int gnnpn_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
                               int64_t ldc, int64_t M, int N, int K, int split_k, void* stream) {
-    GNNPN_REQUIRE(A && B && C, "gemm: null operand");
     GNNPN_REQUIRE(M >= 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(A && B && C, "gemm: null operand");
     GNNPN_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K), "gemm: leading dimension too small");
     GNNPN_REQUIRE(split_k >= 1 && split_k <= 1024, "gemm: split_k must be 1..1024");
     if (M == 0) return GNNPN_OK;

@@ -101,8 +101,9 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
                                        int64_t ldx, const float* self_coef, const float* bias,
                                        const float* scale, const float* shift, int act, float* y, int64_t ldy,
                                        int32_t n_rows, int32_t C, void* stream) {
-    GNNPN_REQUIRE(rowptr && x && y, "csr_aggregate: null operand");
     GNNPN_REQUIRE(n_rows >= 0 && C > 0 && ldx >= C && ldy >= C, "csr_aggregate: bad shape");
+    if (n_rows == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(rowptr && x && y, "csr_aggregate: null operand");
     GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "csr_aggregate: scale and shift go together");
     GNNPN_REQUIRE(x != y, "csr_aggregate: in-place aggregation is not supported");
     if (n_rows == 0) return GNNPN_OK;
@@ -299,9 +300,9 @@ __global__ void gcn_edge_norm_kernel(const int32_t* __restrict__ rowptr, const i
 
 extern "C" int gnnpn_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, const float* w_raw,
                                   float* deg_inv_sqrt, float* norm, int32_t n_rows, void* stream) {
-    GNNPN_REQUIRE(rowptr && col && w_raw && deg_inv_sqrt && norm, "gcn_norm: null operand");
     GNNPN_REQUIRE(n_rows >= 0, "gcn_norm: bad shape");
     if (n_rows == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(rowptr && col && w_raw && deg_inv_sqrt && norm, "gcn_norm: null operand");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gcn_deg_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rowptr, w_raw, deg_inv_sqrt, n_rows);
     hipLaunchKernelGGL(gcn_edge_norm_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, rowptr, col, w_raw,
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const int32_t* __rest
 
 extern "C" int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, float* out, int64_t ldo,
                                       int32_t n_seg, int32_t C, void* stream) {
-    GNNPN_REQUIRE(segptr && x && out, "segment_mean: null operand");
     GNNPN_REQUIRE(n_seg >= 0 && C > 0 && ldx >= C && ldo >= C, "segment_mean: bad shape");
     if (n_seg == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(segptr && out, "segment_mean: null operand");      // x may be NULL when every segment is empty
     hipLaunchKernelGGL(segment_mean_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, (hipStream_t)stream, segptr, x,
                        ldx, out, ldo, n_seg, C);
     GNNPN_CHECK_LAUNCH("segment_mean_f32");

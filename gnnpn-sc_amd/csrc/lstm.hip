@@ -90,6 +90,7 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
     GNNPN_REQUIRE(in, "lstm_encode: null net array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
+    if (B == 0) return GNNPN_OK;                    // empty batch: its buffers may be NULL
     GNNPN_REQUIRE(precision >= GNNPN_PREC_F32 && precision <= GNNPN_PREC_SPLIT, "lstm_encode: unknown precision %d", precision);
     if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: hidden size %d not built (256, 32)", H);
     LstmNets nets{};

@@ -241,9 +241,10 @@ extern "C" int gnnpn_request_branch_f32(const float* x, int32_t nfeat, const flo
                                         int32_t n_graphs, int32_t max_nodes, int32_t n_layers,
                                         const gnnpn_gin_layer_t* layers, int32_t hidden, const float* lin_w_packed,
                                         const float* lin_b, float* out, void* stream) {
+    GNNPN_REQUIRE(n_graphs >= 0 && n_layers >= 1 && nfeat >= 0 && vocab > 0 && emb > 0, "request_branch: bad shape");
+    if (n_graphs == 0) return GNNPN_OK;
     GNNPN_REQUIRE(x && table && rowptr && seg_ptr && layers && lin_w_packed && lin_b && out,
                   "request_branch: null operand");   // col may be NULL when no graph has an edge
-    GNNPN_REQUIRE(n_graphs >= 0 && n_layers >= 1 && nfeat >= 0 && vocab > 0 && emb > 0, "request_branch: bad shape");
     if (hidden != HID || n_layers > MAX_LAYERS || emb + nfeat > 32 || max_nodes > ROWS)
         GNNPN_FAIL(GNNPN_E_UNSUP, "request_branch: built for hidden = %d, <= %d layers, <= 32 input features and graphs of "
                    "<= %d nodes (got hidden %d, %d layers, %d features, %d nodes): use the layered kernels", HID,

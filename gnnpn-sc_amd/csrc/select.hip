@@ -70,9 +70,10 @@ extern "C" int gnnpn_select_candidates(const float* scores, int64_t ld_scores, c
                                        const double* qos, const double* local_bounds, const uint8_t* present,
                                        const double* global_bounds, float* out_rows, int32_t* out_ids, int32_t B,
                                        int32_t T, int32_t n_per, void* stream) {
+    GNNPN_REQUIRE(B >= 0 && T > 0, "select_candidates: bad shape");
+    if (B == 0) return GNNPN_OK;
     GNNPN_REQUIRE(scores && cat_ptr && qos && local_bounds && present && global_bounds && out_rows && out_ids,
                   "select_candidates: null operand");
-    GNNPN_REQUIRE(B >= 0 && T > 0, "select_candidates: bad shape");
     GNNPN_REQUIRE(n_per >= 1 && n_per <= 64, "select_candidates: n_per must be in [1,64], got %d", n_per);
     GNNPN_REQUIRE(gnnpn_aligned(out_rows, 16), "select_candidates: out_rows must be 16-byte aligned");
     if (B == 0) return GNNPN_OK;
@@ -142,8 +143,9 @@ __global__ __launch_bounds__(1024) void rank_rows_indirect_kernel(const float* _
 
 extern "C" int gnnpn_rank_rows(const float* scores, int64_t ld_scores, int32_t* ranking, int32_t B, int32_t S,
                                void* stream) {
-    GNNPN_REQUIRE(scores && ranking, "rank_rows: null operand");
     GNNPN_REQUIRE(B >= 0 && S > 0 && ld_scores >= S, "rank_rows: bad shape");
+    if (B == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(scores && ranking, "rank_rows: null operand");
     if (S > 32768) GNNPN_FAIL(GNNPN_E_UNSUP, "rank_rows: S=%d exceeds the single-workgroup LDS sort (32768)", S);
     if (B == 0) return GNNPN_OK;
     int P = 2;
@@ -184,9 +186,9 @@ __global__ void precision_at_k_kernel(const int32_t* __restrict__ ranking, int64
 
 extern "C" int gnnpn_precision_at_k(const int32_t* ranking, int64_t ld_rank, const float* labels, int64_t ld_lab,
                                     int32_t B, int32_t S, const int32_t* ks, int32_t n_k, float* out, void* stream) {
-    GNNPN_REQUIRE(ranking && labels && ks && out, "precision_at_k: null operand");
     GNNPN_REQUIRE(B >= 0 && S > 0 && n_k > 0 && ld_rank >= 1 && ld_lab >= S, "precision_at_k: bad shape");
     if (B == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(ranking && labels && ks && out, "precision_at_k: null operand");
     hipLaunchKernelGGL(precision_at_k_kernel, dim3((B * n_k + 127) / 128), dim3(128), 0, (hipStream_t)stream, ranking,
                        ld_rank, labels, ld_lab, B, S, ks, n_k, out);
     GNNPN_CHECK_LAUNCH("precision_at_k");

@@ -363,3 +363,29 @@ def test_gcn_layer_against_dense_fp64_formula(dev):
     xw = ops.linear(x.to(dev), W.t().contiguous().to(dev))
     got = ops.csr_aggregate(csr.rowptr, csr.col, norm, xw, bias=b.to(dev))
     assert float((got.double().cpu() - want).abs().max()) < 5e-5
+
+
+def test_empty_inputs_everywhere(dev):
+    """Zero rows / zero problems / zero edges through every op of the path: empty outputs of the right shape, no launch
+    error, nothing written out of bounds."""
+    ops = _ops()
+    from gnnpn_sc_amd import graph
+    z = lambda *s: torch.zeros(s, device=dev)   # noqa: E731
+    assert ops.linear(z(0, 8), torch.rand(5, 8, device=dev), torch.rand(5, device=dev)).shape == (0, 5)
+    assert ops.embed_concat(z(0, 7), torch.rand(100, 20, device=dev)).shape == (0, 26)
+    assert ops.rank_rows(z(0, 9)).shape == (0, 9)
+    assert ops.qos_reward(z(0, 4, 8), "High").shape == (0,)
+    # a graph without edges: the aggregate is the self term only
+    x = torch.rand(6, 12, device=dev)
+    csr = graph.csr_by_destination(torch.zeros((2, 0), dtype=torch.long, device=dev), 6)
+    eps = torch.tensor([0.25], device=dev)
+    y = ops.csr_aggregate(csr.rowptr, csr.col, None, x, self_coef=eps)
+    assert torch.allclose(y, 1.25 * x, rtol=0, atol=1e-6)
+    assert ops.segment_mean(torch.tensor([0, 0, 6], dtype=torch.int32, device=dev), x).shape == (2, 12)   # an empty segment -> zeros
+    assert float(ops.segment_mean(torch.tensor([0, 0, 6], dtype=torch.int32, device=dev), x)[0].abs().max()) == 0.0
+    H = 256
+    net = {"inputs": z(0, 7, 8), "w_in": torch.rand(4 * H, 8, device=dev), "b_in": torch.rand(4 * H, device=dev),
+           "whh": ops.pack_lstm_weight(torch.rand(4 * H, H) / 16).to(dev), "bhh": torch.rand(4 * H, device=dev)}
+    enc, h_n, c_n = ops.lstm_encode([net])
+    assert enc[0].shape == (0, 7, H) and h_n[0].shape == (0, H)
+    ops.check_status(dev)

@@ -458,3 +458,31 @@ def test_sampling_mode_forward_golden(dev, name):
             counts[int(o["idx_high"][0, 0])] += 1
         want = torch.softmax((greedy["win_high_raw"] + greedy["win_low"])[0, 0].cpu(), 0)
         assert float((counts / 300 - want).abs().max()) < 0.12
+
+
+def test_empty_and_degenerate_shapes(dev):
+    """Edge shapes of the decode path: an EMPTY batch (every entry point returns empty outputs, no launch), one problem,
+    one category, windows of one candidate (K = 1: the pick is forced, margin = +inf in the oracle)."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
+    H = 256
+    for T, K, B in ((5, 3, 0), (1, 4, 3), (6, 1, 5), (1, 1, 1)):
+        nets = []
+        for level, seed in (("Low", 1), ("High", 2)):
+            m = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, level=level)
+            m.load_state_dict(opn.make_state_dict(H, seed), strict=True)
+            nets.append(m.to(dev).eval())
+        x = torch.rand(B, T * K, 8, generator=torch.Generator().manual_seed(T * 10 + K)).to(dev)
+        out = two_level_greedy(nets[0], nets[1], x)
+        ops.check_status(dev)
+        assert out["idx_high"].shape == (B, T) and out["R"].shape == (B,) and out["actions"].shape == (B, T, 8)
+        if B:
+            ref = opn.two_level_greedy(opn.make_state_dict(H, 1), opn.make_state_dict(H, 2), x.cpu(), T, K)
+            rec = prefix_parity(out["idx_low"], out["idx_high"], ref, f"edge/T{T}K{K}B{B}", rows=x.cpu())
+            s = rec["same_mask"]
+            assert_R_parity(out["R"], ref["R"], "edge", mask=s)
+            if K == 1:
+                assert s.all() and torch.equal(out["idx_high"].cpu().long(), torch.arange(T).expand(B, T))
+        # the reference-style call on the same shape
+        R, probs, actions, idxs, _ = nets[1](x, None, nets[0](x, None, sample="greedy", training="SL")[4], sample="greedy")
+        assert R.shape == (B,) and len(idxs) == T and idxs[0].shape == (B,)
