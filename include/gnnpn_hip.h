@@ -11,6 +11,8 @@
  *   - float = IEEE fp32, indices = int32 unless stated; row-major everywhere;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
  *     on it and the call returns without synchronising;
+ *   - a zero-sized batch (B, M, n_rows, n_graphs ... = 0) is valid: the call returns 0 at once, launches nothing,
+ *     and the buffers of that batch may be NULL (what an empty torch tensor's data_ptr() is);
  *   - return 0 on success, a negative GNNPN_E_* code on failure (nothing was enqueued);
  *     gnnpn_last_error() returns a thread-local message for the last failure.
  *   - no internal host threads, no hidden allocation: workspaces are explicit arguments.
