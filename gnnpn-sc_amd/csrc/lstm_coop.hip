@@ -40,20 +40,28 @@ constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 pari
 // Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
 // growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
 // a hint when to sweep again, validity is still decided by the granules' own tags.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two adjacent granules with one 16-byte load.  Every granule is written by ONE aligned 8-byte store, and a load of any
+// width reads its cache line at one instant, so each 8-byte half is still seen whole — tag and value of a half always
+// belong together (the two halves may come from different publishes, which is why each carries its own tag).
+__device__ __forceinline__ void granule_load2_issue(u32x4& v, const u64* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+
 template <int PREC>
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
                                               int wave, int lane, bool keep, bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
-    unsigned v[16];
+    u32x4 v[8];                                              // granules 2*(64 j + lane), +1: {value, tag, value, tag}
     unsigned spins = 0;
     for (;;) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) granule_load2_issue(v[j], src + 2 * (j * 64 + lane));
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u64 x = granule_load(src + j * 64 + lane);
-            v[j] = (unsigned)x;
-            ok &= (unsigned)(x >> 32) == tag;
-        }
+        for (int j = 0; j < 8; ++j) ok &= (v[j].y == tag) & (v[j].w == tag);
         if (__all(ok) || nowait) break;
         int nap = 1;
         for (;;) {                                           // wait for the hint
@@ -68,14 +76,20 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentine
     }
     if (keep) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i = j * 64 + lane;            // 0..1023 within the quarter
+        for (int j = 0; j < 8; ++j) {
+            const int i = 2 * (j * 64 + lane);      // 0..1022 (even) within the quarter; i and i+1 share a row
             if constexpr (PREC == 0) {
-                hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(v[j]);
+                *reinterpret_cast<float2*>(&hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)]) =
+                    make_float2(__uint_as_float(v[j].x), __uint_as_float(v[j].z));
             } else {
                 _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
-                if constexpr (PREC == 2) split_store(h16, __uint_as_float(v[j]));
-                else h16[0] = (_Float16)__uint_as_float(v[j]);
+                if constexpr (PREC == 2) {
+                    split_store(h16, __uint_as_float(v[j].x));
+                    split_store(h16 + 1, __uint_as_float(v[j].z));
+                } else {
+                    h16[0] = (_Float16)__uint_as_float(v[j].x);
+                    h16[1] = (_Float16)__uint_as_float(v[j].z);
+                }
             }
         }
     }
