@@ -14,6 +14,14 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
                        __HIP_MEMORY_SCOPE_AGENT);                                // global_store_dwordx2 sc1
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two adjacent granules with one 16-byte load.  Every granule is written by ONE aligned 8-byte store, and a load of any
+// width reads its cache line at one instant, so each 8-byte half is still seen whole — tag and value of a half always
+// belong together (the two halves may come from different publishes, which is why each carries its own tag).
+__device__ __forceinline__ void granule_load2_issue(u32x4& v, const u64* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+
 // A failed bounded wait: the launch's own status word (zeroed by every launch) and the caller's sticky word
 // (never cleared by the library), see gnnpn_launch_opts_t.sticky_status.
 __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsigned code) {

@@ -186,29 +186,34 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     const int n_p = G * 4 * K;            // this wave's rows 4w..4w+3 from all members
                     const int n_l = 4 * K;
                     constexpr int NPJ = EVH_ == 2 ? 4 : 8;   // partial-dot granules per lane: G*4*K / 64, K <= 8 in the EVH_ = 2 builds
-                    unsigned vh[16], vp[NPJ], vl = 0;
+                    constexpr int NPJ2 = NPJ / 2;            // 16-byte loads: two adjacent granules each (coop_common.h)
+                    u32x4 vh[8], vp[NPJ2];
+                    unsigned vl = 0;
                     bool ok = false;
                     for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
                         bool good = true;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const u64 x = granule_load(src_h + j * 64 + lane);
-                            vh[j] = (unsigned)x;
-                            good &= (unsigned)(x >> 32) == tag;
-                        }
+                        for (int j = 0; j < 8; ++j) granule_load2_issue(vh[j], src_h + 2 * (j * 64 + lane));
 #pragma unroll
-                        for (int j = 0; j < NPJ; ++j) {
-                            if (lane + 64 * j < n_p) {
-                                const u64 x = granule_load(src_p + lane + 64 * j);
-                                vp[j] = (unsigned)x;
-                                good &= (unsigned)(x >> 32) == tag;
-                            }
+                        for (int j = 0; j < NPJ2; ++j) {
+                            vp[j] = u32x4{0u, tag, 0u, tag};
+                            if (2 * (lane + 64 * j) < n_p) granule_load2_issue(vp[j], src_p + 2 * (lane + 64 * j));   // n_p is even
                         }
                         if (latent_in_launch && lane < n_l) {
                             const u64 x = granule_load(src_l + lane);
                             vl = (unsigned)x;
                             good &= (unsigned)(x >> 32) == 1u;
                         }
+                        if constexpr (NPJ2 == 2)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]), "+v"(vh[4]), "+v"(vh[5]),
+                                         "+v"(vh[6]), "+v"(vh[7]), "+v"(vp[0]), "+v"(vp[1])::"memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]), "+v"(vh[4]), "+v"(vh[5]),
+                                         "+v"(vh[6]), "+v"(vh[7]), "+v"(vp[0]), "+v"(vp[1]), "+v"(vp[2]), "+v"(vp[3])::"memory");
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) good &= (vh[j].y == tag) & (vh[j].w == tag);
+#pragma unroll
+                        for (int j = 0; j < NPJ2; ++j) good &= (vp[j].y == tag) & (vp[j].w == tag);
                         if (__all(good)) {
                             ok = true;
                             break;
@@ -217,16 +222,22 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     }
                     if (!ok) abort_flag = 1;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int i = j * 64 + lane;
-                        if constexpr (SPLIT)
-                            split_store(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), __uint_as_float(vh[j]));
-                        else
-                            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 2 * (j * 64 + lane);          // even: i and i + 1 share a row
+                        if constexpr (SPLIT) {
+                            _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
+                            split_store(h16, __uint_as_float(vh[j].x));
+                            split_store(h16 + 1, __uint_as_float(vh[j].z));
+                        } else {
+                            *reinterpret_cast<float2*>(&hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)]) =
+                                make_float2(__uint_as_float(vh[j].x), __uint_as_float(vh[j].z));
+                        }
                     }
 #pragma unroll
-                    for (int j = 0; j < NPJ; ++j) {
-                        if (lane + 64 * j < n_p) part_lin[wave][lane + 64 * j] = __uint_as_float(vp[j]);
+                    for (int j = 0; j < NPJ2; ++j) {
+                        if (2 * (lane + 64 * j) < n_p)
+                            *reinterpret_cast<float2*>(&part_lin[wave][2 * (lane + 64 * j)]) =
+                                make_float2(__uint_as_float(vp[j].x), __uint_as_float(vp[j].z));
                     }
                     if (lane < n_l) {
                         float lv = 0.0f;

@@ -40,14 +40,6 @@ constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 pari
 // Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
 // growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
 // a hint when to sweep again, validity is still decided by the granules' own tags.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// two adjacent granules with one 16-byte load.  Every granule is written by ONE aligned 8-byte store, and a load of any
-// width reads its cache line at one instant, so each 8-byte half is still seen whole — tag and value of a half always
-// belong together (the two halves may come from different publishes, which is why each carries its own tag).
-__device__ __forceinline__ void granule_load2_issue(u32x4& v, const u64* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-}
-
 template <int PREC>
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
                                               int wave, int lane, bool keep, bool nowait = false) {
