@@ -15,11 +15,55 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// two adjacent granules with one 16-byte load.  Every granule is written by ONE aligned 8-byte store, and a load of any
+// Two adjacent granules with one 16-byte load.  Every granule is written by ONE aligned 8-byte store, and a load of any
 // width reads its cache line at one instant, so each 8-byte half is still seen whole — tag and value of a half always
 // belong together (the two halves may come from different publishes, which is why each carries its own tag).
-__device__ __forceinline__ void granule_load2_issue(u32x4& v, const u64* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+// The loads of a sweep and the wait for them are ONE asm statement: the compiler knows nothing about the asynchronous
+// register writes of a hand-written load, and a spill or a copy of a destination register placed between the issue and
+// the s_waitcnt would save garbage (seen: a 12-byte spill there made a wave wait for tags it had already been sent).
+// Pair j of the lane is at p + 128 j granules (1 KB apart: its row quarter is 64 lanes x 16 B per pair index).
+#define GNNPN_LD2(dst, base, off) "global_load_dwordx4 " dst ", " base ", off offset:" off " sc1\n\t"
+__device__ __forceinline__ void granule_load2_x8(u32x4 (&v)[8], const u64* p) {
+    const u64* q = p + 512;                                  // + 4 KB: the 13-bit immediate reaches 4095
+    asm volatile(GNNPN_LD2("%0", "%8", "0") GNNPN_LD2("%1", "%8", "1024") GNNPN_LD2("%2", "%8", "2048") GNNPN_LD2("%3", "%8", "3072")
+                 GNNPN_LD2("%4", "%9", "0") GNNPN_LD2("%5", "%9", "1024") GNNPN_LD2("%6", "%9", "2048") GNNPN_LD2("%7", "%9", "3072")
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p), "v"(q)
+                 : "memory");
+}
+// the same for the lanes that still miss something (call under `if (lane_is_missing)`): the others keep what they have
+__device__ __forceinline__ void granule_reload2_x8(u32x4 (&v)[8], const u64* p) {
+    const u64* q = p + 512;
+    asm volatile(GNNPN_LD2("%0", "%8", "0") GNNPN_LD2("%1", "%8", "1024") GNNPN_LD2("%2", "%8", "2048") GNNPN_LD2("%3", "%8", "3072")
+                 GNNPN_LD2("%4", "%9", "0") GNNPN_LD2("%5", "%9", "1024") GNNPN_LD2("%6", "%9", "2048") GNNPN_LD2("%7", "%9", "3072")
+                 "s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "v"(p), "v"(q)
+                 : "memory");
+}
+// 8 pairs at p (h quarter) and NP pairs at r (partial dots), one wait
+__device__ __forceinline__ void granule_load2_x8_x2(u32x4 (&v)[8], u32x4 (&w)[2], const u64* p, const u64* r) {
+    const u64* q = p + 512;
+    asm volatile(GNNPN_LD2("%0", "%10", "0") GNNPN_LD2("%1", "%10", "1024") GNNPN_LD2("%2", "%10", "2048") GNNPN_LD2("%3", "%10", "3072")
+                 GNNPN_LD2("%4", "%11", "0") GNNPN_LD2("%5", "%11", "1024") GNNPN_LD2("%6", "%11", "2048") GNNPN_LD2("%7", "%11", "3072")
+                 GNNPN_LD2("%8", "%12", "0") GNNPN_LD2("%9", "%12", "1024")
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(w[0]), "=&v"(w[1])
+                 : "v"(p), "v"(q), "v"(r)
+                 : "memory");
+}
+__device__ __forceinline__ void granule_load2_x8_x4(u32x4 (&v)[8], u32x4 (&w)[4], const u64* p, const u64* r) {
+    const u64* q = p + 512;
+    asm volatile(GNNPN_LD2("%0", "%12", "0") GNNPN_LD2("%1", "%12", "1024") GNNPN_LD2("%2", "%12", "2048") GNNPN_LD2("%3", "%12", "3072")
+                 GNNPN_LD2("%4", "%13", "0") GNNPN_LD2("%5", "%13", "1024") GNNPN_LD2("%6", "%13", "2048") GNNPN_LD2("%7", "%13", "3072")
+                 GNNPN_LD2("%8", "%14", "0") GNNPN_LD2("%9", "%14", "1024") GNNPN_LD2("%10", "%14", "2048") GNNPN_LD2("%11", "%14", "3072")
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(p), "v"(q), "v"(r)
+                 : "memory");
 }
 
 // A failed bounded wait: the launch's own status word (zeroed by every launch) and the caller's sticky word
@@ -48,6 +92,7 @@ constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1
 constexpr int COOP_XCDCNT_OFFSET = 1024;
 constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;
+constexpr int COOP_OVERREAD_BYTES = 4096;    // slack at the end of the decoder workspace: fixed-shape 16-byte sweeps may read (never use) that far past their data
 constexpr int COOP_OVERSUB = 3;              // launched workgroups per needed workgroup
 constexpr unsigned COOP_SURPLUS_WAIT_TICKS = 1600;   // 16 us of s_memrealtime (100 MHz): how long an early surplus workgroup keeps its slot
 constexpr unsigned COOP_RESERVE_WAIT_TICKS = 200000; // 2 ms: how long the reserve (the last arrivals) waits before it takes the open seats

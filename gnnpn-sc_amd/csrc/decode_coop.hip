@@ -192,28 +192,20 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     bool ok = false;
                     for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
                         bool good = true;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) granule_load2_issue(vh[j], src_h + 2 * (j * 64 + lane));
-#pragma unroll
-                        for (int j = 0; j < NPJ2; ++j) {
-                            vp[j] = u32x4{0u, tag, 0u, tag};
-                            if (2 * (lane + 64 * j) < n_p) granule_load2_issue(vp[j], src_p + 2 * (lane + 64 * j));   // n_p is even
-                        }
+                        // pairs of this lane beyond n_p (K < 8 / K < 16) are loaded and never looked at: they lie at most
+                        // 4 KB past this wave's segment, inside the workspace (COOP_OVERREAD_BYTES of slack at its end)
+                        if constexpr (NPJ2 == 2) granule_load2_x8_x2(vh, vp, src_h + 2 * lane, src_p + 2 * lane);
+                        else granule_load2_x8_x4(vh, vp, src_h + 2 * lane, src_p + 2 * lane);
                         if (latent_in_launch && lane < n_l) {
                             const u64 x = granule_load(src_l + lane);
                             vl = (unsigned)x;
                             good &= (unsigned)(x >> 32) == 1u;
                         }
-                        if constexpr (NPJ2 == 2)
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]), "+v"(vh[4]), "+v"(vh[5]),
-                                         "+v"(vh[6]), "+v"(vh[7]), "+v"(vp[0]), "+v"(vp[1])::"memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]), "+v"(vh[4]), "+v"(vh[5]),
-                                         "+v"(vh[6]), "+v"(vh[7]), "+v"(vp[0]), "+v"(vp[1]), "+v"(vp[2]), "+v"(vp[3])::"memory");
 #pragma unroll
                         for (int j = 0; j < 8; ++j) good &= (vh[j].y == tag) & (vh[j].w == tag);
 #pragma unroll
-                        for (int j = 0; j < NPJ2; ++j) good &= (vp[j].y == tag) & (vp[j].w == tag);
+                        for (int j = 0; j < NPJ2; ++j)
+                            if (2 * (lane + 64 * j) < n_p) good &= (vp[j].y == tag) & (vp[j].w == tag);
                         if (__all(good)) {
                             ok = true;
                             break;
@@ -525,7 +517,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
     const int64_t groups = 64, tiles = (B + ROWS - 1) / ROWS;
     const int64_t a8 = COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
-                       tiles * T * ROWS * (int64_t)n_per * 8;
+                       tiles * T * ROWS * (int64_t)n_per * 8 + COOP_OVERREAD_BYTES;
     const int64_t a16 = gnnpn_decode_coop2_workspace_bytes(B, T, n_per);
     return a8 > a16 ? a8 : a16;
 }
@@ -565,7 +557,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     const int64_t h_bytes = (int64_t)groups * 2 * ROWS * H * 8;
     const int64_t p_bytes = (int64_t)groups * 2 * G * ROWS * args.K * 8;
     const int64_t l_bytes = (int64_t)n_tiles * args.T * ROWS * args.K * 8;
-    const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes;
+    const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes + COOP_OVERREAD_BYTES;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
     if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)

@@ -29,42 +29,33 @@ constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
-constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + sentinels
+constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + 64 spare
 }  // namespace
 
 // Sweep this wave's quarter (rows 4w..4w+3, all 256 units) of one parity buffer until every
-// granule carries `tag`; values go to LDS.  Returns false on timeout.
-// The first pass is optimistic (peers run in lock step, so it normally succeeds).  If it does not,
-// the wave does NOT keep re-reading its 1024 granules — with two launches sharing the CUs that
-// polling traffic (8 KB per wave per pass) swamps the L2 and slows the very peers it waits for.
-// Instead it polls the 32 per-wave SENTINEL words of the group (one 8-byte load per lane < 32, with a
-// growing s_sleep) that each publishing wave bumps after its granule stores; the sentinels are only
-// a hint when to sweep again, validity is still decided by the granules' own tags.
+// granule carries `tag`; values go to LDS.  Returns false on timeout.  Eight 16-byte loads per lane (two granules each).
 template <int PREC>
-__device__ __forceinline__ bool sweep_quarter(const u64* buf, const u64* sentinels, unsigned tag, float* hs,
-                                              int wave, int lane, bool keep, bool nowait = false) {
+__device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, float* hs, int wave, int lane, bool keep,
+                                              bool nowait = false) {
     const u64* src = buf + wave * 4 * H;
     u32x4 v[8];                                              // granules 2*(64 j + lane), +1: {value, tag, value, tag}
+    granule_load2_x8(v, src + 2 * lane);
+    bool bad = false;                                        // this lane is still missing a tag
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
+    // The first pass is optimistic (peers run in lock step, so it normally succeeds).  If it does not, only the LANES that
+    // miss something re-read (a late member's 32 units sit in 16 lanes of the wave), between naps — not the whole quarter
+    // (with two launches sharing the CUs, full re-sweeps swamp the L2 and slow the very peers it waits for).
     unsigned spins = 0;
-    for (;;) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) granule_load2_issue(v[j], src + 2 * (j * 64 + lane));
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ok &= (v[j].y == tag) & (v[j].w == tag);
-        if (__all(ok) || nowait) break;
-        int nap = 1;
-        for (;;) {                                           // wait for the hint
-            bool seen = true;
-            if (lane < 4 * G) seen = (unsigned)(granule_load(sentinels + lane) >> 32) >= tag;
-            if (__all(seen)) break;
-            if (++spins > SPIN_LIMIT) return false;
-            for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
-            if (nap < 16) nap <<= 1;
-        }
+    int nap = 1;
+    while (__any(bad) && !nowait) {
         if (++spins > SPIN_LIMIT) return false;
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+        if (nap < 16) nap <<= 1;
+        if (bad) granule_reload2_x8(v, src + 2 * lane);
+        bad = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
     }
     if (keep) {
 #pragma unroll
@@ -129,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     const float* __restrict__ Wp = nets.whh[net];
     float* __restrict__ enc = nets.enc_out[net];
     u64* xg = xchg + (size_t)group * GROUP_GRANULES;
-    u64* sent = xg + 2 * ROWS * H;                        // [parity][4*G] sentinels
 
     // this lane's two gate columns: tile 0 = [i | f], tile 1 = [g | o], 8 units per wave
     const int unit = member * UNITS + wave * 8 + (c & 7);
@@ -209,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             bool ok = true;
             if (t == 0) {
                 for (int i = threadIdx.x; i < ROWS * LDH16; i += 256) hs[i] = 0.0f;
-                if (!first_tile) ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, false);
+                if (!first_tile) ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
             } else if (!(ablate & 8)) {
-                ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), sent + ((step - 1) & 1) * (4 * G), step, hs, wave, lane, true, ablate & 4);
+                ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
             if (stamps) s1 = phase_stamp();
@@ -301,8 +291,6 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                 hst[r0][wave * 8 + (c & 7)] = hlast.x;
                 hst[r0 + 1][wave * 8 + (c & 7)] = hlast.y;
             }
-            if (lane == 0 && !(ablate & 16))                    // hint for waiting peers (see sweep_quarter)
-                granule_publish(sent + (step & 1) * (4 * G) + member * 4 + wave, step + 1, 0.0f, same_xcd);
             if (stamps) {
                 asm volatile("" ::"v"(hlast.y));
                 s5 = phase_stamp();
