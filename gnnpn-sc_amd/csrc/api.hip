@@ -1,5 +1,6 @@
 #include "common.h"
 #include <string.h>
+#include <mutex>
 #include "lstm_shared.h"
 #include "decode_shared.h"
 
@@ -12,6 +13,28 @@ extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 // per-call arguments (gnnpn_launch_opts_t): nothing that selects a kernel build is process-wide state.
 static int g_lstm_ablate = 0;
 int gnnpn_option_lstm_ablate() { return g_lstm_ablate; }
+
+// ---- canonical seats of the cooperative kernels (coop_common.h::coop_place): one table per device, [8 XCDs][256 CU keys]
+// seat + 1 of every CU that has ever hosted a cooperative workgroup, then the 8 per-XCD counters that hand the seats out.
+// Filled by the kernels themselves (first come, first seated), never reset: every later launch of the process puts the
+// SAME CU in the SAME seat, so the groups of two launches that share the chip share their CUs group by group.
+// Created on the first call for a device — which the workspace-size queries make, i.e. before any launch and outside any
+// stream capture (allocation and synchronisation are not capturable).
+unsigned* gnnpn_cu_seat_table() {
+    static unsigned* table[64] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!table[dev]) {
+        unsigned* p = nullptr;
+        if (hipMalloc(&p, COOP_SEAT_TABLE_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, COOP_SEAT_TABLE_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;      // before any stream's first cooperative kernel reads it
+        table[dev] = p;
+    }
+    return table[dev];
+}
 
 extern "C" int gnnpn_set_option(const char* name, int value) {
     if (!name) GNNPN_FAIL(GNNPN_E_ARG, "set_option: null name");

@@ -92,6 +92,7 @@ constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1
 constexpr int COOP_XCDCNT_OFFSET = 1024;
 constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;
+constexpr int COOP_TAKEN_OFFSET = 10240;     // [10240,12288) per-XCD seat flags (64 per XCD)
 constexpr int COOP_OVERREAD_BYTES = 4096;    // slack at the end of the decoder workspace: fixed-shape 16-byte sweeps may read (never use) that far past their data
 constexpr int COOP_OVERSUB = 3;              // launched workgroups per needed workgroup
 constexpr unsigned COOP_SURPLUS_WAIT_TICKS = 1600;   // 16 us of s_memrealtime (100 MHz): how long an early surplus workgroup keeps its slot
@@ -142,9 +143,17 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 
 // Called by every thread of the workgroup.  false: surplus workgroup (leave at once).  `slot` is two ints of LDS.
 //
+// Seats are CANONICAL: the first cooperative launch of the process that reaches a CU writes that CU's seat (the next
+// free number of its XCD) into a per-device table (`seats`, api.hip) and every later launch puts the same CU in the same
+// seat.  The groups of two launches that share the chip (PipelinedRunner's two slots) then share their CUs group by
+// group: all 8 members of a group see the same partner group, i.e. the same contention at the same moment, instead of
+// eight partners in eight different phases — measured: the time a group waits for its slowest member falls from 6.7 %
+// to 4.8 % of the two-slot step, 278.4 k -> 284.0 k problems/s (Normal B=1024: 145.4 k -> 150.8 k).
+//
 // Workgroup ids go round-robin over the XCDs, so each XCD receives per_xcd = gridDim.x / 8 = COOP_OVERSUB * target
 // workgroups of the launch and needs `target` of them seated.  Every arrival takes an arrival index a (per XCD):
-//   * first workgroup of the launch on its CU, seat open  -> seated (member k % G of the XCD's group k / G);
+//   * first workgroup of the launch on its CU, the CU's canonical seat s below `target` -> seated (member s % G of the
+//     XCD's group s / G);
 //   * otherwise it is surplus, and what it does with its CU slot decides whether the launch gets staffed:
 //     - the early ones (a < per_xcd - target) keep the slot for up to 16 us, or until staffing completes, and exit: while
 //       one sits there the dispatcher can only place the launch's next workgroups on CUs that still have room — the
@@ -153,18 +162,19 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 //     - the LAST `target` arrivals of the XCD are the reserve and are not burned: they keep their slots until staffing
 //       completes (at most one of them fits on each claimed CU, so the ones not yet dispatched stay in the dispatcher's
 //       queue — at least as many as there are open seats — and go to the unclaimed CUs when those free up), and after
-//       COOP_RESERVE_WAIT_TICKS (2 ms) they take the open seats themselves, on whatever CU they are: a group with two
-//       members on one CU is slower, not wrong.
+//       COOP_RESERVE_WAIT_TICKS (2 ms) they take the open seats themselves (lowest free seat first), on whatever CU they
+//       are: a group with two members on one CU is slower, not wrong.
 //   Measured need for the reserve: an ordinary kernel of the other stream whose workgroups fill a CU for longer than
 //   ~50 us (the front end at 5000 candidates x 512 problems) outlasted 64 surplus workgroups of 16 us each, the launch
 //   stayed one or two members short on some XCDs and its groups timed out (tools/repro_synth4.sh, record in DESIGN.md).
 template <int G>
-__device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member) {
+__device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned xcc = xcc_id();
         unsigned* count = status + COOP_XCDCNT_OFFSET / 4;
         unsigned* arrive = status + COOP_ARRIVE_OFFSET / 4;
+        unsigned* taken = status + COOP_TAKEN_OFFSET / 4 + xcc * 64;
         const unsigned target = (unsigned)(gpx * G);
         auto staffed = [&]() {
             bool ok = true;
@@ -177,12 +187,26 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
             if (lane == 0) {
                 arrival = atomicAdd(arrive + xcc, 1u);
                 const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-                const unsigned prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + ((xcc << 8) | ((hw >> 8) & 0xffu)), 1u);
+                const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
+                const unsigned prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);
                 if (prev == 0u) {                                // the first workgroup of this launch on this CU
-                    const unsigned k = atomicAdd(count + xcc, 1u);
-                    if (k < target) {
-                        g = (int)xcc * gpx + (int)(k / G);
-                        m = (int)(k % G);
+                    // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch)
+                    unsigned s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (s == 0u) {
+                        if (atomicCAS(seats + key, 0u, 0xffffffffu) == 0u) {
+                            s = atomicAdd(seats + 8 * 256 + xcc, 1u) + 1u;
+                            __hip_atomic_store(seats + key, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            s = 0xffffffffu;
+                        }
+                    }
+                    for (unsigned spin = 0; s == 0xffffffffu && spin < 100000u; ++spin)     // another launch is writing it
+                        s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned seat = s - 1u;
+                    if (seat < target && atomicCAS(taken + seat, 0u, 1u) == 0u) {
+                        atomicAdd(count + xcc, 1u);
+                        g = (int)xcc * gpx + (int)(seat / G);
+                        m = (int)(seat % G);
                     }
                 }
             }
@@ -199,13 +223,15 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                     __builtin_amdgcn_s_sleep(8);
                     done = staffed();
                 }
-                if (!done && reserve) {
-                    if (lane == 0 && __hip_atomic_load(count + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        const unsigned k = atomicAdd(count + xcc, 1u);
-                        if (k < target) {
-                            g = (int)xcc * gpx + (int)(k / G);
-                            m = (int)(k % G);
-                            atomicAdd(status + 2, 1u);           // statistics: seats taken on an already claimed CU
+                if (!done && reserve) {                          // take an open seat, whichever CU this is
+                    if (lane == 0) {
+                        for (unsigned seat = 0; seat < target && g < 0; ++seat) {
+                            if (atomicCAS(taken + seat, 0u, 1u) == 0u) {
+                                atomicAdd(count + xcc, 1u);
+                                g = (int)xcc * gpx + (int)(seat / G);
+                                m = (int)(seat % G);
+                                atomicAdd(status + 2, 1u);       // statistics: seats taken off the canonical CU
+                            }
                         }
                     }
                     g = __shfl(g, 0, 64);

@@ -80,7 +80,7 @@ template <bool FOLDX, bool DIAG, bool SPLIT, int OCC, int EVH_ = (OCC == 2 ? 2 :
 __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                      u64* __restrict__ xp, u64* __restrict__ xl,
                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
-                                                                     int n_nets, int groups_per_net, int gpx, int ablate_arg) {
+                                                                     int n_nets, int groups_per_net, int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     const int kq = lane >> 4, c = lane & 15;
     __shared__ int place[2];
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
+    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 }
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
+    (void)gnnpn_cu_seat_table();   // callers size their workspace before the first launch and outside any capture: create the seat table here
     const int64_t groups = 64, tiles = (B + ROWS - 1) / ROWS;
     const int64_t a8 = COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
                        tiles * T * ROWS * (int64_t)n_per * 8 + COOP_OVERREAD_BYTES;
@@ -562,6 +563,8 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
     if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
+    unsigned* p_seats = gnnpn_cu_seat_table();
+    if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "%s: cannot allocate the seat table", "pointer_decode");
     char* base = static_cast<char*>(workspace);
     u64* p_h = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES);
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
@@ -576,7 +579,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
 #define GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, EVH_)                                                                   \
     hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(COOP_OVERSUB * groups * G), dim3(256),     \
                        coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
-                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl)
+                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl, p_seats)
 #define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
     bool any_sample = false;
     for (int n = 0; n < n_nets; ++n) any_sample |= args.net[n].sample != 0;
@@ -585,7 +588,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
             GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the sampling build exists for the folded fp32 input side only");
         hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false, 1, 1, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),
                            coop_lds_padding((const void*)pointer_decode_coop_kernel<true, false, false, 1, 1, true>, lds_kb), s,
-                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl);
+                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl, p_seats);
         return GNNPN_OK;
     }
     if (shared_cu && (!fold || (abl & 32)))

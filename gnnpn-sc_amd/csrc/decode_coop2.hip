@@ -41,7 +41,7 @@ template <int NP, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                       u64* __restrict__ xp, u64* __restrict__ xl,
                                                                       unsigned* __restrict__ err, unsigned* __restrict__ sticky,
-                                                                      int n_nets, int groups_per_net, int gpx, int ablate) {
+                                                                      int n_nets, int groups_per_net, int gpx, int ablate, unsigned* __restrict__ seats) {
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, c = lane & 15, gate = c >> 2;
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
+    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];
@@ -370,6 +370,8 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256)) return GNNPN_E_UNSUP;
     if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess) return GNNPN_E_UNSUP;
+    unsigned* p_seats = gnnpn_cu_seat_table();
+    if (!p_seats) return GNNPN_E_UNSUP;
     char* base = static_cast<char*>(workspace);
     u64* p_h = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES);
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
@@ -384,11 +386,11 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
         if (split)                                                                                               \
             hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),           \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, true>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl, p_seats);                                 \
         else                                                                                                     \
             hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(COOP_OVERSUB * groups * G), dim3(256),          \
                                coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, false>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl);                                 \
+                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl, p_seats);                                 \
     } while (0)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);

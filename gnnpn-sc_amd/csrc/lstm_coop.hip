@@ -95,7 +95,7 @@ template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                   int32_t B, int32_t L, int n_nets, int groups_per_net,
-                                                                  int gpx, int ablate_arg) {
+                                                                  int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
     __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi tile + lo tile (stride LDH16 halfs)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     // placement by claim (coop_common.h): one member per CU, a group's members on one XCD
     __shared__ int place[2];
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member)) return;   // surplus workgroup of the over-subscribed launch
+    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
 // workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
 // stamps, hello granules), then the exchange buffers
 extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
+    (void)gnnpn_cu_seat_table();   // callers size their workspace before the first launch and outside any capture: create the seat table here
     return COOP_STATUS_BYTES + (int64_t)64 * GROUP_GRANULES * sizeof(u64);   // up to 64 groups
 }
 
@@ -354,6 +355,8 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     // zero the status word and every tag before each launch (tags start at 1)
     if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
+    unsigned* p_seats = gnnpn_cu_seat_table();
+    if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "%s: cannot allocate the seat table", "lstm_encode");
     u64* p_x = reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES);
     unsigned* p_e = reinterpret_cast<unsigned*>(workspace);
     bool pre = nets.pregates[0] != nullptr;
@@ -367,7 +370,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(COOP_OVERSUB * groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
-                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl)
+                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl, p_seats)
     if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
         if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
         GNNPN_ENC(0, false, true);

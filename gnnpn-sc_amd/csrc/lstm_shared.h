@@ -36,4 +36,6 @@ inline CoopOpts coop_opts(const gnnpn_launch_opts_t* o) {
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, const CoopOpts& opts,
                              void* workspace, int64_t workspace_bytes, hipStream_t s);
+constexpr int COOP_SEAT_TABLE_WORDS = 8 * 256 + 8;
+unsigned* gnnpn_cu_seat_table();   // api.hip: the device's canonical CU -> seat table (nullptr: allocation failed)
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero
