@@ -390,6 +390,8 @@ def test_two_slots_whichever_starts_first(dev):
             w = runner.workspaces[s]
             placed = int(w.encode()[4:8].view(torch.int32).item())
             assert placed == 256, placed                         # 32 groups x 8 members, one per CU
+            off_seat = int(w.encode()[8:12].view(torch.int32).item())
+            assert off_seat == 0, off_seat                       # every member on its CU's canonical seat (no reserve take-over)
 
 
 def test_two_slots_beside_long_ordinary_kernels(dev):
