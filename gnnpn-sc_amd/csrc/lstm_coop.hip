@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pg[tl][r] = pg_next[tl][r];
             }
+            // x_t . w_in^T as its own k-ordered chain: issued HERE, in front of the sweep — it depends on nothing of this step,
+            // and the matrix pipe works it off while the sweep's loads are in flight (it used to sit behind the main chain,
+            // ~130 cycles on the critical path in front of the cell update)
+            f32x4 px0 = {0.f, 0.f, 0.f, 0.f}, px1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!PRE) {
+                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[0][0], px0, 0, 0, 0);
+                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[1][0], px1, 0, 0, 0);
+                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[0][1], px0, 0, 0, 0);
+                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[1][1], px1, 0, 0, 0);
+            }
             // h_{t-1}: zeros at t == 0, else the peers' published slices.  At a tile switch the
             // sweep still runs (values dropped): it proves every peer is done with the buffer
             // this member is about to overwrite.
@@ -249,12 +259,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                 asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));   // the MFMA chains have retired
                 s3 = phase_stamp();
             }
-            if constexpr (!PRE) {   // x_t . w_in^T as its own k-ordered chain, then + b_in (as gnnpn_linear_f32 would)
-                f32x4 px0 = {0.f, 0.f, 0.f, 0.f}, px1 = {0.f, 0.f, 0.f, 0.f};
-                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[0][0], px0, 0, 0, 0);
-                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX[1][0], px1, 0, 0, 0);
-                px0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[0][1], px0, 0, 0, 0);
-                px1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX[1][1], px1, 0, 0, 0);
+            if constexpr (!PRE) {   // ... + b_in (as gnnpn_linear_f32 would)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pg[0][r] = __fadd_rn(px0[r], bx[0]);
