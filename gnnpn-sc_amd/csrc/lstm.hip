@@ -116,7 +116,7 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
     const CoopOpts opts = coop_opts(opts_in);
-    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 2, "lstm_encode: opts.impl must be 0 (auto), 1 (streaming) or 2 (cooperative)");
+    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 3, "lstm_encode: opts.impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-member groups) or 3 (cooperative, 16-member groups)");
     GNNPN_REQUIRE(opts.lds_kb >= 0 && opts.lds_kb <= 160, "lstm_encode: opts.lds_kb must be 0..160");
     const int impl = opts.impl;
     const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl >= 2);

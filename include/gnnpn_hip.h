@@ -209,7 +209,8 @@ typedef struct {
 
 /* Per-call launch options of the two recurrent entry points (NULL = all defaults).  They select among
  * implementations of the SAME arithmetic; nothing here is process-wide state.
- *   impl            encoder: 0 auto, 1 per-workgroup streaming, 2 cooperative (8-CU groups)
+ *   impl            encoder: 0 auto, 1 per-workgroup streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups: 168
+ *                   registers per thread, three workgroups per CU; fp32, folded input side; measured slower, opt-in)
  *                   decoder: 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups),
  *                            4 cooperative (8-CU groups, 256-register build that shares a CU with another launch)
  *   lds_kb          LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernel, 0 = none:
