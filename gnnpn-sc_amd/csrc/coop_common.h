@@ -22,47 +22,60 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // register writes of a hand-written load, and a spill or a copy of a destination register placed between the issue and
 // the s_waitcnt would save garbage (seen: a 12-byte spill there made a wave wait for tags it had already been sent).
 // Pair j of the lane is at p + 128 j granules (1 KB apart: its row quarter is 64 lanes x 16 B per pair index).
-#define GNNPN_LD2(dst, base, off) "global_load_dwordx4 " dst ", " base ", off offset:" off " sc1\n\t"
-__device__ __forceinline__ void granule_load2_x8(u32x4 (&v)[8], const u64* p) {
-    const u64* q = p + 512;                                  // + 4 KB: the 13-bit immediate reaches 4095
-    asm volatile(GNNPN_LD2("%0", "%8", "0") GNNPN_LD2("%1", "%8", "1024") GNNPN_LD2("%2", "%8", "2048") GNNPN_LD2("%3", "%8", "3072")
-                 GNNPN_LD2("%4", "%9", "0") GNNPN_LD2("%5", "%9", "1024") GNNPN_LD2("%6", "%9", "2048") GNNPN_LD2("%7", "%9", "3072")
+// The base address of a sweep is uniform over the wave (group, parity and wave index): it travels in SGPRs (`uniform_ptr`)
+// and the lanes add a 32-bit byte offset — one VGPR instead of two 64-bit VGPR pointers, and no 64-bit vector adds per step.
+#define GNNPN_LD2(dst, voff, sbase, off) "global_load_dwordx4 " dst ", " voff ", " sbase " offset:" off " sc1\n\t"
+__device__ __forceinline__ const u64* uniform_ptr(const u64* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const u64*>(((unsigned long long)hi << 32) | lo);
+}
+// pair j of lane l: base + 16 l + 1024 j bytes (`voff` = 16 l)
+__device__ __forceinline__ void granule_load2_x8(u32x4 (&v)[8], const u64* base, unsigned voff) {
+    const u64* q = base + 512;                               // + 4 KB: the 13-bit immediate reaches 4095
+    asm volatile(GNNPN_LD2("%0", "%8", "%9", "0") GNNPN_LD2("%1", "%8", "%9", "1024") GNNPN_LD2("%2", "%8", "%9", "2048")
+                 GNNPN_LD2("%3", "%8", "%9", "3072") GNNPN_LD2("%4", "%8", "%10", "0") GNNPN_LD2("%5", "%8", "%10", "1024")
+                 GNNPN_LD2("%6", "%8", "%10", "2048") GNNPN_LD2("%7", "%8", "%10", "3072")
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(p), "v"(q)
+                 : "v"(voff), "s"(base), "s"(q)
                  : "memory");
 }
 // the same for the lanes that still miss something (call under `if (lane_is_missing)`): the others keep what they have
-__device__ __forceinline__ void granule_reload2_x8(u32x4 (&v)[8], const u64* p) {
-    const u64* q = p + 512;
-    asm volatile(GNNPN_LD2("%0", "%8", "0") GNNPN_LD2("%1", "%8", "1024") GNNPN_LD2("%2", "%8", "2048") GNNPN_LD2("%3", "%8", "3072")
-                 GNNPN_LD2("%4", "%9", "0") GNNPN_LD2("%5", "%9", "1024") GNNPN_LD2("%6", "%9", "2048") GNNPN_LD2("%7", "%9", "3072")
+__device__ __forceinline__ void granule_reload2_x8(u32x4 (&v)[8], const u64* base, unsigned voff) {
+    const u64* q = base + 512;
+    asm volatile(GNNPN_LD2("%0", "%8", "%9", "0") GNNPN_LD2("%1", "%8", "%9", "1024") GNNPN_LD2("%2", "%8", "%9", "2048")
+                 GNNPN_LD2("%3", "%8", "%9", "3072") GNNPN_LD2("%4", "%8", "%10", "0") GNNPN_LD2("%5", "%8", "%10", "1024")
+                 GNNPN_LD2("%6", "%8", "%10", "2048") GNNPN_LD2("%7", "%8", "%10", "3072")
                  "s_waitcnt vmcnt(0)"
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-                 : "v"(p), "v"(q)
+                 : "v"(voff), "s"(base), "s"(q)
                  : "memory");
 }
-// 8 pairs at p (h quarter) and NP pairs at r (partial dots), one wait
-__device__ __forceinline__ void granule_load2_x8_x2(u32x4 (&v)[8], u32x4 (&w)[2], const u64* p, const u64* r) {
-    const u64* q = p + 512;
-    asm volatile(GNNPN_LD2("%0", "%10", "0") GNNPN_LD2("%1", "%10", "1024") GNNPN_LD2("%2", "%10", "2048") GNNPN_LD2("%3", "%10", "3072")
-                 GNNPN_LD2("%4", "%11", "0") GNNPN_LD2("%5", "%11", "1024") GNNPN_LD2("%6", "%11", "2048") GNNPN_LD2("%7", "%11", "3072")
-                 GNNPN_LD2("%8", "%12", "0") GNNPN_LD2("%9", "%12", "1024")
+// 8 pairs at `base` (h quarter) and NP pairs at `pbase` (partial dots), one wait
+__device__ __forceinline__ void granule_load2_x8_x2(u32x4 (&v)[8], u32x4 (&w)[2], const u64* base, const u64* pbase, unsigned voff) {
+    const u64* q = base + 512;
+    asm volatile(GNNPN_LD2("%0", "%10", "%11", "0") GNNPN_LD2("%1", "%10", "%11", "1024") GNNPN_LD2("%2", "%10", "%11", "2048")
+                 GNNPN_LD2("%3", "%10", "%11", "3072") GNNPN_LD2("%4", "%10", "%12", "0") GNNPN_LD2("%5", "%10", "%12", "1024")
+                 GNNPN_LD2("%6", "%10", "%12", "2048") GNNPN_LD2("%7", "%10", "%12", "3072")
+                 GNNPN_LD2("%8", "%10", "%13", "0") GNNPN_LD2("%9", "%10", "%13", "1024")
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
                    "=&v"(w[0]), "=&v"(w[1])
-                 : "v"(p), "v"(q), "v"(r)
+                 : "v"(voff), "s"(base), "s"(q), "s"(pbase)
                  : "memory");
 }
-__device__ __forceinline__ void granule_load2_x8_x4(u32x4 (&v)[8], u32x4 (&w)[4], const u64* p, const u64* r) {
-    const u64* q = p + 512;
-    asm volatile(GNNPN_LD2("%0", "%12", "0") GNNPN_LD2("%1", "%12", "1024") GNNPN_LD2("%2", "%12", "2048") GNNPN_LD2("%3", "%12", "3072")
-                 GNNPN_LD2("%4", "%13", "0") GNNPN_LD2("%5", "%13", "1024") GNNPN_LD2("%6", "%13", "2048") GNNPN_LD2("%7", "%13", "3072")
-                 GNNPN_LD2("%8", "%14", "0") GNNPN_LD2("%9", "%14", "1024") GNNPN_LD2("%10", "%14", "2048") GNNPN_LD2("%11", "%14", "3072")
+__device__ __forceinline__ void granule_load2_x8_x4(u32x4 (&v)[8], u32x4 (&w)[4], const u64* base, const u64* pbase, unsigned voff) {
+    const u64* q = base + 512;
+    asm volatile(GNNPN_LD2("%0", "%12", "%13", "0") GNNPN_LD2("%1", "%12", "%13", "1024") GNNPN_LD2("%2", "%12", "%13", "2048")
+                 GNNPN_LD2("%3", "%12", "%13", "3072") GNNPN_LD2("%4", "%12", "%14", "0") GNNPN_LD2("%5", "%12", "%14", "1024")
+                 GNNPN_LD2("%6", "%12", "%14", "2048") GNNPN_LD2("%7", "%12", "%14", "3072")
+                 GNNPN_LD2("%8", "%12", "%15", "0") GNNPN_LD2("%9", "%12", "%15", "1024") GNNPN_LD2("%10", "%12", "%15", "2048")
+                 GNNPN_LD2("%11", "%12", "%15", "3072")
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
                    "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                 : "v"(p), "v"(q), "v"(r)
+                 : "v"(voff), "s"(base), "s"(q), "s"(pbase)
                  : "memory");
 }
 

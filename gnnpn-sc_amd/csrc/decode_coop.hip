@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                         bool good = true;
                         // pairs of this lane beyond n_p (K < 8 / K < 16) are loaded and never looked at: they lie at most
                         // 4 KB past this wave's segment, inside the workspace (COOP_OVERREAD_BYTES of slack at its end)
-                        if constexpr (NPJ2 == 2) granule_load2_x8_x2(vh, vp, src_h + 2 * lane, src_p + 2 * lane);
-                        else granule_load2_x8_x4(vh, vp, src_h + 2 * lane, src_p + 2 * lane);
+                        if constexpr (NPJ2 == 2) granule_load2_x8_x2(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
+                        else granule_load2_x8_x4(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
                         if (latent_in_launch && lane < n_l) {
                             const u64 x = granule_load(src_l + lane);
                             vl = (unsigned)x;

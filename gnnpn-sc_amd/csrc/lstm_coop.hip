@@ -37,9 +37,10 @@ constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 pari
 template <int PREC>
 __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, float* hs, int wave, int lane, bool keep,
                                               bool nowait = false) {
-    const u64* src = buf + wave * 4 * H;
+    const u64* src = uniform_ptr(buf + wave * 4 * H);      // group, parity, wave: uniform over the wave
+    const unsigned voff = 16u * lane;
     u32x4 v[8];                                              // granules 2*(64 j + lane), +1: {value, tag, value, tag}
-    granule_load2_x8(v, src + 2 * lane);
+    granule_load2_x8(v, src, voff);
     bool bad = false;                                        // this lane is still missing a tag
 #pragma unroll
     for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
@@ -52,7 +53,7 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
         if (++spins > SPIN_LIMIT) return false;
         for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
         if (nap < 16) nap <<= 1;
-        if (bad) granule_reload2_x8(v, src + 2 * lane);
+        if (bad) granule_reload2_x8(v, src, voff);
         bad = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
