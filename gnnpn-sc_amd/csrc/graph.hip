@@ -125,8 +125,8 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
 // diagonal: destination rows [b*R, (b+1)*R) only gather source rows of the same block (R = the table size S).  The kernel
 // above re-fetches every source row from L2 once per neighbour (33 x 1 KiB per output row at degree 32: L2-gather-bound,
 // 14 % of the HBM roofline).  Here a workgroup owns (block b, channel slice s of SLICE channels): it copies the block's
-// slice x[b*R .. (b+1)*R)[SLICE*s .. SLICE*(s+1)) into LDS ONCE (R * SLICE * 4 B <= 160 KB: SLICE = 16 up to R = 2560,
-// 8 up to 5120, 4 up to 10240) and serves every gather from there, so each source element crosses the L2 -> CU path once.
+// slice x[b*R .. (b+1)*R)[SLICE*s .. SLICE*(s+1)) into LDS ONCE ((R + 1) * SLICE * 4 B <= 160 KB: SLICE = 16 up to R = 2559,
+// 8 up to 5119, 4 up to 10239) and serves every gather from there, so each source element crosses the L2 -> CU path once.
 // LPR = SLICE/4 lanes per destination row, one float4 each; a wave works on 64/LPR rows at a time and walks their neighbour
 // lists in step (4 edges per trip, the (col, w) loads of a trip issued before its LDS reads).  Sums are strictly in CSR
 // order with separately rounded multiply and add: bit-identical to csr_aggregate_kernel.
@@ -135,30 +135,140 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
 // value of lane L of the own group of LPR (4, 2 or 1) consecutive lanes, as a DPP quad permute (no LDS round trip)
 template <int LPR, int L>
 __device__ __forceinline__ int quad_from(int v) {
-    if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xF, 0xF, false);                 // [L,L,L,L]
-    else if constexpr (LPR == 2) return __builtin_amdgcn_update_dpp(0, v, L | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6), 0xF, 0xF, false);
+    if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xF, 0xF, true);                 // [L,L,L,L]
+    else if constexpr (LPR == 2) return __builtin_amdgcn_update_dpp(0, v, L | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6), 0xF, 0xF, true);
     else return v;
 }
 
-template <int LPR>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) i32x4_u { int32_t v[4]; };     // 16 bytes at 4-byte alignment: one global_load_dwordx4
+struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
+
+// the 4 consecutive (col, w) entries at idx of one lane of a row's lane group (entries beyond the row's end are fetched and
+// ignored).  SAFE = no row of the wave ends within 4 entries of the arrays' end, so 16-byte loads cannot overrun them.
+template <bool HAS_W, bool SAFE>
+__device__ __forceinline__ void lds_agg_fetch(const int32_t* __restrict__ col, const float* __restrict__ w, int idx, int e1,
+                                              int (&cb)[4], float (&wb)[4]) {
+    if (SAFE) {
+        if (idx < e1) {
+            const i32x4_u c4 = *reinterpret_cast<const i32x4_u*>(col + idx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cb[k] = c4.v[k];
+            if (HAS_W) {
+                const f32x4_u w4 = *reinterpret_cast<const f32x4_u*>(w + idx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wb[k] = w4.v[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (idx + k < e1) {
+                cb[k] = col[idx + k];
+                if (HAS_W) wb[k] = w[idx + k];
+            }
+    }
+}
+
+// one batch of 4*LPR edges per row: entry k of lane p of the row's lane group is edge 4p+k; every lane of the group takes it
+// from there by a DPP quad permute (folded into the address add), reads its 16 bytes of the source row from LDS, and adds in
+// edge order.  Entries beyond a row's end point at the all-zero row behind the block with weight 0: acc + 0*0 = acc exactly
+// (acc starts at +0 and therefore is never -0), so the loop carries no masks.
+template <int LPR, bool HAS_W>
+__device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4], int sub16,
+                                                f32x2& a01, f32x2& a23) {
+#pragma unroll
+    for (int p = 0; p < LPR; ++p) {
+        float4 xv[4];
+        float wq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = (p == 0 ? quad_from<LPR, 0>(cc[k]) : p == 1 ? quad_from<LPR, 1 % LPR>(cc[k])
+                             : p == 2 ? quad_from<LPR, 2 % LPR>(cc[k]) : quad_from<LPR, 3 % LPR>(cc[k])) + sub16;
+            xv[k] = *reinterpret_cast<const float4*>(tile + off);
+            if (HAS_W) {
+                const int wi = __float_as_int(ww[k]);
+                wq[k] = __int_as_float(p == 0 ? quad_from<LPR, 0>(wi) : p == 1 ? quad_from<LPR, 1 % LPR>(wi)
+                                       : p == 2 ? quad_from<LPR, 2 % LPR>(wi) : quad_from<LPR, 3 % LPR>(wi));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x2 lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
+            if (HAS_W) {
+                const f32x2 w2 = {wq[k], wq[k]};
+                lo = lo * w2;                         // -ffp-contract=off: the product is rounded before the add
+                hi = hi * w2;
+            }
+            a01 = a01 + lo;
+            a23 = a23 + hi;
+        }
+    }
+}
+
+// the rows of one pass of a wave (one row per lane group), all their edges: the next batch's (col, w) are requested before
+// the current batch is consumed and turned into LDS offsets after it, so their latency lies under the batch's LDS reads.
+template <int LPR, bool HAS_W, bool SAFE>
+__device__ __forceinline__ void lds_agg_rows(const char* __restrict__ tile_b, const int32_t* __restrict__ col,
+                                             const float* __restrict__ w, int e, int e1, int r0, int zoff, int sub,
+                                             f32x2& a01, f32x2& a23) {
+    constexpr int SLICE = 4 * LPR;
+    const int sub16 = 16 * sub;
+    int cb[4] = {0, 0, 0, 0};
+    float wb[4] = {0.f, 0.f, 0.f, 0.f};
+    int cc[4];
+    float ww[4];
+    lds_agg_fetch<HAS_W, SAFE>(col, w, e + 4 * sub, e1, cb, wb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // LDS byte offset of the source row; beyond the row's end: the zero row, weight 0
+        const bool ok = e + 4 * sub + k < e1;
+        cc[k] = ok ? (cb[k] - r0) * (SLICE * 4) : zoff;
+        ww[k] = ok ? wb[k] : 0.0f;
+    }
+    while (__any(e < e1)) {
+        e += 4 * LPR;
+        lds_agg_fetch<HAS_W, SAFE>(col, w, e + 4 * sub, e1, cb, wb);
+        lds_agg_consume<LPR, HAS_W>(tile_b, cc, ww, sub16, a01, a23);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = e + 4 * sub + k < e1;
+            cc[k] = ok ? (cb[k] - r0) * (SLICE * 4) : zoff;
+            ww[k] = ok ? wb[k] : 0.0f;
+        }
+    }
+}
+
+template <int LPR, bool HAS_W>
 __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ y, int64_t ldy,
     int32_t n_rows, int32_t C, int32_t R, int32_t n_blocks, int32_t n_slices) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];      // [R][SLICE]
-    constexpr int SLICE = 4 * LPR;
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [R + 1][SLICE]: the block's slice and one all-zero row
+    constexpr int SLICE = 4 * LPR, RPP = 1024 / LPR;                   // rows per pass of the workgroup
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int s = j % n_slices, b = (j / n_slices) * 8 + xcd;
     if (b >= n_blocks) return;
     const int r0 = b * R, rows = min(R, n_rows - r0);
     const int c0 = s * SLICE;
     const int sub = threadIdx.x % LPR, c = c0 + 4 * sub;               // this lane's 4 channels
-    // ---- fill: the block's channel slice, 16 B per lane
-    for (int r = threadIdx.x / LPR; r < rows; r += 1024 / LPR) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + c);
-        *reinterpret_cast<float4*>(tile + r * SLICE + 4 * sub) = v;
+    const int nnz = rowptr[n_rows];
+    // ---- fill: the block's channel slice, 16 B per lane, 5 rows in flight per lane
+    for (int rr = threadIdx.x / LPR; rr < rows; rr += 5 * RPP) {
+        float4 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int r = min(rr + u * RPP, rows - 1);                 // clamped: the loads need no branch
+            v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {                                  // (clamped duplicates rewrite row rows-1 with its own bytes)
+            const int r = min(rr + u * RPP, rows - 1);
+            *reinterpret_cast<float4*>(tile + r * SLICE + 4 * sub) = v[u];
+        }
     }
+    const int zoff = R * (SLICE * 4);                                   // byte offset of the zero row
+    if (threadIdx.x < SLICE) tile[R * SLICE + threadIdx.x] = 0.0f;
     __syncthreads();
     const float one_plus_eps = self_coef ? __fadd_rn(1.0f, *self_coef) : 0.0f;
     float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
@@ -170,8 +280,11 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
             sh[v] = shift[c + v];
         }
     }
-    // ---- gather: rows dealt to (wave, lane group) round-robin; a wave's rows advance together
-    for (int rb = 0; rb < rows; rb += 1024 / LPR) {
+    const char* tile_b = reinterpret_cast<const char*>(tile);
+    // ---- gather: rows dealt to (wave, lane group) round-robin; a wave's 64/LPR consecutive rows advance together, 4*LPR
+    // edges per batch.  The (col, w) lists of those rows are ONE contiguous range of the arrays; each lane fetches 4
+    // consecutive entries with one 16-byte load per array (the next batch's while the current one is consumed).
+    for (int rb = 0; rb < rows; rb += RPP) {
         const int r = rb + threadIdx.x / LPR;
         const bool live = r < rows;
         int e = 0, e1 = 0;
@@ -179,47 +292,13 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
             e = rowptr[r0 + r];
             e1 = rowptr[r0 + r + 1];
         }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        while (__any(e < e1)) {
-            // (col, w) of the trip's 4 edges: the LPR lanes of a row each fetch a DIFFERENT edge (consecutive addresses: one
-            // line per row and instruction instead of one per row, edge and instruction) and hand it round by a DPP
-            // quad permute — the texture-addresser was the bound with every lane of a row fetching the same word
-            constexpr int NL = 4 / LPR;
-            int cl[NL];
-            float wl[NL];
-#pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int idx = e + k * LPR + sub;
-                const bool ok = idx < e1;
-                cl[k] = ok ? col[idx] - r0 : 0;
-                wl[k] = (ok && w) ? w[idx] : 1.0f;
-            }
-            int cj[4];
-            float wj[4];
-            cj[0] = quad_from<LPR, 0>(cl[0]);
-            wj[0] = __int_as_float(quad_from<LPR, 0>(__float_as_int(wl[0])));
-            cj[1] = quad_from<LPR, 1 % LPR>(cl[1 / LPR]);
-            wj[1] = __int_as_float(quad_from<LPR, 1 % LPR>(__float_as_int(wl[1 / LPR])));
-            cj[2] = quad_from<LPR, 2 % LPR>(cl[2 / LPR]);
-            wj[2] = __int_as_float(quad_from<LPR, 2 % LPR>(__float_as_int(wl[2 / LPR])));
-            cj[3] = quad_from<LPR, 3 % LPR>(cl[3 / LPR]);
-            wj[3] = __int_as_float(quad_from<LPR, 3 % LPR>(__float_as_int(wl[3 / LPR])));
-            float4 xv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(tile + cj[u] * SLICE + 4 * sub);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (e + u < e1) {
-                    const float t4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], w ? __fmul_rn(wj[u], t4[v]) : t4[v]);
-                }
-            }
-            e += 4;
-        }
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        if (__all(e1 + 4 <= nnz)) lds_agg_rows<LPR, HAS_W, true>(tile_b, col, w, e, e1, r0, zoff, sub, a01, a23);
+        else lds_agg_rows<LPR, HAS_W, false>(tile_b, col, w, e, e1, r0, zoff, sub, a01, a23);
         if (!live) continue;
         const float4 own = *reinterpret_cast<const float4*>(tile + r * SLICE + 4 * sub);
         const float o4[4] = {own.x, own.y, own.z, own.w};
+        float acc[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             float t = acc[v];
@@ -245,28 +324,31 @@ extern "C" int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32
     constexpr int64_t LDS_BYTES = 160 * 1024;
     int lpr = 0;                                   // lanes per row = SLICE / 4: the widest slice whose block fits the LDS
     for (int cand = 4; cand >= 1; cand >>= 1)
-        if (C % (4 * cand) == 0 && (int64_t)block_rows * 16 * cand <= LDS_BYTES) {
+        if (C % (4 * cand) == 0 && ((int64_t)block_rows + 1) * 16 * cand <= LDS_BYTES) {
             lpr = cand;
             break;
         }
     if (!vec || lpr == 0)
         GNNPN_FAIL(GNNPN_E_UNSUP, "csr_aggregate_blocks: blocks of %d rows x %d channels do not fit the LDS-staged form "
-                   "(16-byte aligned rows, block_rows * 16 B <= 160 KB): use gnnpn_csr_aggregate_f32", block_rows, C);
+                   "(16-byte aligned rows, (block_rows + 1) * 16 B <= 160 KB): use gnnpn_csr_aggregate_f32", block_rows, C);
     const int n_blocks = (n_rows + block_rows - 1) / block_rows, n_slices = C / (4 * lpr);
-    const unsigned lds = (unsigned)((int64_t)block_rows * 16 * lpr);
+    const unsigned lds = (unsigned)(((int64_t)block_rows + 1) * 16 * lpr);
     dim3 grid((unsigned)(((n_blocks + 7) / 8) * n_slices * 8)), block(1024);
     hipStream_t st = (hipStream_t)stream;
-#define GNNPN_AGG_LDS(LPR_)                                                                                              \
+#define GNNPN_AGG_LDS(LPR_, W_)                                                                                              \
     do {                                                                                                                 \
-        if (hipFuncSetAttribute((const void*)csr_aggregate_lds_kernel<LPR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds) != hipSuccess)                                                                  \
+        if (hipFuncSetAttribute((const void*)csr_aggregate_lds_kernel<LPR_, W_>,                                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                      \
             GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_blocks: cannot reserve %u B of LDS", lds);                          \
-        hipLaunchKernelGGL((csr_aggregate_lds_kernel<LPR_>), grid, block, lds, st, rowptr, col, w, x, ldx, self_coef,    \
+        hipLaunchKernelGGL((csr_aggregate_lds_kernel<LPR_, W_>), grid, block, lds, st, rowptr, col, w, x, ldx, self_coef, \
                            bias, scale, shift, act, y, ldy, n_rows, C, block_rows, n_blocks, n_slices);                  \
     } while (0)
-    if (lpr == 4) GNNPN_AGG_LDS(4);
-    else if (lpr == 2) GNNPN_AGG_LDS(2);
-    else GNNPN_AGG_LDS(1);
+    if (lpr == 4 && w) GNNPN_AGG_LDS(4, true);
+    else if (lpr == 4) GNNPN_AGG_LDS(4, false);
+    else if (lpr == 2 && w) GNNPN_AGG_LDS(2, true);
+    else if (lpr == 2) GNNPN_AGG_LDS(2, false);
+    else if (w) GNNPN_AGG_LDS(1, true);
+    else GNNPN_AGG_LDS(1, false);
 #undef GNNPN_AGG_LDS
     GNNPN_CHECK_LAUNCH("csr_aggregate_blocks_f32");
     return GNNPN_OK;

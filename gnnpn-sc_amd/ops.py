@@ -44,7 +44,7 @@ def embed_concat(x, table):
     return out
 
 
-LDS_BLOCK_ROWS_MAX = 10240      # block_rows * 16 B <= 160 KB
+LDS_BLOCK_ROWS_MAX = 10239      # (block_rows + 1) * 16 B <= 160 KB: the block and one all-zero row
 LDS_MIN_WORKGROUPS = 128        # below this many (block, slice) workgroups the one-wave-per-row gather fills the chip better
 PREFER_LDS_AGGREGATE = False    # the LDS-staged form is bit-identical but measured slower than the gather form on MI355X
 #                                 (profiles/r02_csr_aggregate_roofline.json): opt-in

@@ -82,7 +82,7 @@ int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col, const flo
  * block_rows = S, or a single graph with block_rows = n_rows.  One workgroup per (block, channel slice) copies the block's
  * slice into LDS once and serves all gathers from there (each source element crosses L2 -> CU once instead of once per
  * neighbour); same CSR-order sums, same epilogue, bit-identical results.
- * GNNPN_E_UNSUP (nothing enqueued) when a block does not fit: block_rows * 16 B > 160 KB (block_rows > 10240), or rows
+ * GNNPN_E_UNSUP (nothing enqueued) when a block does not fit: (block_rows + 1) * 16 B > 160 KB (block_rows > 10239), or rows
  * not 16-byte aligned; callers then use gnnpn_csr_aggregate_f32.
  * Replaces: GCNConv.propagate over the batched service graph, src/models/modelML.py:153. */
 int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, const float* w,

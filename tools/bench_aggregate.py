@@ -71,7 +71,7 @@ for cfg in a.configs.split(","):
         assert torch.equal(lds(), gather()), f"LDS-staged form differs from the gather form at S={S}"
         ms_l = timed(lds, a.reps)
         rec["lds"] = {"ms": round(ms_l, 4), "GBps": round(alg / ms_l / 1e6, 1), "frac_of_8TBps": round(alg / ms_l / 8e9, 4),
-                      "slice_channels": next(4 * c for c in (4, 2, 1) if S * 16 * c <= 160 * 1024), "bit_identical_to_gather": True}
+                      "slice_channels": next(4 * c for c in (4, 2, 1) if (S + 1) * 16 * c <= 160 * 1024), "bit_identical_to_gather": True}
     out.append(rec)
     print(json.dumps(rec), flush=True)
     del rp, col, w, x, norm
