@@ -25,7 +25,8 @@ _SIGNATURES = {
     "gnnpn_csr_aggregate_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
                                         c_int32, _P]),
     "gnnpn_csr_aggregate_blocks_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
-                                               c_int32, c_int32, _P]),
+                                               c_int32, c_int32, _P, _P]),
+    "gnnpn_csr_block_row_order": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,

@@ -144,21 +144,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) i32x4_u { int32_t v[4]; };     // 16 bytes at 4-byte alignment: one global_load_dwordx4
 struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
 
-// the 4 consecutive (col, w) entries at idx of one lane of a row's lane group (entries beyond the row's end are fetched and
-// ignored).  SAFE = no row of the wave ends within 4 entries of the arrays' end, so 16-byte loads cannot overrun them.
+// the 4 consecutive (col, w) entries at idx of one lane of a row's lane group.  SAFE = no row of the wave ends within 4
+// entries of the arrays' end: one unconditional 16-byte load per array (SGPR base + 32-bit lane offset; a lane beyond its
+// row's end re-reads the line behind it and the values are ignored).
 template <bool HAS_W, bool SAFE>
 __device__ __forceinline__ void lds_agg_fetch(const int32_t* __restrict__ col, const float* __restrict__ w, int idx, int e1,
                                               int (&cb)[4], float (&wb)[4]) {
     if (SAFE) {
-        if (idx < e1) {
-            const i32x4_u c4 = *reinterpret_cast<const i32x4_u*>(col + idx);
+        const unsigned boff = 4u * (unsigned)min(idx, e1);
+        const i32x4_u c4 = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + boff);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cb[k] = c4.v[k];
-            if (HAS_W) {
-                const f32x4_u w4 = *reinterpret_cast<const f32x4_u*>(w + idx);
+        for (int k = 0; k < 4; ++k) cb[k] = c4.v[k];
+        if (HAS_W) {
+            const f32x4_u w4 = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(w) + boff);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) wb[k] = w4.v[k];
-            }
+            for (int k = 0; k < 4; ++k) wb[k] = w4.v[k];
         }
     } else {
 #pragma unroll
@@ -170,70 +170,92 @@ __device__ __forceinline__ void lds_agg_fetch(const int32_t* __restrict__ col, c
     }
 }
 
-// one batch of 4*LPR edges per row: entry k of lane p of the row's lane group is edge 4p+k; every lane of the group takes it
-// from there by a DPP quad permute (folded into the address add), reads its 16 bytes of the source row from LDS, and adds in
-// edge order.  Entries beyond a row's end point at the all-zero row behind the block with weight 0: acc + 0*0 = acc exactly
-// (acc starts at +0 and therefore is never -0), so the loop carries no masks.
-template <int LPR, bool HAS_W>
-__device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4], int sub16,
-                                                f32x2& a01, f32x2& a23) {
+// the 4 edges held by lane P of every row's lane group: each lane of the group takes (offset, weight) from there by a DPP
+// quad permute (folded into the address add) and requests its 16 bytes of the source row from LDS ...
+template <int LPR, bool HAS_W, int P>
+__device__ __forceinline__ void lds_agg_read4(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4],
+                                              int lane_off, float4 (&xv)[4], float (&wq)[4]) {
 #pragma unroll
-    for (int p = 0; p < LPR; ++p) {
-        float4 xv[4];
-        float wq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int off = (p == 0 ? quad_from<LPR, 0>(cc[k]) : p == 1 ? quad_from<LPR, 1 % LPR>(cc[k])
-                             : p == 2 ? quad_from<LPR, 2 % LPR>(cc[k]) : quad_from<LPR, 3 % LPR>(cc[k])) + sub16;
-            xv[k] = *reinterpret_cast<const float4*>(tile + off);
-            if (HAS_W) {
-                const int wi = __float_as_int(ww[k]);
-                wq[k] = __int_as_float(p == 0 ? quad_from<LPR, 0>(wi) : p == 1 ? quad_from<LPR, 1 % LPR>(wi)
-                                       : p == 2 ? quad_from<LPR, 2 % LPR>(wi) : quad_from<LPR, 3 % LPR>(wi));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x2 lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
-            if (HAS_W) {
-                const f32x2 w2 = {wq[k], wq[k]};
-                lo = lo * w2;                         // -ffp-contract=off: the product is rounded before the add
-                hi = hi * w2;
-            }
-            a01 = a01 + lo;
-            a23 = a23 + hi;
-        }
+    for (int k = 0; k < 4; ++k) {
+        xv[k] = *reinterpret_cast<const float4*>(tile + (quad_from<LPR, P>(cc[k]) + lane_off));
+        if (HAS_W) wq[k] = __int_as_float(quad_from<LPR, P>(__float_as_int(ww[k])));
     }
 }
 
-// the rows of one pass of a wave (one row per lane group), all their edges: the next batch's (col, w) are requested before
-// the current batch is consumed and turned into LDS offsets after it, so their latency lies under the batch's LDS reads.
+// ... and adds them in edge order
+template <bool HAS_W>
+__device__ __forceinline__ void lds_agg_add4(const float4 (&xv)[4], const float (&wq)[4], f32x2& a01, f32x2& a23) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x2 lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
+        if (HAS_W) {
+            const f32x2 w2 = {wq[k], wq[k]};
+            lo = lo * w2;                             // -ffp-contract=off: the product is rounded before the add
+            hi = hi * w2;
+        }
+        a01 = a01 + lo;
+        a23 = a23 + hi;
+    }
+}
+
+// the first NP groups of 4 edges of a batch, as straight-line code: the reads of group p+1 are in flight under the adds of p
+template <int LPR, bool HAS_W, int NP>
+__device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4],
+                                                int lane_off, f32x2& a01, f32x2& a23) {
+    float4 xa[4], xb[4];
+    float wa[4], wb[4];
+    lds_agg_read4<LPR, HAS_W, 0>(tile, cc, ww, lane_off, xa, wa);
+    if (NP > 1) lds_agg_read4<LPR, HAS_W, 1 % LPR>(tile, cc, ww, lane_off, xb, wb);
+    lds_agg_add4<HAS_W>(xa, wa, a01, a23);
+    if (NP > 2) lds_agg_read4<LPR, HAS_W, 2 % LPR>(tile, cc, ww, lane_off, xa, wa);
+    if (NP > 1) lds_agg_add4<HAS_W>(xb, wb, a01, a23);
+    if (NP > 3) lds_agg_read4<LPR, HAS_W, 3 % LPR>(tile, cc, ww, lane_off, xb, wb);
+    if (NP > 2) lds_agg_add4<HAS_W>(xa, wa, a01, a23);
+    if (NP > 3) lds_agg_add4<HAS_W>(xb, wb, a01, a23);
+}
+
+// the rows of one pass of a wave (one row per lane group of LPR lanes), all their edges, 4*LPR per batch: entry k of lane p
+// of the group is edge 4p+k of the batch.  The next batch's (col, w) are requested before the current batch is consumed, so
+// their latency lies under its LDS reads.  Entries beyond a row's end point at the all-zero row behind the block with
+// weight 0: acc + 0*0 = acc exactly (acc starts at +0 and therefore is never -0), so the adds carry no masks; a batch that
+// is full for every row of the wave skips even that replacement, the last ones stop after the last group of 4 any row needs.
 template <int LPR, bool HAS_W, bool SAFE>
 __device__ __forceinline__ void lds_agg_rows(const char* __restrict__ tile_b, const int32_t* __restrict__ col,
-                                             const float* __restrict__ w, int e, int e1, int r0, int zoff, int sub,
+                                             const float* __restrict__ w, int e, int e1, int zoff, int sub, int lane_off,
                                              f32x2& a01, f32x2& a23) {
     constexpr int SLICE = 4 * LPR;
-    const int sub16 = 16 * sub;
     int cb[4] = {0, 0, 0, 0};
     float wb[4] = {0.f, 0.f, 0.f, 0.f};
-    int cc[4];
-    float ww[4];
     lds_agg_fetch<HAS_W, SAFE>(col, w, e + 4 * sub, e1, cb, wb);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // LDS byte offset of the source row; beyond the row's end: the zero row, weight 0
-        const bool ok = e + 4 * sub + k < e1;
-        cc[k] = ok ? (cb[k] - r0) * (SLICE * 4) : zoff;
-        ww[k] = ok ? wb[k] : 0.0f;
-    }
-    while (__any(e < e1)) {
-        e += 4 * LPR;
-        lds_agg_fetch<HAS_W, SAFE>(col, w, e + 4 * sub, e1, cb, wb);
-        lds_agg_consume<LPR, HAS_W>(tile_b, cc, ww, sub16, a01, a23);
+    for (;;) {
+        const int rem = e1 - e;                      // edges this row still has (<= 0: done)
+        if (!__any(rem > 0)) break;
+        const bool full = __all(rem >= 4 * LPR);
+        int cc[4];
+        float ww[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool ok = e + 4 * sub + k < e1;
-            cc[k] = ok ? (cb[k] - r0) * (SLICE * 4) : zoff;
-            ww[k] = ok ? wb[k] : 0.0f;
+            cc[k] = cb[k] * (SLICE * 4);             // LDS byte offset of the source row (lane_off carries -r0 and the lane's 16 B)
+            ww[k] = wb[k];
+        }
+        if (!full) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = 4 * sub + k < rem;
+                cc[k] = ok ? cc[k] : zoff;
+                ww[k] = ok ? ww[k] : 0.0f;
+            }
+        }
+        e += 4 * LPR;
+        lds_agg_fetch<HAS_W, SAFE>(col, w, e + 4 * sub, e1, cb, wb);
+        if (full) {
+            lds_agg_consume<LPR, HAS_W, LPR>(tile_b, cc, ww, lane_off, a01, a23);
+        } else {                                     // the groups of 4 any row of the wave still needs
+            const int np = LPR == 1 ? 1 : !__any(rem > 4) ? 1 : (LPR == 2 || !__any(rem > 8)) ? 2 : !__any(rem > 12) ? 3 : 4;
+            if (np == 1) lds_agg_consume<LPR, HAS_W, 1>(tile_b, cc, ww, lane_off, a01, a23);
+            else if (np == 2) lds_agg_consume<LPR, HAS_W, (LPR > 1 ? 2 : 1)>(tile_b, cc, ww, lane_off, a01, a23);
+            else if (np == 3) lds_agg_consume<LPR, HAS_W, (LPR > 2 ? 3 : 1)>(tile_b, cc, ww, lane_off, a01, a23);
+            else lds_agg_consume<LPR, HAS_W, LPR>(tile_b, cc, ww, lane_off, a01, a23);
         }
     }
 }
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ y, int64_t ldy,
-    int32_t n_rows, int32_t C, int32_t R, int32_t n_blocks, int32_t n_slices) {
+    int32_t n_rows, int32_t C, int32_t R, int32_t n_blocks, int32_t n_slices, const int32_t* __restrict__ row_order) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [R + 1][SLICE]: the block's slice and one all-zero row
     constexpr int SLICE = 4 * LPR, RPP = 1024 / LPR;                   // rows per pass of the workgroup
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -253,21 +275,20 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
     const int c0 = s * SLICE;
     const int sub = threadIdx.x % LPR, c = c0 + 4 * sub;               // this lane's 4 channels
     const int nnz = rowptr[n_rows];
-    // ---- fill: the block's channel slice, 16 B per lane, 5 rows in flight per lane
-    for (int rr = threadIdx.x / LPR; rr < rows; rr += 5 * RPP) {
-        float4 v[5];
+    // ---- fill: the block's channel slice, 16 B per lane, 10 rows in flight per lane (a block of 2560 rows in ONE round trip)
+    for (int rr = threadIdx.x / LPR; rr < rows; rr += 10 * RPP) {
+        float4 v[10];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < 10; ++u) {
             const int r = min(rr + u * RPP, rows - 1);                 // clamped: the loads need no branch
             v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + r) * ldx + c);
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {                                  // (clamped duplicates rewrite row rows-1 with its own bytes)
+        for (int u = 0; u < 10; ++u) {                                 // (clamped duplicates rewrite row rows-1 with its own bytes)
             const int r = min(rr + u * RPP, rows - 1);
             *reinterpret_cast<float4*>(tile + r * SLICE + 4 * sub) = v[u];
         }
     }
-    const int zoff = R * (SLICE * 4);                                   // byte offset of the zero row
     if (threadIdx.x < SLICE) tile[R * SLICE + threadIdx.x] = 0.0f;
     __syncthreads();
     const float one_plus_eps = self_coef ? __fadd_rn(1.0f, *self_coef) : 0.0f;
@@ -281,20 +302,22 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
         }
     }
     const char* tile_b = reinterpret_cast<const char*>(tile);
-    // ---- gather: rows dealt to (wave, lane group) round-robin; a wave's 64/LPR consecutive rows advance together, 4*LPR
-    // edges per batch.  The (col, w) lists of those rows are ONE contiguous range of the arrays; each lane fetches 4
-    // consecutive entries with one 16-byte load per array (the next batch's while the current one is consumed).
+    const int lane_off = 16 * sub - r0 * (SLICE * 4);                   // + col * SLICE * 4 = the lane's 16 bytes of source row col
+    const int zoff = (R + r0) * (SLICE * 4);                            // the zero row, in the same terms
+    // ---- gather: the block's rows are dealt to (wave, lane group) in passes of 1024/LPR — in the caller's row_order
+    // (descending degree: the 64/LPR rows a wave walks in step then have nearly the same number of edges) or as they come.
     for (int rb = 0; rb < rows; rb += RPP) {
-        const int r = rb + threadIdx.x / LPR;
-        const bool live = r < rows;
-        int e = 0, e1 = 0;
+        const int i = rb + threadIdx.x / LPR;
+        const bool live = i < rows;
+        int r = i, e = 0, e1 = 0;
         if (live) {
+            if (row_order) r = row_order[r0 + i] - r0;
             e = rowptr[r0 + r];
             e1 = rowptr[r0 + r + 1];
         }
         f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-        if (__all(e1 + 4 <= nnz)) lds_agg_rows<LPR, HAS_W, true>(tile_b, col, w, e, e1, r0, zoff, sub, a01, a23);
-        else lds_agg_rows<LPR, HAS_W, false>(tile_b, col, w, e, e1, r0, zoff, sub, a01, a23);
+        if (__all(e1 + 4 <= nnz)) lds_agg_rows<LPR, HAS_W, true>(tile_b, col, w, e, e1, zoff, sub, lane_off, a01, a23);
+        else lds_agg_rows<LPR, HAS_W, false>(tile_b, col, w, e, e1, zoff, sub, lane_off, a01, a23);
         if (!live) continue;
         const float4 own = *reinterpret_cast<const float4*>(tile + r * SLICE + 4 * sub);
         const float o4[4] = {own.x, own.y, own.z, own.w};
@@ -314,7 +337,7 @@ __global__ __launch_bounds__(1024) void csr_aggregate_lds_kernel(
 extern "C" int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
                                               int64_t ldx, const float* self_coef, const float* bias, const float* scale,
                                               const float* shift, int act, float* y, int64_t ldy, int32_t n_rows, int32_t C,
-                                              int32_t block_rows, void* stream) {
+                                              int32_t block_rows, const int32_t* row_order, void* stream) {
     GNNPN_REQUIRE(rowptr && x && y, "csr_aggregate_blocks: null operand");
     GNNPN_REQUIRE(n_rows >= 0 && C > 0 && ldx >= C && ldy >= C && block_rows > 0, "csr_aggregate_blocks: bad shape");
     GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "csr_aggregate_blocks: scale and shift go together");
@@ -335,13 +358,13 @@ extern "C" int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32
     const unsigned lds = (unsigned)(((int64_t)block_rows + 1) * 16 * lpr);
     dim3 grid((unsigned)(((n_blocks + 7) / 8) * n_slices * 8)), block(1024);
     hipStream_t st = (hipStream_t)stream;
-#define GNNPN_AGG_LDS(LPR_, W_)                                                                                              \
+#define GNNPN_AGG_LDS(LPR_, W_)                                                                                          \
     do {                                                                                                                 \
         if (hipFuncSetAttribute((const void*)csr_aggregate_lds_kernel<LPR_, W_>,                                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                      \
             GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_blocks: cannot reserve %u B of LDS", lds);                          \
         hipLaunchKernelGGL((csr_aggregate_lds_kernel<LPR_, W_>), grid, block, lds, st, rowptr, col, w, x, ldx, self_coef, \
-                           bias, scale, shift, act, y, ldy, n_rows, C, block_rows, n_blocks, n_slices);                  \
+                           bias, scale, shift, act, y, ldy, n_rows, C, block_rows, n_blocks, n_slices, row_order);       \
     } while (0)
     if (lpr == 4 && w) GNNPN_AGG_LDS(4, true);
     else if (lpr == 4) GNNPN_AGG_LDS(4, false);
@@ -351,6 +374,58 @@ extern "C" int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32
     else GNNPN_AGG_LDS(1, false);
 #undef GNNPN_AGG_LDS
     GNNPN_CHECK_LAUNCH("csr_aggregate_blocks_f32");
+    return GNNPN_OK;
+}
+
+// The row order the LDS-staged aggregate walks a block in: per block the rows by descending number of edges (ties: ascending
+// row), as global row numbers.  One workgroup per block: bitonic sort of 32-bit keys {0xFFFF - min(degree, 0xFFFF), local
+// row} in LDS.  A property of the graph: computed once, reused by every layer and call.
+__global__ __launch_bounds__(1024) void csr_block_order_kernel(const int32_t* __restrict__ rowptr, int32_t n_rows, int32_t R,
+                                                               int32_t P, int32_t* __restrict__ order) {
+    extern __shared__ uint32_t okeys[];                                // [P], P = the power of two >= R
+    const int r0 = blockIdx.x * R, rows = min(R, n_rows - r0);
+    for (int i = threadIdx.x; i < P; i += 1024) {
+        uint32_t k = 0xFFFFFFFFu;
+        if (i < rows) {
+            const int deg = rowptr[r0 + i + 1] - rowptr[r0 + i];
+            k = ((uint32_t)(0xFFFF - min(max(deg, 0), 0xFFFF)) << 16) | (uint32_t)i;
+        }
+        okeys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint32_t a = okeys[i], b = okeys[p];
+                    if ((a > b) == ((i & k) == 0)) {
+                        okeys[i] = b;
+                        okeys[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < rows; i += 1024) order[r0 + i] = r0 + (int32_t)(okeys[i] & 0xFFFFu);
+}
+
+extern "C" int gnnpn_csr_block_row_order(const int32_t* rowptr, int32_t n_rows, int32_t block_rows, int32_t* row_order,
+                                         void* stream) {
+    GNNPN_REQUIRE(n_rows >= 0 && block_rows > 0, "csr_block_row_order: bad shape");
+    if (n_rows == 0) return GNNPN_OK;
+    GNNPN_REQUIRE(rowptr && row_order, "csr_block_row_order: null operand");
+    if (block_rows > 16384)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "csr_block_row_order: blocks of %d rows (at most 16384)", block_rows);
+    int P = 2;
+    while (P < block_rows) P <<= 1;
+    const unsigned lds = (unsigned)P * 4u;
+    if (hipFuncSetAttribute((const void*)csr_block_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_block_row_order: cannot reserve %u B of LDS", lds);
+    const int n_blocks = (n_rows + block_rows - 1) / block_rows;
+    hipLaunchKernelGGL(csr_block_order_kernel, dim3((unsigned)n_blocks), dim3(1024), lds, (hipStream_t)stream, rowptr, n_rows,
+                       block_rows, P, row_order);
+    GNNPN_CHECK_LAUNCH("csr_block_row_order");
     return GNNPN_OK;
 }
 

@@ -2,6 +2,8 @@
 output with torch (device memory only), pass raw pointers + the current HIP stream.  No compute
 happens in Python; there is no CPU path — non-CUDA tensors raise ``GnnpnError``.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -46,27 +48,47 @@ def embed_concat(x, table):
 
 LDS_BLOCK_ROWS_MAX = 10239      # (block_rows + 1) * 16 B <= 160 KB: the block and one all-zero row
 LDS_MIN_WORKGROUPS = 128        # below this many (block, slice) workgroups the one-wave-per-row gather fills the chip better
-PREFER_LDS_AGGREGATE = False    # the LDS-staged form is bit-identical but measured slower than the gather form on MI355X
-#                                 (profiles/r02_csr_aggregate_roofline.json): opt-in
+LDS_SLICE16_ROWS_MAX = 2559     # blocks up to here stage 16-channel slices: the LDS-staged form is the faster one there
+PREFER_LDS_AGGREGATE = None     # None: the LDS-staged form where it is measured faster (16-channel slices, enough workgroups:
+#                                 profiles/r02_csr_aggregate_roofline.json); True / False force the choice
+_row_orders = {}                # id(rowptr tensor) -> (weak reference to it, block_rows, order)
+
+
+def csr_block_row_order(rowptr, block_rows):
+    """Per block of ``block_rows`` rows: the rows by descending edge count (gnnpn_csr_block_row_order) — the order in which
+    the LDS-staged aggregate deals a block's rows to its wavefronts.  Cached per rowptr tensor (a property of the graph)."""
+    key = id(rowptr)
+    hit = _row_orders.get(key)
+    if hit is not None and hit[0]() is rowptr and hit[1] == block_rows:
+        return hit[2]
+    n = rowptr.numel() - 1
+    order = torch.empty(n, dtype=I32, device=rowptr.device)
+    check(_lib.load().gnnpn_csr_block_row_order(dev_ptr(rowptr, I32, "rowptr"), n, int(block_rows), dev_ptr(order, I32, "order"),
+                                                stream_ptr()), "gnnpn_csr_block_row_order")
+    _row_orders[key] = (weakref.ref(rowptr, lambda _, k=key: _row_orders.pop(k, None)), block_rows, order)
+    return order
 
 
 def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
     """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
     ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
-    records it): with ``ops.PREFER_LDS_AGGREGATE`` the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a
-    block fits the LDS and there are enough (block, slice) workgroups to fill the chip; bit-identical either way."""
+    records it): the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a block fits the LDS with
+    16-channel slices and there are enough (block, slice) workgroups to fill the chip (``ops.PREFER_LDS_AGGREGATE``
+    forces it on wherever it fits, or off); bit-identical either way."""
     x = _rows2d(x, "csr_aggregate.x")
     n = rowptr.numel() - 1
     C = x.shape[1]
     y = torch.empty((n, C), dtype=F32, device=x.device)
-    if PREFER_LDS_AGGREGATE and 0 < block_rows <= LDS_BLOCK_ROWS_MAX and C % 4 == 0:
-        lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and block_rows * 16 * c <= 160 * 1024)
-        if -(-n // block_rows) * (C // (4 * lpr)) >= LDS_MIN_WORKGROUPS:
+    rows_max = LDS_BLOCK_ROWS_MAX if PREFER_LDS_AGGREGATE else LDS_SLICE16_ROWS_MAX
+    if PREFER_LDS_AGGREGATE is not False and 0 < block_rows <= rows_max and C % 4 == 0 and n > 0:
+        lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and (block_rows + 1) * 16 * c <= 160 * 1024)
+        if (lpr == 4 or PREFER_LDS_AGGREGATE) and -(-n // block_rows) * (C // (4 * lpr)) >= LDS_MIN_WORKGROUPS:
+            order = csr_block_row_order(rowptr, block_rows) if block_rows <= 16384 else None
             check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
                 dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
                 dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
                 dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act, dev_ptr(y, F32, "y"), C, n, C,
-                int(block_rows), stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
+                int(block_rows), dev_ptr(order, I32, "row_order", True), stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
             return y
     check(_lib.load().gnnpn_csr_aggregate_f32(
         dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,

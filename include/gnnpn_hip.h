@@ -82,13 +82,20 @@ int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col, const flo
  * block_rows = S, or a single graph with block_rows = n_rows.  One workgroup per (block, channel slice) copies the block's
  * slice into LDS once and serves all gathers from there (each source element crosses L2 -> CU once instead of once per
  * neighbour); same CSR-order sums, same epilogue, bit-identical results.
+ * row_order: NULL, or [n_rows] from gnnpn_csr_block_row_order — the order in which a block's rows are dealt to the
+ * wavefronts (speed only: rows that advance in step then have the same number of edges; the results do not depend on it).
  * GNNPN_E_UNSUP (nothing enqueued) when a block does not fit: (block_rows + 1) * 16 B > 160 KB (block_rows > 10239), or rows
  * not 16-byte aligned; callers then use gnnpn_csr_aggregate_f32.
  * Replaces: GCNConv.propagate over the batched service graph, src/models/modelML.py:153. */
 int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, const float* w,
                                    const float* x, int64_t ldx, const float* self_coef, const float* bias,
                                    const float* scale, const float* shift, int act, float* y, int64_t ldy,
-                                   int32_t n_rows, int32_t C, int32_t block_rows, void* stream);
+                                   int32_t n_rows, int32_t C, int32_t block_rows, const int32_t* row_order, void* stream);
+
+/* row_order[b*block_rows + i] = the global number of the row of block b with the i-th most edges (ties: lower row first).
+ * A property of the graph (one launch per graph, reused by every layer and call); block_rows <= 16384, else GNNPN_E_UNSUP.
+ * No counterpart in the reference: scheduling input of gnnpn_csr_aggregate_blocks_f32. */
+int gnnpn_csr_block_row_order(const int32_t* rowptr, int32_t n_rows, int32_t block_rows, int32_t* row_order, void* stream);
 
 /* GCN symmetric normalisation on a destination-major CSR that already contains one self-loop
  * entry per node (add_remaining_self_loops, fill 1): deg[i] = sum of w_raw over row i (CSR order),

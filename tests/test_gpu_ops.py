@@ -352,12 +352,31 @@ def test_csr_aggregate_lds_staged_equals_gather(dev, S, copies, C, weighted, sel
         dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), dev_ptr(w, torch.float32, "w", True),
         dev_ptr(x, torch.float32, "x"), C, dev_ptr(eps, torch.float32, "eps", True), dev_ptr(bias, torch.float32, "b"),
         dev_ptr(scale, torch.float32, "s"), dev_ptr(shift, torch.float32, "t"), ops.ACT_RELU, dev_ptr(y, torch.float32, "y"),
-        C, n, C, S, stream_ptr())
+        C, n, C, S, None, stream_ptr())
     check(rc, "gnnpn_csr_aggregate_blocks_f32")
     assert torch.equal(y, want)
+    # the same with the block's rows dealt by descending degree (gnnpn_csr_block_row_order): a schedule, not a result
+    order = ops.csr_block_row_order(rp, S)
+    deg = (rp[1:] - rp[:-1]).cpu()
+    o = order.cpu().long()
+    for b in range(0, n, S):
+        blk = o[b:min(b + S, n)]
+        assert sorted(blk.tolist()) == list(range(b, min(b + S, n)))             # a permutation of the block's rows
+        d = deg[blk]
+        assert bool((d[1:] <= d[:-1]).all())                                    # by descending edge count
+        same = d[1:] == d[:-1]
+        assert bool((blk[1:][same] > blk[:-1][same]).all())                     # ties: lower row first
+    y2 = torch.full_like(x, float("nan"))
+    rc = _lib.load().gnnpn_csr_aggregate_blocks_f32(
+        dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), dev_ptr(w, torch.float32, "w", True),
+        dev_ptr(x, torch.float32, "x"), C, dev_ptr(eps, torch.float32, "eps", True), dev_ptr(bias, torch.float32, "b"),
+        dev_ptr(scale, torch.float32, "s"), dev_ptr(shift, torch.float32, "t"), ops.ACT_RELU, dev_ptr(y2, torch.float32, "y"),
+        C, n, C, S, dev_ptr(order, torch.int32, "order"), stream_ptr())
+    check(rc, "gnnpn_csr_aggregate_blocks_f32")
+    assert torch.equal(y2, want)
     rc = _lib.load().gnnpn_csr_aggregate_blocks_f32(
         dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), None, dev_ptr(x, torch.float32, "x"), C, None, None, None,
-        None, 0, dev_ptr(y, torch.float32, "y"), C, n, C, 20000, stream_ptr())
+        None, 0, dev_ptr(y, torch.float32, "y"), C, n, C, 20000, None, stream_ptr())
     assert rc == -2                                               # a block that cannot fit the LDS is refused (GNNPN_E_UNSUP)
 
 
