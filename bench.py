@@ -20,7 +20,9 @@ Steps rotate over --batches (default 4) distinct resident batches per rank.
 
 Extra objects on the line:
   roofline     : the dominant kernel by time, priced against the bound that applies to it
-  kernels      : every timed kernel of the step (avg ms, algorithmic bytes/flops, fraction of peak)
+  kernels      : every timed kernel of the step (avg ms, algorithmic bytes/flops, fraction of peak), plus — marked
+                 "in_step": false — the GCN aggregate on the reference's batching of the service graph (B copies),
+                 which the step does not run (cached service embedding) but the north star prices against HBM
   cpu_baseline : the CPU oracle (oracle/, a torch-CPU port of the reference algorithm) timed on this
                  box's host cores over a bounded sample of the same workload (rank 0, N=1 only)
   split_operands : a second measurement of the same workload with precision="split" (the recurrent W_hh.h
@@ -182,6 +184,41 @@ def cpu_baseline(w, table, pb, net, low, high, budget_s=12.0):
 
 
 REAL_STDOUT = 1
+
+
+def batched_aggregate_roofline(table, B, dev, reps=10):
+    """The GCN aggregate on the reference's own batching of the service graph (B block-diagonal copies of the table,
+    trainML.py:109-114, modelML.py:145-156): one layer, 256 channels, through ops.csr_aggregate (the LDS-staged kernel where
+    a copy's 16-channel slice fits the LDS, else the L2 gather kernel).  NOT part of the step (the step uses the cached
+    service embedding): reported in ``kernels`` with "in_step": false so that the north star's aggregate roofline has a
+    number in this line.  HIP events on the stream the launches go to (torch's current stream), best of 3 rounds."""
+    from gnnpn_sc_amd import graph, ops
+    S = table.n_services
+    copies = max(1, min(B, 256, 700_000 // S))
+    csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
+    nnz = csr.col.numel()
+    rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
+    col = torch.cat([csr.col.long() + c * S for c in range(copies)]).int().to(dev)
+    norm = ops.gcn_norm(rp, col, csr.w.repeat(copies).to(dev))
+    N, C = copies * S, 256
+    x = torch.randn(N, C, device=dev)
+    bias = torch.zeros(C, device=dev)
+    run = lambda: ops.csr_aggregate(rp, col, norm, x, bias=bias, act=ops.ACT_RELU, block_rows=S)   # noqa: E731
+    best = float("inf")
+    for rnd in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        if rnd:
+            best = min(best, e0.elapsed_time(e1) / reps)
+    work = 2 * N * C * 4 + copies * nnz * 8 + (N + 1) * 4             # SURVEY section 8d per graph, times the copies
+    form = "lds-staged" if S <= ops.LDS_SLICE16_ROWS_MAX and copies * (C // 16) >= ops.LDS_MIN_WORKGROUPS else "l2-gather"
+    return {"kernel": "csr_aggregate_batched", "in_step": False, "form": form, "copies": copies, "rows": N, "edges": copies * nnz,
+            "launches_per_step": 0, "avg_ms": round(best, 4), "bound": "hbm", "achieved": round(work / best / 1e6, 3),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(work / best / 1e6 / PEAK_HBM_GBS, 5)}
 
 
 def self_launch(n):
@@ -496,6 +533,15 @@ def main():
         pass
     for k in kernels:
         k["traffic"] = traffic.get(k["kernel"])
+    if world == 1 and args.graph and not args.no_kernel_timers:
+        agg = batched_aggregate_roofline(table, B, dev)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_csr_aggregate_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            agg["traffic"] = (pm["kernels"]["lds" if agg["form"] == "lds-staged" else "gather"]["traffic"]
+                              if (agg["rows"], agg["edges"]) == (641792, 21173504) else None)
+        except (OSError, ValueError, KeyError):
+            agg["traffic"] = None
     roof = None
     if kernels:
         k0 = kernels[0]
@@ -520,7 +566,7 @@ def main():
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}",
                    **({"NOT_A_MEASUREMENT": "GNNPN_BENCH_SHARE_GPU=1: all ranks share one GPU over gloo (launch-path check)"}
                       if share else {})},
-        "roofline": roof, "kernels": kernels,
+        "roofline": roof, "kernels": kernels + ([agg] if world == 1 and args.graph and not args.no_kernel_timers else []),
     }
     if agreement is not None:
         line["agreement_vs_f32"] = agreement
