@@ -243,11 +243,11 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     }
                 }
                 if (stamps) st[1] = phase_stamp();
-                __syncthreads();
-                if (abort_flag) break;
 
                 // ---- logits, softmax and first-max argmax inside the wave: wave w owns rows 4w..4w+3,
                 // 16 lanes per row, lane = candidate (K <= 16).  Row-wide max / sum by DPP rotations.
+                // No workgroup barrier in front of it: the partial dots and latent logits of these rows were staged by
+                // THIS wave; the h tile of the other waves is first needed by the MFMAs behind the barrier below.
                 {
                     const int row = wave * 4 + kq, b = b0 + row, r = c;
                     const bool live = r < K;
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                         }
                     }
                 }
-                __syncthreads();
+                __syncthreads();   // the h tile of every wave and sel[] are complete
+                if (abort_flag) break;
                 if constexpr (FOLDX) {
                     // raw 8-feature row of the pick as MFMA A-fragments (row c), in flight under the W_hh.h MFMAs.
                     // Unconditional loads (row clamped, zeroed at the use): a branch here makes the compiler wait
