@@ -380,6 +380,36 @@ def test_csr_aggregate_lds_staged_equals_gather(dev, S, copies, C, weighted, sel
     assert rc == -2                                               # a block that cannot fit the LDS is refused (GNNPN_E_UNSUP)
 
 
+def test_csr_aggregate_picks_the_lds_form_for_block_local_graphs(dev):
+    """ops.csr_aggregate with the caller's block_rows promise: the LDS-staged kernel where a block takes 16-channel slices
+    and there are enough (block, slice) workgroups, the gather kernel otherwise or when forced — the same bits every way."""
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    S, copies, C = 600, 9, 256
+    table = synth.make_service_table(5, S, 3, degree=10)
+    csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
+    nnz = csr.col.numel()
+    rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
+    col = torch.cat([csr.col.long() + c * S for c in range(copies)]).int().to(dev)
+    w = ops.gcn_norm(rp, col, csr.w.repeat(copies).to(dev))
+    x = torch.randn(copies * S, C, generator=torch.Generator().manual_seed(1)).to(dev)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(2)).to(dev)
+    saved = ops.PREFER_LDS_AGGREGATE
+    try:
+        ops.PREFER_LDS_AGGREGATE = False
+        want = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)
+        ops.PREFER_LDS_AGGREGATE = None                               # default: 9 blocks x 16 slices = 144 workgroups -> LDS form
+        got = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)
+        assert id(rp) in ops._row_orders                              # the LDS form ran (it computed and cached the row order)
+        assert torch.equal(got, want)
+        ops.PREFER_LDS_AGGREGATE = True
+        assert torch.equal(ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S), want)
+        assert torch.equal(ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU), want)      # no promise: gather form
+    finally:
+        ops.PREFER_LDS_AGGREGATE = saved
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation
