@@ -277,23 +277,42 @@ __device__ __forceinline__ u64 phase_stamp() {
     return t;
 }
 
+// fp32 h tile in k-quarter-major order: unit u = 4*kk + kq of row r sits at r*LDT + kq*64 + kk, so the A-fragments of lane
+// (c, kq) for the k-steps kk = 0..63 are 64 CONSECUTIVE floats: 16 ds_read_b128 per chain pass instead of 64 ds_read_b32
+// (their issue cost sits in the MFMA phase — fp32 MFMAs share the SIMD's datapath with every other instruction the wave
+// issues, tools/probes/mfma_valu_coissue.hip).  LDT = 260: the 16 lanes of a ds_read_b128 group hold 16 different rows c,
+// whose 4-float reads start 4*c banks apart — conflict-free; a sweep's two stores per granule pair (units u, u+1: 64 floats
+// apart) are 2-way on 32 banks, which costs a ds_write_b32 nothing.
+constexpr int LDT = 260;
+__device__ __forceinline__ int ht_index(int row, int unit) { return row * LDT + (unit & 3) * 64 + (unit >> 2); }
+
 // Two k-ordered fp32 MFMA chains (one per 16-column tile) over K = 256 against A-fragments read from
-// an LDS tile `src` (row c, stride LDH, element 4*kk + kq).  The A-fragments are fetched 16 k-steps
-// ahead of the MFMAs that use them: left to itself hipcc issues each ds_read right before the MFMAs
-// that need it and waits ~70 cycles per 4 MFMAs (measured 6.3k instead of 4.1k cycles per step).
-template <int LDH, int CH = 16>   // CH: prefetch depth in k-steps (8 where registers are short: 2 x CH fragment registers)
+// an LDS tile `src`: row-major (row c, stride LD, element 4*kk + kq) or, KQ, the k-quarter-major h tile above.
+// The A-fragments are fetched CH k-steps ahead of the MFMAs that use them: left to itself hipcc issues each
+// ds_read right before the MFMAs that need it and waits ~70 cycles per 4 MFMAs (measured 6.3k instead of 4.1k
+// cycles per step).
+template <int LD, int CH = 16, bool KQ = false>   // CH: prefetch depth in k-steps (8 where registers are short: 2 x CH fragment registers)
 __device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq, const float (&w0)[64],
                                                 const float (&w1)[64], f32x4& acc0, f32x4& acc1) {
-    const float* base = src + c * LDH + kq;
+    const float* base = KQ ? src + c * LD + kq * 64 : src + c * LD + kq;
+    const float4* base4 = reinterpret_cast<const float4*>(base);       // KQ: 16-byte aligned (LD * 4 and kq * 256 are)
     float a[2][CH];
+    auto fetch = [&](int ch, float (&dst)[CH]) {
+        if constexpr (KQ) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) a[0][i] = base[4 * i];
+            for (int q = 0; q < CH / 4; ++q) {
+                const float4 v = base4[(CH / 4) * ch + q];
+                dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) dst[i] = base[4 * (CH * ch + i)];
+        }
+    };
+    fetch(0, a[0]);
 #pragma unroll
     for (int ch = 0; ch < 64 / CH; ++ch) {
-        if (ch < 64 / CH - 1) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) a[(ch + 1) & 1][i] = base[4 * (CH * (ch + 1) + i)];
-        }
+        if (ch < 64 / CH - 1) fetch(ch + 1, a[(ch + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {

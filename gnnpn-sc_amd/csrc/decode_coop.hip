@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                      int n_nets, int groups_per_net, int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (k-quarter-major, stride LDT) | fp16 hi + lo tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
         for (int j = 0; j < ROWS; ++j) {
             const float h0v = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
             if constexpr (SPLIT) split_store(reinterpret_cast<_Float16*>(hs) + j * LDH16 + tid, h0v);
-            else hs[j * LDH + tid] = h0v;
+            else hs[ht_index(j, tid)] = h0v;
             if (!FOLDX) xs[j * LDH + tid] = net.start[tid];
         }
         __syncthreads();
@@ -221,8 +221,9 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                             split_store(h16, __uint_as_float(vh[j].x));
                             split_store(h16 + 1, __uint_as_float(vh[j].z));
                         } else {
-                            *reinterpret_cast<float2*>(&hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)]) =
-                                make_float2(__uint_as_float(vh[j].x), __uint_as_float(vh[j].z));
+                            float* d = &hs[ht_index(wave * 4 + (i >> 8), i & 255)];   // units i, i+1: 64 floats apart
+                            d[0] = __uint_as_float(vh[j].x);
+                            d[64] = __uint_as_float(vh[j].z);
                         }
                     }
 #pragma unroll
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                 ah0 = acc[0];
                 ah1 = acc[1];
             } else {
-                mfma_chain_pair<LDH, OCC == 2 ? 8 : 16>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah0, ah1);
+                mfma_chain_pair<LDT, OCC == 2 ? 8 : 16, true>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah0, ah1);
             }
             if (stamps) {
                 asm volatile("" ::"v"(ah0[0]), "v"(ah1[0]));

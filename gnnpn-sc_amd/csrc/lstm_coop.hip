@@ -27,7 +27,6 @@ constexpr int H = 256;
 constexpr int G = 8;              // workgroups per group
 constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
-constexpr int LDH = 258;          // LDS row stride: (row*2 + kq) distinct banks for ds_read_b32
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + 64 spare
 }  // namespace
@@ -63,8 +62,9 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
         for (int j = 0; j < 8; ++j) {
             const int i = 2 * (j * 64 + lane);      // 0..1022 (even) within the quarter; i and i+1 share a row
             if constexpr (PREC == 0) {
-                *reinterpret_cast<float2*>(&hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)]) =
-                    make_float2(__uint_as_float(v[j].x), __uint_as_float(v[j].z));
+                float* d = &hs[ht_index(wave * 4 + (i >> 8), i & 255)];       // units i, i+1: 64 floats apart (coop_common.h)
+                d[0] = __uint_as_float(v[j].x);
+                d[64] = __uint_as_float(v[j].z);
             } else {
                 _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
                 if constexpr (PREC == 2) {
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                                                                   int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi tile + lo tile (stride LDH16 halfs)
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (k-quarter-major, stride LDT) | fp16 hi tile + lo tile (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
     __shared__ int abort_flag;
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                     }
                 }
             } else {
-                if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDH>(hs, c, kq, wB[0], wB[F16 ? 0 : 1], acc0, acc1);
+                if (t > 0 && !(ablate & 1)) mfma_chain_pair<LDT, 16, true>(hs, c, kq, wB[0], wB[F16 ? 0 : 1], acc0, acc1);
             }
             if (t + 1 < L && !(ablate & 0x400)) load_input(t + 1, pg_next, ax_next);
             // Issued BEHIND the MFMA stream (they would otherwise sit in front of it: measured 1.3k cycles per
@@ -379,19 +379,23 @@ __device__ __forceinline__ f32x2 cell_act_tanh_sigmoid(f32x2 x) {
     const float small = fmaf(__fmul_rn(ax, x2), p, ax);
     return f32x2{copysignf(ax < 0.25f ? small : big, x.x), r.y};
 }
-// one k-ordered fp32 MFMA chain over K = 256 (A-fragments prefetched CH k-steps ahead, as mfma_chain_pair)
-template <int LDH_, int CH = 16>
+// one k-ordered fp32 MFMA chain over K = 256 against the k-quarter-major h tile (A-fragments prefetched CH k-steps ahead,
+// as mfma_chain_pair)
+template <int LD, int CH = 16>
 __device__ __forceinline__ void mfma_chain_single(const float* src, int c, int kq, const float (&w)[64], f32x4& acc) {
-    const float* base = src + c * LDH_ + kq;
+    const float4* base4 = reinterpret_cast<const float4*>(src + c * LD + kq * 64);
     float a[2][CH];
+    auto fetch = [&](int ch, float (&dst)[CH]) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) a[0][i] = base[4 * i];
+        for (int q = 0; q < CH / 4; ++q) {
+            const float4 v = base4[(CH / 4) * ch + q];
+            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        }
+    };
+    fetch(0, a[0]);
 #pragma unroll
     for (int ch = 0; ch < 64 / CH; ++ch) {
-        if (ch < 64 / CH - 1) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) a[(ch + 1) & 1][i] = base[4 * (CH * (ch + 1) + i)];
-        }
+        if (ch < 64 / CH - 1) fetch(ch + 1, a[(ch + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w[CH * ch + i], acc, 0, 0, 0);
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets net
                                                                     unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                     int32_t B, int32_t L, int n_nets, int groups_per_net,
                                                                     int gpx, int write_through, unsigned* __restrict__ seats) {
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH];
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDT];      // k-quarter-major (coop_common.h)
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS16];   // own h slice, staged for 64-B row stores
     __shared__ int abort_flag;
     __shared__ int place[2];
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets net
             px = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX1, px, 0, 0, 0);
             bool ok = true;
             if (t == 0) {
-                for (int i = threadIdx.x; i < ROWS * LDH; i += 256) hs[i] = 0.0f;
+                for (int i = threadIdx.x; i < ROWS * LDT; i += 256) hs[i] = 0.0f;
                 if (!first_tile) ok = sweep_quarter<0>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
             } else {
                 ok = sweep_quarter<0>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true);
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets net
             __syncthreads();
             if (abort_flag) break;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0) mfma_chain_single<LDH, 8>(hs, c, kq, wB, acc);
+            if (t > 0) mfma_chain_single<LDT, 8>(hs, c, kq, wB, acc);
             if (t + 1 < L) load_input(t + 1, ax_next);
             if (t > 0 && threadIdx.x < ROWS * 4) {       // enc_out of the previous step: 64 B per problem row
                 const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
