@@ -52,6 +52,22 @@ __device__ __forceinline__ void granule_reload2_x8(u32x4 (&v)[8], const u64* bas
                  : "v"(voff), "s"(base), "s"(q)
                  : "memory");
 }
+// the same with the lane mask applied INSIDE the statement (s_and_saveexec ... restore): unconditional at the source level,
+// operands tied in place — a sweep loop built on this one statement keeps its 32 registers where they are (a separate
+// first-pass load, or this load under an `if`, made the register allocator copy all of them every step)
+__device__ __forceinline__ void granule_reload2_x8_masked(u32x4 (&v)[8], const u64* base, unsigned voff, unsigned long long lanes) {
+    const u64* q = base + 512;
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %8, %12\n\t"
+                 GNNPN_LD2("%0", "%9", "%10", "0") GNNPN_LD2("%1", "%9", "%10", "1024") GNNPN_LD2("%2", "%9", "%10", "2048")
+                 GNNPN_LD2("%3", "%9", "%10", "3072") GNNPN_LD2("%4", "%9", "%11", "0") GNNPN_LD2("%5", "%9", "%11", "1024")
+                 GNNPN_LD2("%6", "%9", "%11", "2048") GNNPN_LD2("%7", "%9", "%11", "3072")
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %8"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "=&s"(saved)
+                 : "v"(voff), "s"(base), "s"(q), "s"(lanes)
+                 : "memory", "scc");
+}
 // 8 pairs at `base` (h quarter) and NP pairs at `pbase` (partial dots), one wait
 __device__ __forceinline__ void granule_load2_x8_x2(u32x4 (&v)[8], u32x4 (&w)[2], const u64* base, const u64* pbase, unsigned voff) {
     const u64* q = base + 512;

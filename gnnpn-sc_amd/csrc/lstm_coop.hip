@@ -39,23 +39,25 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
     const u64* src = uniform_ptr(buf + wave * 4 * H);      // group, parity, wave: uniform over the wave
     const unsigned voff = 16u * lane;
     u32x4 v[8];                                              // granules 2*(64 j + lane), +1: {value, tag, value, tag}
-    granule_load2_x8(v, src, voff);
-    bool bad = false;                                        // this lane is still missing a tag
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
-    // The first pass is optimistic (peers run in lock step, so it normally succeeds).  If it does not, only the LANES that
-    // miss something re-read (a late member's 32 units sit in 16 lanes of the wave), between naps — not the whole quarter
-    // (with two launches sharing the CUs, full re-sweeps swamp the L2 and slow the very peers it waits for).
+    for (int j = 0; j < 8; ++j) asm volatile("" : "=v"(v[j]));   // "defined" without an instruction: the loop below owns the registers
+    // ONE load statement in ONE loop (its operands tied in place): with a first-pass load and a separate re-read statement the
+    // register allocator copied all 32 registers twice per step to merge the two.  The first pass is optimistic (peers run in
+    // lock step, so it normally succeeds).  If it does not, only the LANES that miss something re-read (a late member's 32
+    // units sit in 16 lanes of the wave), between naps — not the whole quarter (with two launches sharing the CUs, full
+    // re-sweeps swamp the L2 and slow the very peers it waits for).
+    bool bad = true;                                         // this lane is still missing a tag
     unsigned spins = 0;
     int nap = 1;
-    while (__any(bad) && !nowait) {
-        if (++spins > SPIN_LIMIT) return false;
-        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
-        if (nap < 16) nap <<= 1;
-        if (bad) granule_reload2_x8(v, src, voff);
+    for (;;) {
+        granule_reload2_x8_masked(v, src, voff, __ballot(bad));
         bad = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
+        if (!__any(bad) || nowait) break;
+        if (++spins > SPIN_LIMIT) return false;
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+        if (nap < 16) nap <<= 1;
     }
     if (keep) {
 #pragma unroll
