@@ -95,6 +95,39 @@ __device__ __forceinline__ void granule_load2_x8_x4(u32x4 (&v)[8], u32x4 (&w)[4]
                  : "memory");
 }
 
+// ... and ONE more granule per lane at `lbase` + 8 * lane (the Low net's window logits, read by the High net): in the same
+// statement, so that it shares the sweep's round trip — as a separate load behind the statement's wait it cost the High net
+// a second, dependent L2 round trip every step.  Lanes beyond the window read on (inside the workspace: COOP_OVERREAD_BYTES).
+__device__ __forceinline__ void granule_load2_x8_x2_lat(u32x4 (&v)[8], u32x4 (&w)[2], u64& lat, const u64* base, const u64* pbase,
+                                                        const u64* lbase, unsigned voff) {
+    const u64* q = base + 512;
+    asm volatile(GNNPN_LD2("%0", "%11", "%13", "0") GNNPN_LD2("%1", "%11", "%13", "1024") GNNPN_LD2("%2", "%11", "%13", "2048")
+                 GNNPN_LD2("%3", "%11", "%13", "3072") GNNPN_LD2("%4", "%11", "%14", "0") GNNPN_LD2("%5", "%11", "%14", "1024")
+                 GNNPN_LD2("%6", "%11", "%14", "2048") GNNPN_LD2("%7", "%11", "%14", "3072")
+                 GNNPN_LD2("%8", "%11", "%15", "0") GNNPN_LD2("%9", "%11", "%15", "1024")
+                 "global_load_dwordx2 %10, %12, %16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(w[0]), "=&v"(w[1]), "=&v"(lat)
+                 : "v"(voff), "v"(voff >> 1), "s"(base), "s"(q), "s"(pbase), "s"(lbase)
+                 : "memory");
+}
+__device__ __forceinline__ void granule_load2_x8_x4_lat(u32x4 (&v)[8], u32x4 (&w)[4], u64& lat, const u64* base, const u64* pbase,
+                                                        const u64* lbase, unsigned voff) {
+    const u64* q = base + 512;
+    asm volatile(GNNPN_LD2("%0", "%13", "%15", "0") GNNPN_LD2("%1", "%13", "%15", "1024") GNNPN_LD2("%2", "%13", "%15", "2048")
+                 GNNPN_LD2("%3", "%13", "%15", "3072") GNNPN_LD2("%4", "%13", "%16", "0") GNNPN_LD2("%5", "%13", "%16", "1024")
+                 GNNPN_LD2("%6", "%13", "%16", "2048") GNNPN_LD2("%7", "%13", "%16", "3072")
+                 GNNPN_LD2("%8", "%13", "%17", "0") GNNPN_LD2("%9", "%13", "%17", "1024") GNNPN_LD2("%10", "%13", "%17", "2048")
+                 GNNPN_LD2("%11", "%13", "%17", "3072")
+                 "global_load_dwordx2 %12, %14, %18 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(lat)
+                 : "v"(voff), "v"(voff >> 1), "s"(base), "s"(q), "s"(pbase), "s"(lbase)
+                 : "memory");
+}
+
 // A failed bounded wait: the launch's own status word (zeroed by every launch) and the caller's sticky word
 // (never cleared by the library), see gnnpn_launch_opts_t.sticky_status.
 __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsigned code) {

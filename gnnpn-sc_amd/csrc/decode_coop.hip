@@ -194,12 +194,15 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                         bool good = true;
                         // pairs of this lane beyond n_p (K < 8 / K < 16) are loaded and never looked at: they lie at most
                         // 4 KB past this wave's segment, inside the workspace (COOP_OVERREAD_BYTES of slack at its end)
-                        if constexpr (NPJ2 == 2) granule_load2_x8_x2(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
-                        else granule_load2_x8_x4(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
-                        if (latent_in_launch && lane < n_l) {
-                            const u64 x = granule_load(src_l + lane);
+                        if (latent_in_launch) {   // Low's window logits ride the same statement (one round trip, not two)
+                            u64 x;
+                            if constexpr (NPJ2 == 2) granule_load2_x8_x2_lat(vh, vp, x, uniform_ptr(src_h), uniform_ptr(src_p), uniform_ptr(src_l), 16u * lane);
+                            else granule_load2_x8_x4_lat(vh, vp, x, uniform_ptr(src_h), uniform_ptr(src_p), uniform_ptr(src_l), 16u * lane);
                             vl = (unsigned)x;
-                            good &= (unsigned)(x >> 32) == 1u;
+                            good &= (lane >= n_l) | ((unsigned)(x >> 32) == 1u);
+                        } else {
+                            if constexpr (NPJ2 == 2) granule_load2_x8_x2(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
+                            else granule_load2_x8_x4(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
                         }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) good &= (vh[j].y == tag) & (vh[j].w == tag);
