@@ -63,10 +63,11 @@ __device__ __forceinline__ void decode_diag_record(int group, int member, int ti
 // max / sum over each row of 16 lanes by DPP rotations (every lane ends with the row's result)
 __device__ __forceinline__ int ror16(int v, int n) {
     switch (n) {
-        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
-        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);
-        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);
-        default: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);
+        // (a rotation has a source for every lane: bound_ctrl only spares the compiler an `old = 0` move per use)
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, true);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, true);
+        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);
     }
 }
 
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                 {
                     const int row = wave * 4 + kq, b = b0 + row, r = c;
                     const bool live = r < K;
+                    const float lv = lat[row][r];   // read beside the partial dots (r < KMAX: in range; used only where live)
                     float dot = 0.0f;
                     if (live) {
                         // the G members' partial dots of (row, candidate) are contiguous: two 16-byte LDS reads
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                         if (publishes_latent)
                             granule_store(xl + (((size_t)tile * T + (k - 1)) * ROWS + row) * K + r, 1u, v);
                     }
-                    if (has_lat && live) v = __fadd_rn(v, lat[row][r]);
+                    v = (has_lat && live) ? __fadd_rn(v, lv) : v;
                     // key: larger logit wins, ties -> lower candidate index (torch.max returns the first)
                     const unsigned hi = live ? float_order_key(v) : 0u;
                     unsigned long long key = ((unsigned long long)hi << 32) | (unsigned)(15 - r);
