@@ -284,10 +284,10 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                         key = o > key ? o : key;
                     }
                     const int best_r = 15 - (int)(key & 0xffffffffu);
-                    // best logit value = the winner's v: fetch it by one more rotation-reduce (max of v)
-                    float best = live ? v : -INFINITY;
-#pragma unroll
-                    for (int n = 1; n <= 8; n <<= 1) best = fmaxf(best, __int_as_float(ror16(__float_as_int(best), n)));
+                    // best logit value = the winner's v: the inverse of its order key (the map is a bijection; a second
+                    // rotation-reduce for the maximum cost four more dependent DPP stages per step)
+                    const unsigned bkey = (unsigned)(key >> 32);
+                    const float best = __uint_as_float((bkey & 0x80000000u) ? (bkey ^ 0x80000000u) : ~bkey);
                     float e = live ? expf(__fsub_rn(v, best)) : 0.0f;
                     const float e_own = e;
 #pragma unroll
