@@ -65,7 +65,8 @@ def csr_block_row_order(rowptr, block_rows):
     order = torch.empty(n, dtype=I32, device=rowptr.device)
     check(_lib.load().gnnpn_csr_block_row_order(dev_ptr(rowptr, I32, "rowptr"), n, int(block_rows), dev_ptr(order, I32, "order"),
                                                 stream_ptr()), "gnnpn_csr_block_row_order")
-    _row_orders[key] = (weakref.ref(rowptr, lambda _, k=key: _row_orders.pop(k, None)), block_rows, order)
+    if not torch.cuda.is_current_stream_capturing():      # memory of a capture's private pool must not outlive the graph
+        _row_orders[key] = (weakref.ref(rowptr, lambda _, k=key: _row_orders.pop(k, None)), block_rows, order)
     return order
 
 
