@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec; 6.29 TB/s is the measured copy ceiling
 PEAK_F32_TFLOPS = 157.3        # fp32 matrix (= fp32 vector) dense peak
+PEAK_F16_TFLOPS = 2500.0       # fp16 / bf16 MFMA dense peak (never the 2:1-sparsity figure)
 
 WORKLOADS = {
     # name: T, K, S, per-GPU batch, task nodes per problem, GCN layers   
@@ -73,12 +74,18 @@ def build_models(T, S, K, dev, n_gcn=2, hidden_pn=256, seed=0):
     return net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval()
 
 
-def algorithmic_cost(name, w, B):
+def algorithmic_cost(name, w, B, precision="f32"):
     """Algorithmic bytes / flops of ONE launch of each timed kernel."""
     T, K, H = w["T"], w["K"], 256
     L = T * K
-    if name == "lstm_encode":       # both nets in one launch: recurrent matmul flops
-        return dict(bound="mfma", work=2 * B * L * 2 * H * 4 * H, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
+    if name == "lstm_encode":       # both nets in one launch: recurrent matmul flops, priced against the matrix peak of the
+        # operand type the products run in: fp32 MFMA | fp16 MFMA (f16: one product; split: three fp16 products per term)
+        flops = 2 * B * L * 2 * H * 4 * H
+        if precision == "f16":
+            return dict(bound="mfma", work=flops, unit="TFLOP/s", peak=PEAK_F16_TFLOPS)
+        if precision == "split":
+            return dict(bound="mfma", work=3 * flops, unit="TFLOP/s", peak=PEAK_F16_TFLOPS)
+        return dict(bound="mfma", work=flops, unit="TFLOP/s", peak=PEAK_F32_TFLOPS)
     if name == "pointer_decode":    # BOTH nets in one launch; per net and problem exactly SURVEY.md section 8d's "PN decode,
         # one problem, one net": every enc_out row once (L*H*4) + per-step state T*(2*H*4) + outputs T*(8 + K*4)
         byt = 2 * B * (L * H * 4 + T * (2 * H * 4) + T * (8 + K * 4))
@@ -516,7 +523,7 @@ def main():
     value = world * B * args.steps / elapsed
     kernels = []
     for name, (avg_ms, n) in sorted(timers.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-        c = algorithmic_cost(name, w, B)
+        c = algorithmic_cost(name, w, B, args.precision)
         achieved = c["work"] / (avg_ms * 1e-3) / (1e12 if c["bound"] == "mfma" else 1e9)
         kernels.append({"kernel": name, "launches_per_step": n // n_timed, "avg_ms": round(avg_ms, 4),
                         "bound": c["bound"], "achieved": round(achieved, 3), "peak": c["peak"], "unit": c["unit"],
