@@ -134,6 +134,64 @@ def test_segment_mean(dev):
     assert torch.equal(out, oml.scatter_mean(x, batch, len(sizes)))
 
 
+@pytest.mark.parametrize("C", [100, 1, 64, 200])
+def test_segment_mean_ragged_channels_and_long_segments(dev, C):
+    """One wave per (segment, 64-channel chunk), 8 row loads in flight: channel counts that are no multiple of 64, segments
+    longer and shorter than the 8-row unroll, empty segments — the node-order sums of the oracle's scatter_mean, bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(40 + C)
+    sizes = [1001, 0, 8, 9, 7, 0, 16, 1, 333]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    x = torch.randn(sum(sizes), C, generator=g)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    out = ops.segment_mean(ptr.to(dev), x.to(dev)).cpu()
+    assert torch.equal(out, oml.scatter_mean(x, batch, len(sizes)))
+
+
+@pytest.mark.parametrize("S,copies,C,weighted", [(700, 10, 256, True), (2559, 9, 64, True), (333, 40, 128, False)])
+def test_csr_aggregate_lds_staged_skewed_degrees(dev, S, copies, C, weighted):
+    """The LDS-staged aggregate on block-diagonal copies of a graph with a heavy-tailed degree distribution: rows without
+    edges, rows with hundreds of them (many 16-edge batches, the tail groups of 4), the last rows' lists ending at the
+    arrays' end (the guarded fetch path), the largest block that takes 16-channel slices (S = 2559) — with the rows dealt by
+    descending degree and as they come, against the one-wave-per-row gather kernel: the same bits."""
+    from gnnpn_sc_amd import _lib
+    from gnnpn_sc_amd._lib import check, dev_ptr, stream_ptr
+    ops = _ops()
+    g = torch.Generator().manual_seed(S + copies)
+    deg = torch.zeros(S, dtype=torch.long)
+    heavy = torch.randperm(S, generator=g)[: max(3, S // 40)]
+    deg[:] = torch.randint(0, 9, (S,), generator=g)
+    deg[heavy] = torch.randint(60, 400, (heavy.numel(),), generator=g)
+    deg[torch.randperm(S, generator=g)[: S // 10]] = 0
+    deg[S - 1] = 3                                                     # a short list at the very end of the arrays
+    rp1 = torch.zeros(S + 1, dtype=torch.long)
+    rp1[1:] = torch.cumsum(deg, 0)
+    nnz = int(rp1[-1])
+    col1 = torch.randint(0, S, (nnz,), generator=g)
+    w1 = torch.rand(nnz, generator=g) + 0.25
+    rp = torch.cat([rp1[:-1] + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
+    col = torch.cat([col1 + c * S for c in range(copies)]).int().to(dev)
+    w = w1.repeat(copies).to(dev) if weighted else None
+    n = copies * S
+    x = torch.randn(n, C, generator=g).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    saved = ops.PREFER_LDS_AGGREGATE
+    try:
+        ops.PREFER_LDS_AGGREGATE = False
+        want = ops.csr_aggregate(rp, col, w, x, bias=bias, act=ops.ACT_RELU)
+    finally:
+        ops.PREFER_LDS_AGGREGATE = saved
+    order = ops.csr_block_row_order(rp, S)
+    for o in (order, None):
+        y = torch.full_like(x, float("nan"))
+        check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
+            dev_ptr(rp, torch.int32, "rp"), dev_ptr(col, torch.int32, "col"), dev_ptr(w, torch.float32, "w", True),
+            dev_ptr(x, torch.float32, "x"), C, None, dev_ptr(bias, torch.float32, "b"), None, None, ops.ACT_RELU,
+            dev_ptr(y, torch.float32, "y"), C, n, C, S, dev_ptr(o, torch.int32, "order", True), stream_ptr()),
+            "gnnpn_csr_aggregate_blocks_f32")
+        assert torch.equal(y, want)
+
+
 @pytest.mark.parametrize("H,B,L", [(32, 5, 18), (256, 3, 40), (256, 9, 235)])
 def test_lstm_encode_vs_torch(dev, H, B, L):
     ops = _ops()
