@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 

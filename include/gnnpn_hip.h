@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 2
+#define GNNPN_ABI_VERSION 3   /* 3: gnnpn_csr_aggregate_blocks_f32 takes a row order; gnnpn_csr_block_row_order */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
