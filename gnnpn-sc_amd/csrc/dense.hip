@@ -21,6 +21,8 @@ struct DenseCfg {
     static constexpr int TN = BN / 64;
 };
 
+struct __attribute__((packed, aligned(4))) f4_align4 { float v[4]; };
+
 // load a [ROWS x 32] tile (rows r0.., k from k0) of a row-major matrix into registers
 template <int NF4>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int64_t r0,
@@ -34,8 +36,9 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < n_rows) {
             const float* src = P + row * ld + k;
-            if (vec_ok && k + 3 < K) {
-                v = *reinterpret_cast<const float4*>(src);
+            if (vec_ok && k + 3 < K) {          // one global_load_dwordx4: needs 4-byte alignment only (rows of 135 floats too)
+                const f4_align4 t = *reinterpret_cast<const f4_align4*>(src);
+                v = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
             } else {
                 if (k + 0 < K) v.x = src[0];
                 if (k + 1 < K) v.y = src[1];
@@ -146,8 +149,7 @@ extern "C" int gnnpn_linear_f32(const float* A, int64_t lda, const float* W, int
     GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "linear: scale and shift go together");
     GNNPN_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
     if (M == 0) return GNNPN_OK;
-    const int vec_a = gnnpn_aligned(A, 16) && (lda % 4 == 0);
-    const int vec_w = gnnpn_aligned(W, 16) && (ldw % 4 == 0);
+    const int vec_a = gnnpn_aligned(A, 4), vec_w = gnnpn_aligned(W, 4);   // 16-byte loads at 4-byte alignment (tile_load)
     hipStream_t s = (hipStream_t)stream;
     // 128x128 tiles only for deep, wide products; everything this path runs (K <= 260) is faster on 64x64 tiles — 7 resident
     // workgroups per CU instead of 2 hide the four short k-tiles' latencies: [512k x 128] x [128 x 128] 301 -> 222 us,
@@ -157,6 +159,10 @@ extern "C" int gnnpn_linear_f32(const float* A, int64_t lda, const float* W, int
         dim3 grid((N + 127) / 128, (unsigned)((M + 127) / 128));
         GNNPN_REQUIRE(grid.y < 65536u * 32768u, "linear: M too large");
         hipLaunchKernelGGL((linear_f32_kernel<128, 128>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, scale,
+                           shift, act, C, ldc, M, N, K, vec_a, vec_w);
+    } else if (N % 128 == 0 && M >= 64 * 512) {   // full-width 64x128 tiles: A is read once per 128 columns (5-15 % over 64x64)
+        dim3 grid(N / 128, (unsigned)((M + 63) / 64));
+        hipLaunchKernelGGL((linear_f32_kernel<64, 128>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, scale,
                            shift, act, C, ldc, M, N, K, vec_a, vec_w);
     } else {
         dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
