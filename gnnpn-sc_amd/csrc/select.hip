@@ -66,6 +66,88 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     }
 }
 
+// The same reduction with 16 lanes per (problem, category) segment, four segments per wave, for n_per <= 16: the row-wide
+// maximum is four DPP rotations instead of six cross-wave shuffles on each key half, and a category of 5 services (the
+// 1000-task shapes) no longer occupies a whole wave.  Same keys, same order of picks, same emitted rows.
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int n = 1; n <= 8; n <<= 1) {
+        const int ctrl = 0x120 + n;                                    // row_ror:n
+        unsigned lo, hi;
+        switch (n) {
+            case 1: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x121, 0xF, 0xF, true);
+                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x121, 0xF, 0xF, true); break;
+            case 2: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x122, 0xF, 0xF, true);
+                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x122, 0xF, 0xF, true); break;
+            case 4: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x124, 0xF, 0xF, true);
+                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x124, 0xF, 0xF, true); break;
+            default: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x128, 0xF, 0xF, true);
+                     hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x128, 0xF, 0xF, true); break;
+        }
+        (void)ctrl;
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void select_candidates16_kernel(
+    const float* __restrict__ scores, int64_t ld_scores, const int32_t* __restrict__ cat_ptr,
+    const double* __restrict__ qos, const double* __restrict__ local_bounds, const uint8_t* __restrict__ present,
+    const double* __restrict__ global_bounds, float* __restrict__ out_rows, int32_t* __restrict__ out_ids,
+    int32_t B, int32_t T, int32_t n_per) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t seg = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    if (seg >= (int64_t)B * T) return;                                  // whole 16-lane rows leave together
+    const int b = (int)(seg / T), c = (int)(seg - (int64_t)b * T);
+    const int s_begin = cat_ptr[c], s_end = cat_ptr[c + 1];
+    const bool pres = present[seg] != 0;
+    const double* lb = local_bounds + seg * 4;
+    const double lo_c = lb[0], hi_c = lb[1], lo_q = lb[2], hi_q = lb[3];
+    const float* srow = scores + (int64_t)b * ld_scores;
+
+    unsigned long long last = ~0ull;
+    int my_pick = -1;   // lane r of the row keeps the r-th pick
+    int n_found = 0;
+    if (pres) {
+        for (int r = 0; r < n_per; ++r) {
+            unsigned long long best = 0ull;
+            for (int s = s_begin + sub; s < s_end; s += 16) {
+                const double cost = qos[(int64_t)s * 4 + 2], qual = qos[(int64_t)s * 4 + 3];
+                const bool feas = lo_c <= cost && cost <= hi_c && lo_q <= qual && qual <= hi_q;
+                const unsigned long long key = rank_key(srow[s], (uint32_t)s);
+                if (feas && key < last && key > best) best = key;
+            }
+            best = row16_max_u64(best);
+            if (best == 0ull) break;
+            if (sub == r) my_pick = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            last = best;
+            ++n_found;
+        }
+    }
+    // emit n_per rows: picks repeated cyclically (loadData.py:137-141), dummy rows otherwise (:148)
+    const int src_lane = (lane & ~15) + (n_found > 0 ? sub % n_found : 0);
+    const int id = __shfl(my_pick, src_lane, 64);
+    if (sub < n_per) {
+        const int64_t pos = (int64_t)b * T * n_per + (int64_t)c * n_per + sub;
+        float4 q, tail = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n_found > 0) {
+            const double* qs = qos + (int64_t)id * 4;
+            q = make_float4((float)qs[0], (float)qs[1], (float)qs[2], (float)qs[3]);
+        } else {
+            q = make_float4(0.f, 1.f, 1.f, 1.f);
+        }
+        if (c == 0) {
+            const double* g = global_bounds + (int64_t)b * 4;
+            tail = make_float4((float)g[0], (float)g[1], (float)g[2], (float)g[3]);
+        }
+        float4* dst = reinterpret_cast<float4*>(out_rows + pos * 8);
+        dst[0] = q;
+        dst[1] = tail;
+        out_ids[pos] = n_found > 0 ? id : -1;
+    }
+}
+
 extern "C" int gnnpn_select_candidates(const float* scores, int64_t ld_scores, const int32_t* cat_ptr,
                                        const double* qos, const double* local_bounds, const uint8_t* present,
                                        const double* global_bounds, float* out_rows, int32_t* out_ids, int32_t B,
@@ -78,9 +160,14 @@ extern "C" int gnnpn_select_candidates(const float* scores, int64_t ld_scores, c
     GNNPN_REQUIRE(gnnpn_aligned(out_rows, 16), "select_candidates: out_rows must be 16-byte aligned");
     if (B == 0) return GNNPN_OK;
     const int64_t n_seg = (int64_t)B * T;
-    hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
-                       out_rows, out_ids, B, T, n_per);
+    if (n_per <= 16)
+        hipLaunchKernelGGL(select_candidates16_kernel, dim3((unsigned)((n_seg + 15) / 16)), dim3(256), 0,
+                           (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
+                           out_rows, out_ids, B, T, n_per);
+    else
+        hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
+                           out_rows, out_ids, B, T, n_per);
     GNNPN_CHECK_LAUNCH("select_candidates");
     return GNNPN_OK;
 }

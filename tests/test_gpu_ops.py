@@ -332,6 +332,38 @@ def test_select_candidates_vs_oracle(dev):
     assert (ids.cpu()[(want[:, :, :4] == torch.tensor([0., 1., 1., 1.])).all(-1)] == -1).all()
 
 
+@pytest.mark.parametrize("K", [1, 5, 16])
+def test_select_candidates_16_lane_form_equals_wave_form(dev, K):
+    """n_per <= 16 runs with 16 lanes per (problem, category) segment (four segments per wave), larger n_per with a whole
+    wave per segment.  The picks are the same sequence, so the first K of a 20-pick selection (emitted cyclically when
+    fewer are feasible) are the K-pick selection: categories of 1..70 services, absent categories, tight and loose bounds,
+    score ties."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(70 + K)
+    sizes = torch.randint(1, 71, (37,), generator=g)
+    sizes[3], sizes[11] = 1, 70
+    cat_ptr = torch.zeros(38, dtype=torch.int32)
+    cat_ptr[1:] = torch.cumsum(sizes, 0).int()
+    S, T, B = int(cat_ptr[-1]), 37, 9
+    qos = torch.rand(S, 4, generator=g, dtype=torch.float64)
+    scores = torch.rand(B, S, generator=g)
+    n7 = scores[:, 1::7].shape[1]
+    scores[:, 0:7 * n7:7] = scores[:, 1::7]                              # ties -> lowest id
+    lo = torch.rand(B, T, 2, generator=g, dtype=torch.float64) * 0.5
+    hi = lo + torch.rand(B, T, 2, generator=g, dtype=torch.float64) * 0.7
+    local = torch.stack([lo[..., 0], hi[..., 0], lo[..., 1], hi[..., 1]], -1).contiguous()
+    local[0, :5] = torch.tensor([0., 1., 0., 1.], dtype=torch.float64)   # everything feasible
+    local[1, :5] = torch.tensor([2., 3., 2., 3.], dtype=torch.float64)   # nothing feasible -> dummy rows
+    present = (torch.rand(B, T, generator=g) > 0.15).to(torch.uint8)
+    glob = torch.rand(B, 4, generator=g, dtype=torch.float64)
+    args = (scores.to(dev), cat_ptr.to(dev), qos.to(dev), local.to(dev), present.to(dev), glob.to(dev))
+    rows_k, ids_k = ops.select_candidates(*args, K)
+    rows_w, ids_w = ops.select_candidates(*args, 20)
+    assert torch.equal(ids_k.view(B, T, K), ids_w.view(B, T, 20)[:, :, :K])
+    assert torch.equal(rows_k.view(B, T, K, 8)[..., :4], rows_w.view(B, T, 20, 8)[:, :, :K, :4])
+    assert torch.equal(rows_k.view(B, T, K, 8)[:, 0, :, 4:], rows_w.view(B, T, 20, 8)[:, 0, :K, 4:])
+
+
 @pytest.mark.parametrize("B,S", [(3, 40), (4, 2507), (2, 16384), (2, 16385), (3, 20000), (1, 32768)])
 def test_rank_rows(dev, B, S):
     ops = _ops()
