@@ -41,7 +41,7 @@ for d, name in (("stats_qws", "r02_qws_b256_solo_eager_kernel_stats.csv"), ("sta
         shutil.copy(f[-1], os.path.join(P, name))
         print("->", name)
 short = {"lstm_encode_coop_kernel": "lstm_encode", "pointer_decode_coop_kernel": "pointer_decode", "gin_request_branch_kernel": "request_branch",
-         "csr_aggregate_kernel<true>": "csr_aggregate_gcn", "select_candidates_kernel": "select_candidates", "linear_f32_kernel<128": "linear_128",
+         "csr_aggregate_kernel<true>": "csr_aggregate_gcn", "select_candidates_kernel": "select_candidates", "select_candidates16_kernel": "select_candidates", "linear_f32_kernel<128": "linear_128",
          "linear_f32_kernel<64": "linear_64", "segment_mean_kernel": "segment_mean"}
 out = {"unit": "bytes per launch",
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over `bench.py --graph 0 --inflight 1` "
