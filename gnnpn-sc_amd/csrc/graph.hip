@@ -128,8 +128,11 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
 // slice x[b*R .. (b+1)*R)[SLICE*s .. SLICE*(s+1)) into LDS ONCE ((R + 1) * SLICE * 4 B <= 160 KB: SLICE = 16 up to R = 2559,
 // 8 up to 5119, 4 up to 10239) and serves every gather from there, so each source element crosses the L2 -> CU path once.
 // LPR = SLICE/4 lanes per destination row, one float4 each; a wave works on 64/LPR rows at a time and walks their neighbour
-// lists in step (4 edges per trip, the (col, w) loads of a trip issued before its LDS reads).  Sums are strictly in CSR
-// order with separately rounded multiply and add: bit-identical to csr_aggregate_kernel.
+// lists in step, 4*LPR edges per batch: every lane fetches 4 consecutive (col, w) entries with one 16-byte load per array
+// (the next batch's while the current one is consumed) and the lanes of a row take each other's entries by DPP quad
+// permutes; rows are dealt to the waves by descending degree (gnnpn_csr_block_row_order) so that rows walking in step have
+// the same length.  Sums are strictly in CSR order with separately rounded (packed) multiply and add: bit-identical to
+// csr_aggregate_kernel.  24.7 % of the HBM roofline at 2507 x 256 copies (gather form 15.4 %); what bounds it: DESIGN.md 8.
 // Placement (speed only): the SLICE-WGs of one block get equal blockIdx % 8 (one XCD), so the two halves of every 128-B
 // line of x — read by two different slices — meet in that XCD's L2 and the (col, w) lists are fetched from HBM once.
 // value of lane L of the own group of LPR (4, 2 or 1) consecutive lanes, as a DPP quad permute (no LDS round trip)
