@@ -242,9 +242,14 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
             if (rc == GNNPN_E_UNSUP && impl == 4)   // K > 8: the 16-member form is the other build that shares a CU
                 rc = gnnpn_launch_decode_coop2(args, n_nets, precision, opts, workspace, workspace_bytes, s);
         }
-        if (rc != GNNPN_OK) return rc;
-        GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
-        return GNNPN_OK;
+        // auto mode: a device the cooperative forms are not built for (fewer than 8 XCDs x 32 CUs, a net the
+        // cooperative sampling build does not cover) is served by the streaming form below instead of an error
+        const bool fall_through = rc == GNNPN_E_UNSUP && impl == 0 && precision == GNNPN_PREC_F32;
+        if (rc != GNNPN_OK && !fall_through) return rc;
+        if (rc == GNNPN_OK) {
+            GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
+            return GNNPN_OK;
+        }
     }
     if (precision == GNNPN_PREC_SPLIT)
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand precision needs the cooperative form (H = 256)");

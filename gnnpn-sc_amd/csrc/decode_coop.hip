@@ -558,7 +558,9 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     int gpx = n_cu / (8 * G);
     if (gpx > 8) gpx = 8;
     while (gpx > 1 && (gpx - 1) * 8 >= n_nets * n_tiles) --gpx;
-    if (gpx < 1) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: device has %d CUs, cooperative form needs >= 64", n_cu);
+    // coop_place assumes 8 XCDs with workgroup ids dealt round-robin over them (MI355X in SPX mode: 256 CUs); a partitioned
+    // device (CPX / DPX / QPX: fewer XCDs) would never finish staffing
+    if (gpx < 1 || n_cu < 256) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: device has %d CUs, the cooperative form is built for 8 XCDs x 32 CUs", n_cu);
     const int groups = gpx * 8;
     if (groups < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: %d groups for %d nets", groups, n_nets);
     const int groups_per_net = groups / n_nets;

@@ -360,7 +360,7 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     int gpx = n_cu / (8 * G);
     if (gpx > 2) gpx = 2;
     while (gpx > 1 && (gpx - 1) * 8 >= n_nets * n_tiles) --gpx;
-    if (gpx < 1) return GNNPN_E_UNSUP;
+    if (gpx < 1 || n_cu < 256) return GNNPN_E_UNSUP;   // built for 8 XCDs x 32 CUs (coop_common.h: coop_place)
     const int groups = gpx * 8;
     if (groups < n_nets) return GNNPN_E_UNSUP;
     const int groups_per_net = groups / n_nets;

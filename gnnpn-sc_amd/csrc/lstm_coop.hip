@@ -535,7 +535,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         int gpx16 = n_cu / (8 * G16);
         if (gpx16 > 8) gpx16 = 8;
         while (gpx16 > 1 && (gpx16 - 1) * 8 >= n_nets * n_tiles) --gpx16;
-        if (gpx16 < 1) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, the 16-member form needs >= 128", n_cu);
+        if (gpx16 < 1 || n_cu < 256) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, the 16-member form is built for 8 XCDs x 32 CUs", n_cu);
         const int groups16 = gpx16 * 8;
         if (groups16 < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups16, n_nets);
         const int64_t need16 = COOP_STATUS_BYTES + (int64_t)groups16 * GROUP_GRANULES16 * sizeof(u64);
@@ -555,7 +555,9 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     int gpx = n_cu / (8 * G);
     if (gpx > 8) gpx = 8;
     while (gpx > 1 && (gpx - 1) * 8 >= n_nets * n_tiles) --gpx;
-    if (gpx < 1) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, cooperative form needs >= 64", n_cu);
+    // coop_place assumes 8 XCDs with workgroup ids dealt round-robin over them (MI355X in SPX mode: 256 CUs); a partitioned
+    // device (CPX / DPX / QPX: fewer XCDs) would never finish staffing
+    if (gpx < 1 || n_cu < 256) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, the cooperative form is built for 8 XCDs x 32 CUs", n_cu);
     const int groups = gpx * 8;
     if (groups < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups, n_nets);
     const int groups_per_net = groups / n_nets;

@@ -2,6 +2,7 @@
 output with torch (device memory only), pass raw pointers + the current HIP stream.  No compute
 happens in Python; there is no CPU path — non-CUDA tensors raise ``GnnpnError``.
 """
+import itertools
 import weakref
 
 import torch
@@ -278,18 +279,24 @@ def decode_failure_record(clear=True):
 
 
 _default_ws = {}
-_all_ws = []
+# id -> Workspaces, by WEAK reference: a PipelinedRunner / capture that is dropped takes its workspaces with
+# it, and check_status() only visits the ones still alive (it synchronises and reads one word per registered object)
+_all_ws = weakref.WeakValueDictionary()
+_ws_ids = itertools.count()
 
 
 def new_workspaces(device):
     w = Workspaces(device)
-    w.id = len(_all_ws)
-    _all_ws.append(w)
+    w.id = next(_ws_ids)
+    _all_ws[w.id] = w
     return w
 
 
 def workspaces_by_id(ws_id):
-    return _all_ws[ws_id]
+    w = _all_ws.get(ws_id)
+    if w is None:
+        raise GnnpnError(f"workspaces #{ws_id} no longer exist (their owner was dropped)")
+    return w
 
 
 def workspaces(device, ws=None):
@@ -313,7 +320,7 @@ def check_status(device=None):
     """Synchronise and raise if a bounded inter-workgroup wait of ANY cooperative launch since the last check timed out
     (the sticky status word of every Workspaces of this process, optionally of one device only)."""
     want = None if device is None else torch.device(device)
-    for w in list(_all_ws):
+    for w in list(_all_ws.values()):
         if want is None or w.device.type == want.type and (want.index is None or w.device.index == want.index):
             w.check()
 

@@ -7,6 +7,7 @@ No autograd: the gradient of  mean_b( advantage_b * sum_k log p_{b,k} )  wrt eve
 hand-written backward kernels with the picks as constants; weights are updated in place.
 """
 import os
+import time
 
 import torch
 
@@ -26,6 +27,9 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     """Gradient of sum_b gscale[b] * sum_k log p_{b,k}(picks) wrt every parameter of ``actor`` (a modelPN.PointerNet):
     -> (dict name -> gradient tensor, logp [B,T]).  inputs [B,L,8]; idx [B,T] int32 picks (global positions); latent_win
     [B,T,K] the Low net's window logits (constants) or None."""
+    if getattr(actor, "general", False):
+        raise NotImplementedError("actor_gradients differentiates the shipped decoder ('Dot' attention, no glimpses): "
+                                  "'Bahdanau' attention / glimpse rounds (modelPN.py:83-109,208-211) have no backward here")
     p = {k: v.detach().float().contiguous() for k, v in _params(actor).items()}
     B, L, F = inputs.shape
     H, T, K = actor.hidden_size, actor.serCategory, actor.serNumber
@@ -67,9 +71,37 @@ class ActorAdam:
     """torch.optim.Adam(model.actor.parameters(), lr) (trainPNHigh.py:62) + clip_grad_norm_ (:105-106), state on the device."""
 
     def __init__(self, actor, lr=0.5e-4, max_grad_norm=2.0):
+        if getattr(actor, "general", False):
+            raise NotImplementedError("ActorAdam steps the parameters of the shipped decoder ('Dot' attention, no glimpses)")
         self.actor, self.lr, self.max_grad_norm, self.steps = actor, lr, max_grad_norm, 0
         self.state = {k: (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32))
                       for k, p in _params(actor).items()}
+
+    def state_dict(self):
+        """torch.optim.Adam's layout (what the reference saves as actor_optim.state_dict(), trainPNHigh.py:118-123):
+        parameters numbered in actor.parameters() order, state[i] = {step, exp_avg, exp_avg_sq}."""
+        names = list(_params(self.actor))
+        state = {i: {"step": self.steps, "exp_avg": self.state[k][0].detach().cpu().clone(),
+                     "exp_avg_sq": self.state[k][1].detach().cpu().clone()} for i, k in enumerate(names)} if self.steps else {}
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        names = list(_params(self.actor))
+        group = sd["param_groups"][0]
+        if list(group["params"]) != list(range(len(names))):
+            raise ValueError("ActorAdam.load_state_dict: the optimizer state belongs to a different parameter list")
+        self.lr = float(group["lr"])
+        steps = {int(st["step"]) for st in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("ActorAdam.load_state_dict: parameters with different step counts")
+        self.steps = steps.pop() if steps else 0
+        for i, k in enumerate(names):
+            if i in sd["state"]:
+                m, v = self.state[k]
+                m.copy_(sd["state"][i]["exp_avg"])
+                v.copy_(sd["state"][i]["exp_avg_sq"])
 
     @torch.no_grad()
     def step(self, grads):
@@ -147,6 +179,7 @@ class TrainModel:
         loader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=0)
         if self.low_model is None:
             return self._train_and_validate_low(loader, n_epochs, epochDiv)
+        t0 = time.time()                                                                            # :75
         for epoch in range(1, n_epochs + 1):
             for batch_id, (sample_batch, _labs) in enumerate(loader):
                 if batch_id == 0:
@@ -158,15 +191,19 @@ class TrainModel:
             if epoch % epochDiv == 0:
                 n = self.epochs // epochDiv
                 os.makedirs(f"./solutions/PNHigh/{self.dataset}", exist_ok=True)
-                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": {}},
+                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": self.actor_optim.state_dict()},
                            f"./solutions/PNHigh/{self.dataset}/epoch{n}.model")                    # :118-123
-                torch.save({"epoch": epoch, "model": self.low_model.state_dict(), "optimizer": {}},
+                torch.save({"epoch": epoch, "model": self.low_model.state_dict(), "optimizer": self.actor_optim.state_dict()},
                            f"./solutions/PNHigh/{self.dataset}/epoch{n}_low.model")                # :124-129
                 acts, tour = evalPN.evaluate(self.low_model, self.model, self.val_dataset, self.serCategory, 128,
                                              str(self.device))                                     # :131-141
                 with open(f"./solutions/PNHigh/{self.dataset}/allActions{n}.txt", "w") as f:       # :143-144
                     json.dump(acts, f)
-                self.val_tour.append(sum(tour) / max(len(tour), 1))
+                self.val_tour += [float(r) for r in tour]                                          # :141, one mean per eval batch
+                with open(f"./solutions/PNHigh/{self.dataset}/val{n}.txt", "w") as f:              # :147-148
+                    json.dump(self.val_tour, f)
+                with open(f"./solutions/PNHigh/{self.dataset}/time{n}.txt", "w") as f:             # :149-150
+                    json.dump([time.time() - t0], f)
             self.epochs += 1
 
     def _train_and_validate_low(self, loader, n_epochs, epochDiv):
@@ -183,7 +220,7 @@ class TrainModel:
             if epoch % epochDiv == 0:
                 n = self.epochs // epochDiv
                 os.makedirs(f"./solutions/PNLow/{self.dataset}", exist_ok=True)
-                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": {}},
+                torch.save({"epoch": epoch, "model": self.model.state_dict(), "optimizer": self.actor_optim.state_dict()},
                            f"./solutions/PNLow/{self.dataset}/epoch{n}.model")                     # trainPNLow.py:112-117
                 all_actions = [[] for _ in range(self.serCategory + 2)]                            # :122
                 all_r = {"quality": [], "averageQ": 0}

@@ -4,9 +4,10 @@
 
     python main.py QWS ML+2PN            # epoch from environment.ini ([QWS-ML+2PN] -> -1)
     python main.py Normal ML+2PN 3       # argv[3] overrides the epoch (reference main.py:219-220)
-    python main.py QWS ML+2PN -1 --infer # first PRODUCE the artefacts on the GPU (random-init or
-                                         # ./solutions/pretrained/<ds>-{ML.pt,PNLow.model,PNHigh.model}
-                                         # weights), then score them
+    python main.py QWS ML+2PN -1 --infer # first PRODUCE the artefacts on the GPU, then score them.  Weights: epoch -1 ->
+                                         # ./solutions/pretrained/<ds>-{ML.pt,PNLow.model,PNHigh.model}; epoch n -> what
+                                         # `main.py <ds> ML` / `PNHigh` wrote for that epoch.  A missing file is an error
+                                         # unless --random-init asks for seeded random weights
 
     python main.py QWS WOA [epoch]       # ES-WOA fine-tuning of the ML+2PN solution on the GPU (reference main.py:86-104,
                                          # mode ML2PNWOATest of [<ds>-WOA]); --seed N makes the run reproducible
@@ -24,24 +25,43 @@ import os
 import sys
 
 
-def _models(cfg, ds, n_services, n_cat):
+def _models(cfg, ds, n_services, n_cat, epoch=-1, random_init=False):
+    """The three networks of an ML+2PN inference run with the weights that belong to ``epoch``:
+      epoch -1  ./solutions/pretrained/<ds>-{ML.pt, PNLow.model, PNHigh.model}   (reference loadData.py:84-89, trainPNHigh.py:237-242)
+      epoch  n  ./solutions/ML/<ds>/model-{n}.pkl (trainML.py:147; a state_dict here), ./solutions/PNHigh/<ds>/epoch{n}.model
+                and epoch{n}_low.model (trainPNHigh.py:118-129) — what `main.py <ds> ML` / `PNHigh` of this build write.
+    A missing file raises: artefacts named after an epoch must never come from untrained weights.  ``random_init``
+    (--random-init) says explicitly that seeded random weights are wanted where a file is absent (smoke runs)."""
     import torch
     from gnnpn_sc_amd.modelML import Net
     from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
     ml, pn = cfg[f"{ds}-ML"], cfg[f"{ds}-PNHigh"]
     K, H = int(pn["serNumber"]), int(pn["hidden_size"])
+    if epoch == -1:
+        pre = "./solutions/pretrained/"
+        p_ml, p_low, p_high = pre + f"{ds}-ML.pt", pre + f"{ds}-PNLow.model", pre + f"{ds}-PNHigh.model"
+    else:
+        p_ml = f"./solutions/ML/{ds}/model-{epoch}.pkl"
+        p_low, p_high = f"./solutions/PNHigh/{ds}/epoch{epoch}_low.model", f"./solutions/PNHigh/{ds}/epoch{epoch}.model"
+    missing = [p for p in (p_ml, p_low, p_high) if not os.path.exists(p)]
+    if missing and not random_init:
+        raise FileNotFoundError(f"ML+2PN --infer for epoch {epoch}: no weights at {', '.join(missing)} "
+                                "(train them with `main.py <ds> ML|PNLow|PNHigh`, or pass --random-init for seeded random weights)")
     torch.manual_seed(0)
+    sd_ml = torch.load(p_ml, map_location="cpu") if os.path.exists(p_ml) else None
+    # the vocabulary the checkpoint was trained with (trainML builds the reference's Embedding(100, c); the synthetic
+    # 1000-task configurations need larger tables)
+    vocab = sd_ml["nodeEncoder.embeddings.0.weight"].shape[0] if sd_ml is not None else max(100, n_cat + 1)
     net = Net(int(ml["hiddenChannels"]), n_services, int(ml["embeddingChannels"]), int(ml["numLayersGIN"]),
-              int(ml["numLayersGCN"]), vocab=max(100, n_cat + 1))
+              int(ml["numLayersGCN"]), vocab=vocab)
+    if sd_ml is not None:
+        net.load_state_dict(sd_ml)
     mk = lambda lvl: CombinatorialRL(0, H, n_cat * K, int(pn["n_glimpses"]), float(pn["tanh_exploration"]),  # noqa: E731
                                      int(pn["use_tanh"]), reward, "Dot", K, n_cat, level=lvl)
     low, high = mk("Low"), mk("High")
-    pre = "./solutions/pretrained/"
-    if os.path.exists(pre + f"{ds}-ML.pt"):
-        net.load_state_dict(torch.load(pre + f"{ds}-ML.pt", map_location="cpu"))
-    for m, name in ((low, f"{ds}-PNLow.model"), (high, f"{ds}-PNHigh.model")):
-        if os.path.exists(pre + name):      # checkpoint format of trainPNLow.py:112-117 / trainPNHigh.py:118-123
-            m.load_state_dict(torch.load(pre + name, map_location="cpu")["model"])
+    for m, path in ((low, p_low), (high, p_high)):
+        if os.path.exists(path):            # checkpoint format of trainPNLow.py:112-117 / trainPNHigh.py:118-129
+            m.load_state_dict(torch.load(path, map_location="cpu")["model"])
     return net, low, high, K
 
 
@@ -114,7 +134,7 @@ def main(argv):
         with open(f"./data/{ds}/serviceFeature.data") as f:
             sf = json.load(f)
         n_services = sum(len(v) for v in sf.values())
-        net, low, high, K = _models(cfg, ds, n_services, len(sf))
+        net, low, high, K = _models(cfg, ds, n_services, len(sf), epoch, "--random-init" in flags)
         ML2PN.infer(ds, net, low, high, K, epoch)
         n_cat = len(sf)
     ML2PN.check(ds, n_cat, epoch)

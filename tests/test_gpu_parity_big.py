@@ -147,7 +147,7 @@ def test_reference_fixture_long_sequences(dev, name, mode):
                  for b in range(B))
         rec = {"robust_prefix_decisions": int(pre.sum()), "identical_in_prefix": ok}
         record_agreement(f"fixture_{name}_{mode}", rec)
-        assert ok >= 0.5 * pre.sum(), rec
+        assert ok >= int(pre.sum()) - 1, rec                            # measured: every one of them (agreement_r02.json)
         return
     rec = prefix_parity(out["idx_low"], out["idx_high"], fx, f"{name}/{mode}", x)
     same = rec["same_mask"]
@@ -158,7 +158,8 @@ def test_reference_fixture_long_sequences(dev, name, mode):
         got = out["win_low"].cpu().numpy()[:n_win, :pre]
         assert np.abs(got - fx["win_low"][:, :pre]).max() < LOGIT_ATOL
     record_agreement(f"fixture_{name}_{mode}", rec)
-    assert rec["identical_decisions"] >= rec["robust_prefix_decisions"] >= 600
+    assert rec["robust_prefix_decisions"] >= 600
+    assert rec["identical_decisions"] == rec["decisions_compared"] == 2 * B * T, rec   # measured: all of them, in every mode
 
 
 def _pipeline(T, S, K, dev, n_gcn, seeds=(7, 8, 9)):

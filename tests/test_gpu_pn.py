@@ -348,7 +348,7 @@ def test_split_encoder_matches_fp32_accuracy(dev):
     a = two_level_greedy(low, high, xd)
     b = two_level_greedy(low, high, xd, precision="split")
     same = (a["actions"] == b["actions"]).all(-1).all(1)
-    assert float(same.float().mean()) >= 0.95
+    assert bool(same.all())                                            # measured: 32 of 32 (floor was 0.95)
     s = same.cpu()
     assert float((a["R"] - b["R"]).abs()[s].max()) <= R_ATOL
 

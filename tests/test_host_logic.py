@@ -79,6 +79,39 @@ def test_check_and_cli_match_reference(fx, workdir):
     assert buf.getvalue().strip() == "Please check the parameters!"       # reference main.py:231
 
 
+def test_infer_weights_follow_the_epoch(tmp_path, monkeypatch):
+    """main._models: `main.py <ds> ML+2PN <epoch> --infer` must run on the weights OF THAT EPOCH — the files
+    trainML / trainPNHigh write — and must refuse to run on random weights when one is missing (unless --random-init)."""
+    import configparser
+    import torch
+    import main as cli
+    from oracle import ml as oml, pn as opn
+    monkeypatch.chdir(tmp_path)
+    T, S, K, H = 6, 60, 3, 32
+    cfg = configparser.RawConfigParser()
+    cfg.read_string("[QWS-ML]\nnumLayersGIN = 2\nnumLayersGCN = 2\nhiddenChannels = 128\nembeddingChannels = 20\n"
+                    f"[QWS-PNHigh]\nserNumber = {K}\nhidden_size = {H}\nn_glimpses = 0\ntanh_exploration = 10\nuse_tanh = 1\n")
+    with pytest.raises(FileNotFoundError, match="epoch 3"):
+        cli._models(cfg, "QWS", S, T, 3)
+    with pytest.raises(FileNotFoundError, match="pretrained"):
+        cli._models(cfg, "QWS", S, T, -1)
+    net, low, high, k = cli._models(cfg, "QWS", S, T, 3, random_init=True)       # explicit: seeded random weights
+    assert k == K
+    sd_ml = oml.make_state_dict(128, 20, 2, 2, seed=7)
+    sd_low, sd_high = opn.make_state_dict(H, 8), opn.make_state_dict(H, 9)
+    (tmp_path / "solutions" / "ML" / "QWS").mkdir(parents=True)
+    (tmp_path / "solutions" / "PNHigh" / "QWS").mkdir(parents=True)
+    torch.save(sd_ml, "solutions/ML/QWS/model-3.pkl")                               # trainML.TrainML.start
+    torch.save({"epoch": 4, "model": sd_high, "optimizer": {}}, "solutions/PNHigh/QWS/epoch3.model")      # trainPNHigh.TrainModel
+    torch.save({"epoch": 4, "model": sd_low, "optimizer": {}}, "solutions/PNHigh/QWS/epoch3_low.model")
+    net, low, high, _ = cli._models(cfg, "QWS", S, T, 3)
+    assert all(torch.equal(v, sd_ml[k_]) for k_, v in net.state_dict().items())
+    assert all(torch.equal(v, sd_low[k_]) for k_, v in low.state_dict().items())
+    assert all(torch.equal(v, sd_high[k_]) for k_, v in high.state_dict().items())
+    with pytest.raises(FileNotFoundError):                                          # another epoch: not these files
+        cli._models(cfg, "QWS", S, T, 2)
+
+
 def test_calc_penalties():
     from gnnpn_sc_amd.ML2PN import calc
     qos = [[0.2, 0.4], [0.5, 0.3], [0.9, 0.9], [1.0, 1.0]]

@@ -1,0 +1,168 @@
+// What v_mfma_f32_16x16x32_{f16,bf16} does with its 32 products and C: the accumulate model behind the a-priori bound of
+// the exact-split recurrent product.  One wave, one MFMA per experiment; experiment t lives on the diagonal:
+// D[t][t] = C[t][t] + sum_k A[t][k] * B[k][t].
+//
+//   hipcc -O2 --offload-arch=gfx950 tools/probes/mfma_accum_model.hip -o tools/probes/mfma_accum_model && tools/probes/mfma_accum_model
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A[16][32], B[32][16] (as float, converted exactly on the device: the host only stores representable values), C, D [16][16]
+template <bool BF>
+__global__ void one_mfma(const float* A, const float* B, const float* C, float* D) {
+    const int lane = threadIdx.x, c = lane & 15, kq = lane >> 4;
+    f32x4 acc;
+    for (int r = 0; r < 4; ++r) acc[r] = C[(4 * kq + r) * 16 + c];
+    if constexpr (BF) {
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (__bf16)A[c * 32 + 8 * kq + j];
+            b[j] = (__bf16)B[(8 * kq + j) * 16 + c];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    } else {
+        f16x8 a, b;
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (_Float16)A[c * 32 + 8 * kq + j];
+            b[j] = (_Float16)B[(8 * kq + j) * 16 + c];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) D[(4 * kq + r) * 16 + c] = acc[r];
+}
+
+struct Exp {
+    const char* what;
+    float c;
+    std::vector<std::pair<int, std::pair<float, float>>> terms;   // k -> (a, b)
+    double exact() const {
+        double s = c;
+        for (auto& t : terms) s += (double)t.second.first * (double)t.second.second;
+        return s;
+    }
+};
+
+static float p2(int e) { return std::ldexp(1.0f, e); }
+
+int main() {
+    std::vector<Exp> ex;
+    auto all32 = [&](float a, float b) {
+        std::vector<std::pair<int, std::pair<float, float>>> v;
+        for (int k = 0; k < 32; ++k) v.push_back({k, {a, b}});
+        return v;
+    };
+    ex.push_back({"c=1, 32 products of 2^-25 (sequential RN adds: 1; one rounding of the exact sum: 1+2^-20)", 1.0f, all32(p2(-12), p2(-13))});
+    ex.push_back({"c=1, one product 2^-24+2^-30 (RN: 1+2^-23; truncation: 1)", 1.0f, {{0, {p2(-12) * (1 + p2(-6)), p2(-12)}}}});
+    ex.push_back({"c=1, one product 2^-24 exactly (tie; RN-even: 1)", 1.0f, {{0, {p2(-12), p2(-12)}}}});
+    ex.push_back({"c=1+2^-23, one product 2^-24 (tie; RN-even: 1+2^-22)", 1.0f + p2(-23), {{0, {p2(-12), p2(-12)}}}});
+    ex.push_back({"c=-1, one product -(2^-24+2^-30) (RN: -(1+2^-23); toward zero: -1)", -1.0f, {{0, {-p2(-12) * (1 + p2(-6)), p2(-12)}}}});
+    ex.push_back({"c=0, k0:+2^20, k1:+2^-10, k31:-2^20 (exact sum: 2^-10; sequential fp32: 0)", 0.0f, {{0, {p2(10), p2(10)}}, {1, {p2(-5), p2(-5)}}, {31, {-p2(10), p2(10)}}}});
+    ex.push_back({"c=0, k0:+2^20, k16:+2^-10, k31:-2^20", 0.0f, {{0, {p2(10), p2(10)}}, {16, {p2(-5), p2(-5)}}, {31, {-p2(10), p2(10)}}}});
+    ex.push_back({"c=2^20, k0:-2^20, k1:+2^-10 (is C aligned with the products or added after their sum?)", p2(20), {{0, {-p2(10), p2(10)}}, {1, {p2(-5), p2(-5)}}}});
+    ex.push_back({"c=0, fp16-denormal input 2^-20 times 2^10 (kept: 2^-10; flushed: 0)", 0.0f, {{0, {p2(-20), p2(10)}}}});
+    ex.push_back({"c=1, products 2^-25 at k0,k1 (their sum is the tie 2^-24)", 1.0f, {{0, {p2(-12), p2(-13)}}, {1, {p2(-12), p2(-13)}}}});
+    ex.push_back({"c=1, products 2^-25 at k0..k3 (sum 2^-23)", 1.0f, {{0, {p2(-12), p2(-13)}}, {1, {p2(-12), p2(-13)}}, {2, {p2(-12), p2(-13)}}, {3, {p2(-12), p2(-13)}}}});
+    {
+        Exp e{"c=1, products 2^-25 at k0,k4,...,k28 (8 of them: 2^-22)", 1.0f, {}};
+        for (int k = 0; k < 32; k += 4) e.terms.push_back({k, {p2(-12), p2(-13)}});
+        ex.push_back(e);
+    }
+    ex.push_back({"c=1, products 2^-25 at k0 and k16", 1.0f, {{0, {p2(-12), p2(-13)}}, {16, {p2(-12), p2(-13)}}}});
+    ex.push_back({"c=0, k0: 1, k1: 1.5*2^-24 (exact then RN: 1+2^-23; bits below 2^-24 of the largest term dropped: 1)", 0.0f, {{0, {1.0f, 1.0f}}, {1, {1.5f * p2(-12), p2(-12)}}}});
+    {
+        Exp e{"c=0, k0: 1, k1..k8: 2^-27 each, k9: 2^-30 (exact: 1+2^-24+2^-30 -> 1+2^-23)", 0.0f, {{0, {1.0f, 1.0f}}}};
+        for (int k = 1; k <= 8; ++k) e.terms.push_back({k, {p2(-13), p2(-14)}});
+        e.terms.push_back({9, {p2(-15), p2(-15)}});
+        ex.push_back(e);
+    }
+    ex.push_back({"c=0.5, k0: 1 (control: 1.5)", 0.5f, {{0, {1.0f, 1.0f}}}});
+    // second batch: how many bits below the largest term survive the alignment
+    std::vector<Exp> ex2;
+    for (int g = 24; g <= 39; ++g) {
+        static char buf[16][96];
+        snprintf(buf[g - 24], 96, "c=0, k0: 1, k1: 2^-24, k2: 2^-%d (up iff bit 2^-%d is seen)", g, g);
+        ex2.push_back({buf[g - 24], 0.0f, {{0, {1.0f, 1.0f}}, {1, {p2(-12), p2(-12)}}, {2, {p2(-(g / 2)), p2(-(g - g / 2))}}}});
+    }
+    // third batch: the same with C as the large term
+    std::vector<Exp> ex3;
+    for (int g = 24; g <= 39; ++g) {
+        static char buf[16][96];
+        snprintf(buf[g - 24], 96, "c=1, k1: 2^-24, k2: 2^-%d (up iff bit 2^-%d is seen)", g, g);
+        ex3.push_back({buf[g - 24], 1.0f, {{1, {p2(-12), p2(-12)}}, {2, {p2(-(g / 2)), p2(-(g - g / 2))}}}});
+    }
+    // fourth: random dot products against sequential-fma, pairwise and exact-then-round models
+    float *dA, *dB, *dC, *dD;
+    hipMalloc(&dA, 16 * 32 * 4); hipMalloc(&dB, 32 * 16 * 4); hipMalloc(&dC, 256 * 4); hipMalloc(&dD, 256 * 4);
+    for (int bf = 0; bf < 2; ++bf) {
+        printf("==== v_mfma_f32_16x16x32_%s\n", bf ? "bf16" : "f16");
+        for (auto* batch : {&ex, &ex2, &ex3}) {
+            float A[16 * 32] = {0}, B[32 * 16] = {0}, C[256] = {0}, D[256];
+            for (size_t t = 0; t < batch->size(); ++t) {
+                C[t * 16 + t] = (*batch)[t].c;
+                for (auto& term : (*batch)[t].terms) {
+                    A[t * 32 + term.first] = term.second.first;
+                    B[term.first * 16 + t] = term.second.second;
+                }
+            }
+            hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice); hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice);
+            hipMemcpy(dC, C, sizeof(C), hipMemcpyHostToDevice);
+            if (bf) hipLaunchKernelGGL(one_mfma<true>, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+            else hipLaunchKernelGGL(one_mfma<false>, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+            hipMemcpy(D, dD, sizeof(D), hipMemcpyDeviceToHost);
+            for (size_t t = 0; t < batch->size(); ++t) {
+                const double exact = (*batch)[t].exact();
+                printf("  [%2zu] %-100s -> %a   (exact %a, RN(exact) %a)\n", t, (*batch)[t].what, D[t * 16 + t], exact, (double)(float)exact);
+            }
+        }
+        // random: 4096 dot products of 32 terms + C; compare with the models
+        unsigned long long s = 88172645463325252ull;
+        auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+        auto q = [&](double v) { return bf ? (float)(__bf16)(float)v : (float)(_Float16)(float)v; };
+        long n = 0, eq_exact = 0, eq_seq = 0, eq_seq_rev = 0, eq_pair = 0;
+        double worst_ulps = 0;
+        for (int rep = 0; rep < 256; ++rep) {
+            float A[16 * 32], B[32 * 16], C[256], D[256];
+            for (int i = 0; i < 16 * 32; ++i) A[i] = q(2 * rnd() - 1);
+            for (int i = 0; i < 32 * 16; ++i) B[i] = q(2 * rnd() - 1);
+            for (int i = 0; i < 256; ++i) C[i] = (float)(4 * (2 * rnd() - 1));
+            hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice); hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice);
+            hipMemcpy(dC, C, sizeof(C), hipMemcpyHostToDevice);
+            if (bf) hipLaunchKernelGGL(one_mfma<true>, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+            else hipLaunchKernelGGL(one_mfma<false>, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD);
+            hipMemcpy(D, dD, sizeof(D), hipMemcpyDeviceToHost);
+            for (int i = 0; i < 16; ++i)
+                for (int j = 0; j < 16; ++j) {
+                    long double e = C[i * 16 + j];
+                    float sq = C[i * 16 + j], sr = C[i * 16 + j];
+                    float pr[32];
+                    for (int k = 0; k < 32; ++k) {
+                        e += (long double)A[i * 32 + k] * B[k * 16 + j];
+                        sq = std::fmaf(A[i * 32 + k], B[k * 16 + j], sq);
+                        pr[k] = A[i * 32 + k] * B[k * 16 + j];   // exact in fp32 (<= 22-bit products)
+                    }
+                    for (int k = 31; k >= 0; --k) sr = std::fmaf(A[i * 32 + k], B[k * 16 + j], sr);
+                    for (int w = 16; w >= 1; w >>= 1)
+                        for (int k = 0; k < w; ++k) pr[k] = pr[k] + pr[k + w];
+                    const float pw = pr[0] + C[i * 16 + j];
+                    const float d = D[i * 16 + j];
+                    ++n;
+                    eq_exact += d == (float)e;
+                    eq_seq += d == sq;
+                    eq_seq_rev += d == sr;
+                    eq_pair += d == pw;
+                    const double ulp = std::ldexp(1.0, std::ilogb((double)(float)e) - 23);
+                    const double u = std::fabs((double)d - (double)e) / ulp;
+                    if (u > worst_ulps) worst_ulps = u;
+                }
+        }
+        printf("  random (|a|,|b| < 1, |c| < 4, 32 terms + C, %ld dots): == RN(exact) %.4f, == fma chain k ascending %.4f, k descending %.4f, == pairwise tree + C %.4f; worst |d - exact| = %.3f ulp of the result\n",
+               n, (double)eq_exact / n, (double)eq_seq / n, (double)eq_seq_rev / n, (double)eq_pair / n, worst_ulps);
+    }
+    return 0;
+}
