@@ -50,6 +50,8 @@ _SIGNATURES = {
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
+    "gnnpn_split3_pieces_f32": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P]),
+    "gnnpn_recurrent_product_f32": (c_int, [_P, _P, c_int32, _P, _P, _P]),
     "gnnpn_gemm_f32": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
     "gnnpn_colsum_chunks_f32": (c_int, [_P, c_int64, c_int64, c_int32, c_int64, _P, _P]),
     "gnnpn_lstm_train_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),

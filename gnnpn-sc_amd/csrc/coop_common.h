@@ -372,63 +372,172 @@ __device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq,
     }
 }
 
-// ---- split-operand recurrent product ("split" precision) ---------------------------------------------
-// x = hi + lo/2^11 with hi = fp16(x), lo = fp16((x - hi) * 2^11): W_hh.h ~= hi.hi + (hi.lo + lo.hi)/2^11 on the
-// fp16 matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate).  Dropped: lo.lo/2^22 and the fp16 rounding of
-// the two residuals, <= 3*2^-22 relative per term — measured error of the encoder output against an fp64 LSTM
-// equals the fp32 chain's (tools/split_encode.py).  LDS tile: 16 rows of LDH16 halfs, hi tile then lo tile.
+// ---- exact-split recurrent product ("split" precision, rebuilt in round 3) -------------------------------------------
+// Every fp32 operand x of W_hh.h is decomposed into THREE fp16 pieces that reproduce it bit for bit,
+//     x * 2^s = p0 + p1 / 2^11 + p2 / 2^22,     p0 = fp16(x 2^s), p1 = fp16((x 2^s - p0) 2^11), p2 = fp16(((x 2^s - p0) 2^11 - p1) 2^11)
+// (each residual is exact in fp32; p2 is the <= 1 bit the first two 11-bit significands cannot hold), s a power-of-two
+// scale that parks the operand high in fp16's range: 2^15 for h (|h| <= 1), per gate column for W (column maximum in
+// [2^14, 2^15)) — exact for 2^-38 <= |x| / max <= 1 and for 0, to 2^-62 * max absolutely below that (tests/test_split3.py).
+// The product keeps every cross term that can reach 2^-24 of |x y|:
+//     x y 2^(s+t) = p0 q0 + (p0 q1 + p1 q0) / 2^11 + (p1 q1 + p0 q2 + p2 q0) / 2^22  [+ terms <= 2^-32 |x y|, dropped]
+// = 6 v_mfma_f32_16x16x32_f16 per 32 k-steps and column tile instead of 16 v_mfma_f32_16x16x4_f32: 96 x 16 cycles per
+// recurrent step against 128 x 32.  The three magnitude classes accumulate in three SEPARATE fp32 accumulators (the matrix
+// core aligns the products of a group to its largest term and drops what falls below 2^-24 of it — measured,
+// tools/probes/mfma_accum_model.hip — so small terms must not share an accumulator with large ones) and are combined once,
+// by two fused multiply-adds.  Error bound and measurements: DESIGN.md section 12.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDH16 = 264;            // row stride in halfs (528 B: 16-B aligned, bank slots spread)
-constexpr int SPLIT_LO = 16 * LDH16;  // offset of the lo tile, in halfs
+constexpr int LDH16 = 264;                 // row stride in halfs (528 B: 16-B aligned, bank slots spread)
+constexpr int SPLIT_TILE = 16 * LDH16;     // halfs per piece tile; the LDS h tile is [3 pieces][16 rows][LDH16]
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+constexpr float SPLIT_H_SCALE = 32768.0f, SPLIT_H_INV = 1.0f / 32768.0f;   // |h| <= 1 -> |h 2^15| <= 2^15 < 65504
 
-__device__ __forceinline__ void split_store(_Float16* hi_at, float x) {   // hi_at: element address inside the hi tile
-    const _Float16 hi = (_Float16)x;
-    hi_at[0] = hi;
-    hi_at[SPLIT_LO] = (_Float16)__fmul_rn(__fsub_rn(x, (float)hi), SPLIT_SCALE);
+__device__ __forceinline__ void split3(float xs, _Float16& p0, _Float16& p1, _Float16& p2) {   // xs: the SCALED operand
+    p0 = (_Float16)xs;
+    const float r1 = __fmul_rn(__fsub_rn(xs, (float)p0), SPLIT_SCALE);      // exact: residual of an 11-bit rounding, times 2^11
+    p1 = (_Float16)r1;
+    p2 = (_Float16)__fmul_rn(__fsub_rn(r1, (float)p1), SPLIT_SCALE);        // exact, and representable: <= 1 significant bit
 }
-// B-fragments of one 16-column tile from the packed weight layout Wp[((k/4*4 + gate)*H + u)*4 + k%4]:
-// lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
+__device__ __forceinline__ unsigned short f16_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+// h granule of the split precision: the publisher splits its own value ONCE and every receiver only unpacks (the fp32
+// value is never needed by a receiver) — {p0 | tag16 << 16, p1 | p2 << 16}.  tag16 = 0x8000 | (tag & 0x7fff): never 0 (a
+// zeroed granule is "empty"), and a parity buffer's previous content is two publishes old, so 15 bits cannot alias.
+__device__ __forceinline__ unsigned split_tag16(unsigned tag) { return 0x8000u | (tag & 0x7fffu); }
+__device__ __forceinline__ u64 split_granule(unsigned tag, float h) {
+    _Float16 p0, p1, p2;
+    split3(__fmul_rn(h, SPLIT_H_SCALE), p0, p1, p2);
+    const unsigned d0 = (unsigned)f16_bits(p0) | (split_tag16(tag) << 16);
+    const unsigned d1 = (unsigned)f16_bits(p1) | ((unsigned)f16_bits(p2) << 16);
+    return ((u64)d1 << 32) | d0;
+}
+__device__ __forceinline__ void split_granule_store(u64* p, unsigned tag, float h, bool same_xcd) {
+    const u64 g = split_granule(tag, h);
+    if (same_xcd) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both granules of a 16-byte pair {A.d0, A.d1, B.d0, B.d1} carry `tag`?
+__device__ __forceinline__ bool split_pair_tagged(u32x4 v, unsigned tag) {
+    const unsigned t = split_tag16(tag);
+    return __builtin_amdgcn_perm(v.z, v.x, 0x07060302u) == (t | (t << 16));
+}
+// unpack a pair (units u, u+1 of one row; u even) into the three piece tiles: one packed 32-bit LDS store per piece
+__device__ __forceinline__ void split_pair_to_lds(_Float16* at, u32x4 v) {   // at: element (row, u) of the p0 tile
+    unsigned* d = reinterpret_cast<unsigned*>(at);
+    d[0] = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);                     // p0(u) | p0(u+1) << 16
+    d[SPLIT_TILE / 2] = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);        // p1
+    d[SPLIT_TILE] = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);            // p2
+}
+// one fp32 value (the tile's initial state h0) into the three tiles
+__device__ __forceinline__ void split_store(_Float16* at, float h) {        // at: element address inside the p0 tile
+    _Float16 p0, p1, p2;
+    split3(__fmul_rn(h, SPLIT_H_SCALE), p0, p1, p2);
+    at[0] = p0;
+    at[SPLIT_TILE] = p1;
+    at[2 * SPLIT_TILE] = p2;
+}
+
+// B-fragments of one 16-column tile from the packed weight layout Wp[((k/4*4 + gate)*H + u)*4 + k%4]: lane (c, kq) holds
+// W[col c][32kk + 8kq + j], j = 0..7, of ITS column, scaled by 2^s with s chosen from the column's largest |w| (the four
+// lanes c, c+16, c+32, c+48 hold the column between them).  Pieces 0 and 1 stay in registers (64 VGPRs per tile each).
+// Piece 2 is zero or a single power of two (the one bit two 11-bit significands cannot hold), so its upper byte IS the
+// fp16 (= an e5m2 number): it lives in LDS as bytes — 192 weight registers would not leave room for two workgroups per CU
+// (measured: 136 B of scratch in the encoder, 450 B in the decoder) — `wt` = this lane's slot of the tile's byte image,
+// two dwords (elements 0..3, 4..7) per k-block kk at wt[4 * 64 * kk] (see split_chain).  An element more than 2^29 below its
+// column's largest (p0 subnormal in fp16) would need more than that byte: its third piece is truncated (|error| < 2^-52
+// of the column maximum; tests/test_split3.py walks that boundary).
+// Returns the factor 2^-(15+s) that un-scales an accumulated product of this column (the 2^15 of h included).
+constexpr int SPLIT_WT_DWORDS = 4 * 8 * 64 * 4;   // per workgroup: [wave][kk][lane]{tile0 lo, tile0 hi, tile1 lo, tile1 hi}
 template <int HD>
-__device__ __forceinline__ void split_weights(const float* __restrict__ Wp, int gate, int u, int kq, f16x8 (&wh)[8],
-                                              f16x8 (&wl)[8]) {
+__device__ __forceinline__ float split_weights(const float* __restrict__ Wp, int gate, int u, int kq, f16x8 (&w0)[8],
+                                               f16x8 (&w1)[8], unsigned* wt) {
+    float m = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float w = Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * HD + u) * 4 + (j & 3)];
-            const _Float16 hi = (_Float16)w;
-            wh[kk][j] = hi;
-            wl[kk][j] = (_Float16)__fmul_rn(__fsub_rn(w, (float)hi), SPLIT_SCALE);
-        }
-}
-// base = hi tile + c * LDH16 + 8 * kq.  NT column tiles sharing the A-fragments; returns hi + lo/2^11 per tile.
-template <int NT>
-__device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&wh)[NT][8], const f16x8 (&wl)[NT][8],
-                                            f32x4 (&acc)[NT]) {
-    f32x4 lo[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) lo[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 ah[2], al[2];
-    ah[0] = *reinterpret_cast<const f16x8*>(base);
-    al[0] = *reinterpret_cast<const f16x8*>(base + SPLIT_LO);
+        for (int j = 0; j < 8; ++j)
+            m = fmaxf(m, fabsf(Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * HD + u) * 4 + (j & 3)]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    int e = 0;
+    if (m > 0.0f && m < 3.0e38f) (void)frexpf(m, &e);                        // m = f 2^e, f in [0.5, 1): m < 2^e
+    int s = m > 0.0f ? 15 - e : 0;                                           // m 2^s in [2^14, 2^15)
+    s = s > 96 ? 96 : (s < -96 ? -96 : s);                                   // 2^-(15+s) stays a normal fp32
+    const float up = ldexpf(1.0f, s);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-        if (kk < 7) {   // next k-block's fragments in flight under this block's MFMAs
-            ah[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + 32 * (kk + 1));
-            al[(kk + 1) & 1] = *reinterpret_cast<const f16x8*>(base + SPLIT_LO + 32 * (kk + 1));
+        unsigned bytes[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = Wp[((size_t)((8 * kk + 2 * kq + (j >> 2)) * 4 + gate) * HD + u) * 4 + (j & 3)];
+            _Float16 p0, p1, p2;
+            split3(__fmul_rn(w, up), p0, p1, p2);
+            w0[kk][j] = p0;
+            w1[kk][j] = p1;
+            bytes[j >> 2] |= (unsigned)(f16_bits(p2) >> 8) << (8 * (j & 3));
         }
+        wt[4 * 64 * kk] = bytes[0];
+        wt[4 * 64 * kk + 1] = bytes[1];
+    }
+    return ldexpf(1.0f, -(15 + s));
+}
+// four third-piece bytes -> two packed fp16 pairs (byte b becomes the half b << 8)
+__device__ __forceinline__ f16x8 split_expand(unsigned lo, unsigned hi) {
+    const u32x4 r = {__builtin_amdgcn_perm(0u, lo, 0x010c000cu), __builtin_amdgcn_perm(0u, lo, 0x030c020cu),
+                     __builtin_amdgcn_perm(0u, hi, 0x010c000cu), __builtin_amdgcn_perm(0u, hi, 0x030c020cu)};
+    return __builtin_bit_cast(f16x8, r);
+}
+// base = p0 tile + c * LDH16 + 8 * kq; wt = this lane's third-piece slot (uint4 per k-block: both tiles).  Two column tiles
+// sharing the A-fragments; acc[n] receives W.h of tile n (un-scaled by inv[n]).
+__device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&w0)[2][8], const f16x8 (&w1)[2][8],
+                                            const unsigned* wt, const float (&inv)[2], f32x4 (&acc)[2]) {
+    constexpr int NT = 2;
+    // a0 = p0.q0 in TWO accumulators (k-blocks 0..3 / 4..7): the matrix core works through a 16x16x32 product in four groups
+    // of 8 k's, aligning a group's 8 products and the accumulator to the largest of them, dropping what falls below 2^-24 of
+    // it and rounding once (tools/probes/mfma_accum_model.hip) — 10 error events of <= 2^-24 of the running magnitude per
+    // group.  16 groups per accumulator keep the worst-case constant at 10 x 16 + 2 = 162 units of 2^-24 sum|h w|, below the
+    // 256 of a 256-term fp32 fma chain (32 groups in one accumulator would be 320); DESIGN.md section 12.
+    f32x4 a0[NT], a0b[NT], a1[NT], a2[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wh[n][kk], acc[n], 0, 0, 0);
+    for (int n = 0; n < NT; ++n) a0[n] = a0b[n] = a1[n] = a2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Fragments are NOT double-buffered (24 + 8 registers would not fit beside two workgroups per CU): each piece is
+    // re-requested for the next k-block right after its last use in this one — h2 after the first pair of MFMAs, h1 after
+    // the third, h0 and the third-piece bytes after the last — so every load has at least 3 pairs (96 cycles) of cover.
+    // Order of the six products per k-block: a2 a1 a2 a0 a2 a1 — an accumulator is reused only after >= 3 other MFMAs.
+    f16x8 h0 = *reinterpret_cast<const f16x8*>(base);
+    f16x8 h1 = *reinterpret_cast<const f16x8*>(base + SPLIT_TILE);
+    f16x8 h2 = *reinterpret_cast<const f16x8*>(base + 2 * SPLIT_TILE);
+    u32x4 t = *reinterpret_cast<const u32x4*>(wt);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk & 1], wl[n][kk], lo[n], 0, 0, 0);
+    for (int kk = 0; kk < 8; ++kk) {
+        const int nx = 32 * (kk + 1);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk & 1], wh[n][kk], lo[n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2, w0[n][kk], a2[n], 0, 0, 0);
+        if (kk < 7) h2 = *reinterpret_cast<const f16x8*>(base + 2 * SPLIT_TILE + nx);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w0[n][kk], a1[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w1[n][kk], a2[n], 0, 0, 0);
+        if (kk < 7) h1 = *reinterpret_cast<const f16x8*>(base + SPLIT_TILE + nx);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (kk < 4) a0[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, w0[n][kk], a0[n], 0, 0, 0);
+            else a0b[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, w0[n][kk], a0b[n], 0, 0, 0);
+        }
+        {
+            const f16x8 w2[NT] = {split_expand(t.x, t.y), split_expand(t.z, t.w)};
+#pragma unroll
+            for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, w2[n], a2[n], 0, 0, 0);
+        }
+        if (kk < 7) t = *reinterpret_cast<const u32x4*>(wt + 4 * 64 * (kk + 1));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, w1[n][kk], a1[n], 0, 0, 0);
+        if (kk < 7) h0 = *reinterpret_cast<const f16x8*>(base + nx);
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[n][r] = fmaf(lo[n][r], SPLIT_INV, acc[n][r]);
+        for (int r = 0; r < 4; ++r)
+            acc[n][r] = __fmul_rn(fmaf(fmaf(a2[n][r], SPLIT_INV, a1[n][r]), SPLIT_INV, __fadd_rn(a0[n][r], a0b[n][r])), inv[n]);
 }
 
 // LSTM cell update for the [i | f] / [g | o] tile pair: lanes c < 8 hold (i, g), lanes c >= 8 hold

@@ -327,35 +327,44 @@ extern "C" int gnnpn_attention_logits_f32(const float* enc_out, const float* que
 }
 
 // ---------------------------------------------------------------------------------------------
-// QoS reward (modelPN.py:15-72): one thread per problem, T sequential steps over 32 B rows.
-__global__ void qos_reward_kernel(const float* __restrict__ actions, float* __restrict__ R, int32_t B, int32_t T,
-                                  int level) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// QoS reward (modelPN.py:15-72): one WAVE per problem (round 3; one thread per problem took 123 us at T = 1000: its 32-byte
+// row loads were a serial chain of round trips).  The 64 lanes fetch 64 consecutive action rows with one coalesced 16-byte
+// load each; the three order-dependent accumulations — the two running fp32 products of np.cumprod (:20) and the fp64 sum —
+// then run over the lanes' values in step order on the scalar-broadcast path (v_readlane), exactly the sequence of
+// operations of the one-thread form; the count of real rows and the minimum are order-free and reduce across the wave.
+__global__ __launch_bounds__(256) void qos_reward_kernel(const float* __restrict__ actions, float* __restrict__ R, int32_t B,
+                                                        int32_t T, int level) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                            // the whole wave
     const float* a = actions + (int64_t)b * T * 8;
-    const float lo0 = a[4], hi0 = a[5], lo1 = a[6], hi1 = a[7];   // step-0 row (:51-54)
-    float prod2 = 1.0f, prod3 = 1.0f, mn = INFINITY;
+    const float lo0 = a[4], hi0 = a[5], lo1 = a[6], hi1 = a[7];    // step-0 row (:51-54)
+    float prod2 = 1.0f, prod3 = 1.0f, mn = INFINITY;               // 1.0f * z == z: the first row needs no special case
     double sum0 = 0.0;
     int n_real = 0;
-    // rows are fetched eight at a time (one 16-byte load each, all in flight together: the loop is
-    // load-latency-bound), the arithmetic stays strictly in step order
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        float4 q[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            q[i] = *reinterpret_cast<const float4*>(a + (int64_t)min(t0 + i, T - 1) * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = t0 + i;
-            if (t < T) {
-                sum0 += (double)q[i].x;                   // np.sum(float32) is pairwise; fp64 then one rounding
-                n_real += q[i].x > 0.0f;                  // :26-28
-                mn = fminf(mn, q[i].y);
-                prod2 = t == 0 ? q[i].z : __fmul_rn(prod2, q[i].z);   // np.cumprod float32 (:20)
-                prod3 = t == 0 ? q[i].w : __fmul_rn(prod3, q[i].w);
-            }
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float4 q = make_float4(0.0f, INFINITY, 1.0f, 1.0f);
+        if (t < T) q = *reinterpret_cast<const float4*>(a + (int64_t)t * 8);
+        n_real += q.x > 0.0f;                                      // :26-28 (a padded lane holds 0)
+        mn = fminf(mn, q.y);
+        const double xd = (double)q.x;                             // np.sum(float32) is pairwise; fp64 then one rounding
+        const int lo = __double2loint(xd), hi = __double2hiint(xd);
+        const int zi = __float_as_int(q.z), wi = __float_as_int(q.w);
+        const int cnt = min(64, T - t0);
+#pragma unroll 8
+        for (int i = 0; i < cnt; ++i) {                            // strictly in step order
+            prod2 = __fmul_rn(prod2, __int_as_float(__builtin_amdgcn_readlane(zi, i)));
+            prod3 = __fmul_rn(prod3, __int_as_float(__builtin_amdgcn_readlane(wi, i)));
+            sum0 += __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_real += __shfl_xor(n_real, off, 64);
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+    }
+    if (lane != 0) return;
     int violate = 0;
     if (prod2 < lo0 || prod2 > hi0) ++violate;    // :23
     if (prod3 < lo1 || prod3 > hi1) ++violate;
@@ -377,7 +386,7 @@ extern "C" int gnnpn_qos_reward_f32(const float* actions, float* R, int32_t B, i
     GNNPN_REQUIRE(B >= 0 && T > 0 && (level == 0 || level == 1), "qos_reward: bad argument");
     if (B == 0) return GNNPN_OK;
     GNNPN_REQUIRE(actions && R, "qos_reward: null operand");
-    hipLaunchKernelGGL(qos_reward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, actions, R, B, T,
+    hipLaunchKernelGGL(qos_reward_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, actions, R, B, T,
                        level);
     GNNPN_CHECK_LAUNCH("qos_reward_f32");
     return GNNPN_OK;

@@ -72,7 +72,7 @@ __device__ __forceinline__ int ror16(int v, int n) {
 }
 
 // DIAG: diagnostic build with phase stamps (tools/stamp_decode.py); production carries none of it.
-// SPLIT: W_hh.h with fp16 hi+lo operands (coop_common.h); everything else as in the fp32 form
+// SPLIT: W_hh.h from exact three-piece fp16 operands (coop_common.h); everything else as in the fp32 form
 // OCC: workgroups per CU the build is sized for — 1 (512 registers: fastest alone) or 2 (256 registers: shares the
 // CU with a workgroup of another launch, pipeline.PipelinedRunner)
 // SAMPLE: the build that can draw the pick from the window softmax (gnnpn_decode_net_t.sample); the greedy builds carry
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                                                                      unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                      int n_nets, int groups_per_net, int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (k-quarter-major, stride LDT) | fp16 hi + lo tiles (stride LDH16 halfs)
+    __shared__ __attribute__((aligned(16))) float hs[SPLIT ? 3 * SPLIT_TILE / 2 : ROWS * LDH16];   // fp32 tile (k-quarter-major, stride LDT) | three fp16 piece tiles (stride LDH16 halfs)
     __shared__ float xs[FOLDX ? 1 : ROWS * LDH];
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
@@ -119,13 +119,16 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     wrow[0] = (0 + (c >> 3)) * H + unit;
     wrow[1] = (2 + (c >> 3)) * H + unit;
     float wBh[SPLIT ? 1 : 2][SPLIT ? 1 : 64], wBx[FOLDX ? 1 : 2][FOLDX ? 1 : 64], bh[2], bi[2], wXf[2][2], sg[2];
-    f16x8 wH16[SPLIT ? 2 : 1][8], wL16[SPLIT ? 2 : 1][8];
+    f16x8 wH16[SPLIT ? 2 : 1][8], wL16[SPLIT ? 2 : 1][8];   // exact split: pieces 0 and 1 (piece 2: LDS bytes, coop_common.h)
+    float winv[2] = {1.0f, 1.0f};
+    __shared__ __attribute__((aligned(16))) unsigned wts[SPLIT ? SPLIT_WT_DWORDS : 4];
+    unsigned* wt_lane = wts + (SPLIT ? (wave * 8 * 64 + lane) * 4 : 0);
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = net.bhh[wrow[tl]];
         if constexpr (SPLIT) {
-            split_weights<H>(net.whh, gate, u, kq, wH16[tl], wL16[tl]);
+            winv[tl] = split_weights<H>(net.whh, gate, u, kq, wH16[tl], wL16[tl], wt_lane + 2 * tl);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 64; ++kk) wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];
@@ -206,7 +209,10 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                             else granule_load2_x8_x4(vh, vp, uniform_ptr(src_h), uniform_ptr(src_p), 16u * lane);
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) good &= (vh[j].y == tag) & (vh[j].w == tag);
+                        for (int j = 0; j < 8; ++j) {
+                            if constexpr (SPLIT) good &= split_pair_tagged(vh[j], tag);
+                            else good &= (vh[j].y == tag) & (vh[j].w == tag);
+                        }
 #pragma unroll
                         for (int j = 0; j < NPJ2; ++j)
                             if (2 * (lane + 64 * j) < n_p) good &= (vp[j].y == tag) & (vp[j].w == tag);
@@ -221,9 +227,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
                     for (int j = 0; j < 8; ++j) {
                         const int i = 2 * (j * 64 + lane);          // even: i and i + 1 share a row
                         if constexpr (SPLIT) {
-                            _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
-                            split_store(h16, __uint_as_float(vh[j].x));
-                            split_store(h16 + 1, __uint_as_float(vh[j].z));
+                            split_pair_to_lds(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), vh[j]);
                         } else {
                             float* d = &hs[ht_index(wave * 4 + (i >> 8), i & 255)];   // units i, i+1: 64 floats apart
                             d[0] = __uint_as_float(vh[j].x);
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
             f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax1 = ah0;
             if constexpr (SPLIT) {
                 f32x4 acc[2] = {ah0, ah1};
-                split_chain<2>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, acc);
+                split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, wt_lane, winv, acc);
                 ah0 = acc[0];
                 ah1 = acc[1];
             } else {
@@ -460,7 +464,10 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
             }
             {
                 u64* dst = out_h + own0 * H + unit;
-                if (same_xcd) {
+                if constexpr (SPLIT) {
+                    split_granule_store(dst, step + 1, hl.x, same_xcd);
+                    split_granule_store(dst + H, step + 1, hl.y, same_xcd);
+                } else if (same_xcd) {
                     granule_store_l2(dst, step + 1, hl.x);
                     granule_store_l2(dst + H, step + 1, hl.y);
                 } else {
@@ -527,7 +534,16 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
     const int64_t a8 = COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
                        tiles * T * ROWS * (int64_t)n_per * 8 + COOP_OVERREAD_BYTES;
     const int64_t a16 = gnnpn_decode_coop2_workspace_bytes(B, T, n_per);
-    return a8 > a16 ? a8 : a16;
+    const int64_t lean = gnnpn_decode_lean_workspace_bytes(B, T, n_per);
+    const int64_t m = a8 > a16 ? a8 : a16;
+    return m > lean ? m : lean;
+}
+
+// device address of the failure record, for the kernels of other translation units (decode_lean.hip)
+unsigned* gnnpn_decode_diag_buffer() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dec_diag)) != hipSuccess) return nullptr;
+    return static_cast<unsigned*>(p);
 }
 
 extern "C" int gnnpn_decode_diag(uint32_t* out, int32_t n_words, int32_t clear) {
@@ -554,6 +570,13 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     for (int n = 0; n < n_nets; ++n)
         if ((args.net[n].xw_fold != nullptr) != fold)
             GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: all nets of a call must use the same input-side form");
+    {   // the shipped configuration (folded input side, greedy picks) runs on the production build, decode_lean.hip;
+        // lstm_ablate bit 6 keeps it on this kernel (A/B runs of tools/ and the both-kernels test)
+        bool any_sample0 = false;
+        for (int n = 0; n < n_nets; ++n) any_sample0 |= args.net[n].sample != 0;
+        if (fold && !any_sample0 && !(gnnpn_option_lstm_ablate() & (32 | 64)) && args.K <= 16)
+            return gnnpn_launch_decode_lean(args, n_nets, precision, shared_cu, opts, workspace, workspace_bytes, s);
+    }
     const int n_tiles = (args.B + ROWS - 1) / ROWS;
     int gpx = n_cu / (8 * G);
     if (gpx > 8) gpx = 8;
@@ -579,7 +602,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    const int abl = (gnnpn_option_lstm_ablate() & ~64) | (opts.write_through ? 128 : 0);
     unsigned* p_s = opts.sticky;
     const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))

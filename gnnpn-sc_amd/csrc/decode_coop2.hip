@@ -37,12 +37,12 @@ __device__ __forceinline__ float ror16v(float v, int n) { return __int_as_float(
 
 // NP = granule loads per lane for the partial dots (= smallest built size >= n_per): sizing the sweep's
 // registers by the actual K keeps the kernel inside 256 registers without spills.
-template <int NP, bool SPLIT>
+template <int NP>
 __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs a, u64* __restrict__ xh,
                                                                       u64* __restrict__ xp, u64* __restrict__ xl,
                                                                       unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                       int n_nets, int groups_per_net, int gpx, int ablate, unsigned* __restrict__ seats) {
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (stride LDH) | fp16 hi + lo tiles (stride LDH16 halfs)
+    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH];     // fp32 h tile (stride LDH)
     __shared__ __attribute__((aligned(16))) float hsl[ROWS][UNITS + 4];
     __shared__ __attribute__((aligned(16))) float part_lin[4][G * 4 * KMAX];   // per wave: the partial dots of its 4 rows, [row%4][cand][member]
     __shared__ float lat[ROWS][KMAX];
@@ -74,14 +74,9 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
     // this lane's gate column: unit = 16m + 4w + (c&3), gate = c>>2
     const int unit = member * UNITS + wave * 4 + (c & 3);
     const int wrow = gate * H + unit;
-    float wBh[SPLIT ? 1 : 64];
-    f16x8 wH16[1][8], wL16[1][8];
-    if constexpr (SPLIT) {
-        split_weights<H>(net.whh, gate, unit, kq, wH16[0], wL16[0]);
-    } else {
+    float wBh[64];
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) wBh[kk] = net.whh[((size_t)(kk * 4 + gate) * H + unit) * 4 + kq];
-    }
+    for (int kk = 0; kk < 64; ++kk) wBh[kk] = net.whh[((size_t)(kk * 4 + gate) * H + unit) * 4 + kq];
     const float bh = net.bhh[wrow], bi = net.xb_fold[wrow], sg = net.start_fold[wrow];
     const float wXf0 = net.xw_fold[wrow * 8 + kq], wXf1 = net.xw_fold[wrow * 8 + 4 + kq];
 
@@ -99,8 +94,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
         __syncthreads();   // previous tile is completely done with the LDS arrays
         for (int j = 0; j < ROWS; ++j) {
             const float h0v = (b0 + j < B) ? net.h0[(int64_t)(b0 + j) * H + tid] : 0.0f;
-            if constexpr (SPLIT) split_store(reinterpret_cast<_Float16*>(hs) + j * LDH16 + tid, h0v);
-            else hs[j * LDH + tid] = h0v;
+            hs[j * LDH + tid] = h0v;
         }
         __syncthreads();
 
@@ -149,10 +143,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int i = j * 64 + lane;
-                        if constexpr (SPLIT)
-                            split_store(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), __uint_as_float(vh[j]));
-                        else
-                            hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
+                        hs[(wave * 4 + (i >> 8)) * LDH + (i & 255)] = __uint_as_float(vh[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
@@ -250,11 +241,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
 
             // ---- decoder LSTM cell: W_hh.h as one k-ordered fma chain per gate column, folded input side
             f32x4 ah = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (SPLIT) {
-                f32x4 acc[1] = {ah};
-                split_chain<1>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, acc);
-                ah = acc[0];
-            } else {
+            {
                 const float* base = hs + c * LDH + kq;
                 float av[2][8];   // A-fragments fetched 8 k-steps ahead (one chain: 8 MFMAs = 256 cycles of cover)
 #pragma unroll
@@ -268,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        ah = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ch & 1][i], wBh[SPLIT ? 0 : 8 * ch + i], ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ch & 1][i], wBh[8 * ch + i], ah, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -379,19 +366,12 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
     const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
     unsigned* p_s = opts.sticky;
-    const bool split = precision == GNNPN_PREC_SPLIT;
+    if (precision == GNNPN_PREC_SPLIT) return GNNPN_E_UNSUP;   // the exact-split product lives in the 8-member builds (decode_coop.hip); callers fall back to them
     const int lds_kb = opts.lds_kb;
 #define GNNPN_DEC2(NP_)                                                                                          \
-    do {                                                                                                         \
-        if (split)                                                                                               \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),           \
-                               coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, true>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl, p_seats);                                 \
-        else                                                                                                     \
-            hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_, false>), dim3(COOP_OVERSUB * groups * G), dim3(256),          \
-                               coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_, false>, lds_kb), s, args, \
-                               p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl, p_seats);                                 \
-    } while (0)
+    hipLaunchKernelGGL((pointer_decode_coop2_kernel<NP_>), dim3(COOP_OVERSUB * groups * G), dim3(256),           \
+                       coop_lds_padding((const void*)pointer_decode_coop2_kernel<NP_>, lds_kb), s, args,         \
+                       p_h, p_p, p_l, p_e, p_s, n_nets, groups_per_net, gpx, abl, p_seats)
     if (args.K <= 5) GNNPN_DEC2(5);
     else if (args.K <= 8) GNNPN_DEC2(8);
     else if (args.K <= 10) GNNPN_DEC2(10);

@@ -53,7 +53,10 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
         granule_reload2_x8_masked(v, src, voff, __ballot(bad));
         bad = false;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bad |= (v[j].y != tag) | (v[j].w != tag);
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (PREC == 2) bad |= !split_pair_tagged(v[j], tag);   // {p0 | tag16, p1 | p2} granules (coop_common.h)
+            else bad |= (v[j].y != tag) | (v[j].w != tag);
+        }
         if (!__any(bad) || nowait) break;
         if (++spins > SPIN_LIMIT) return false;
         for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
@@ -70,8 +73,7 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
             } else {
                 _Float16* h16 = reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255);
                 if constexpr (PREC == 2) {
-                    split_store(h16, __uint_as_float(v[j].x));
-                    split_store(h16 + 1, __uint_as_float(v[j].z));
+                    split_pair_to_lds(h16, v[j]);          // the publisher split the value: three packed stores, no arithmetic
                 } else {
                     h16[0] = (_Float16)__uint_as_float(v[j].x);
                     h16[1] = (_Float16)__uint_as_float(v[j].z);
@@ -90,10 +92,10 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
 // PRE: the input side arrives as stored pre-gates (else: folded, from the raw rows).  DIAG: the diagnostic
 // build (phase stamps / ablation switches of tools/ablate_encode.py); the production instantiation carries
 // none of that code (`ablate` is then the constant 0).
-// PREC 2 = split operands: W_hh and h_{t-1} each as an fp16 pair (hi, lo*2^11), product = hi.hi + (hi.lo + lo.hi)/2^11
-// on the fp16 matrix cores with fp32 accumulation (48 MFMAs per step).  The dropped lo.lo term and the fp16
-// rounding of the two residuals leave a relative error <= 3*2^-22 per term — the size of fp32's own
-// accumulation-order noise — at about a fifth of the fp32-MFMA issue time.  Opt-in; see DESIGN.md.
+// PREC 2 = exact-split operands (coop_common.h): W_hh and h_{t-1} each as THREE fp16 pieces that reproduce the fp32 value
+// bit for bit, every cross term that can reach 2^-24 of a product kept (6 products on the fp16 matrix cores, fp32
+// accumulation in three magnitude classes: 96 MFMAs of 16 cycles per step instead of 128 of 32).  h travels between the
+// members already split (the publisher splits its own value once).  Error bound and measurements: DESIGN.md section 12.
 template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, unsigned* __restrict__ sticky,
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                                                                   int gpx, int ablate_arg, unsigned* __restrict__ seats) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDH16];   // fp32 tile (k-quarter-major, stride LDT) | fp16 hi tile + lo tile (stride LDH16 halfs)
+    constexpr int HS_FLOATS = PREC == 2 ? 3 * SPLIT_TILE / 2 : ROWS * LDH16;
+    __shared__ __attribute__((aligned(16))) float hs[HS_FLOATS];      // fp32 tile (k-quarter-major, stride LDT) | fp16 tile | three fp16 piece tiles (stride LDH16 halfs)
     __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS];   // own h slice, staged for whole-line stores
     __shared__ int abort_flag;
 
@@ -131,13 +134,16 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     wrow[1] = (2 + (c >> 3)) * H + unit;
     float wB[F16 ? 1 : 2][F16 ? 1 : 64], bh[2], wX[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {0.f, 0.f};
     f16x8 wB16[F16 ? 2 : 1][8];   // fp16 B-fragments: lane (c, kq) holds W[col c][32kk + 8kq + j], j = 0..7
-    f16x8 wL16[SPLIT ? 2 : 1][8];   // split: the scaled low halves
+    f16x8 wL16[SPLIT ? 2 : 1][8];                            // exact split: the second pieces (the third: LDS, coop_common.h)
+    float winv[2] = {1.0f, 1.0f};                            // ... and the columns' un-scaling factors
+    __shared__ __attribute__((aligned(16))) unsigned wts[SPLIT ? SPLIT_WT_DWORDS : 4];
+    unsigned* wt_lane = wts + (SPLIT ? (wave * 8 * 64 + lane) * 4 : 0);
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = nets.bhh[net][wrow[tl]];
         if constexpr (SPLIT) {
-            split_weights<H>(Wp, gate, u, kq, wB16[tl], wL16[tl]);
+            winv[tl] = split_weights<H>(Wp, gate, u, kq, wB16[tl], wL16[tl], wt_lane + 2 * tl);
         } else if constexpr (F16) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             // this member is about to overwrite.
             bool ok = true;
             if (t == 0) {
-                for (int i = threadIdx.x; i < ROWS * LDH16; i += 256) hs[i] = 0.0f;
+                for (int i = threadIdx.x; i < HS_FLOATS; i += 256) hs[i] = 0.0f;
                 if (!first_tile) ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
             } else if (!(ablate & 8)) {
                 ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true, ablate & 4);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             if constexpr (SPLIT) {
                 if (t > 0) {
                     f32x4 acc[2] = {acc0, acc1};
-                    split_chain<2>(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wB16, wL16, acc);
+                    split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wB16, wL16, wt_lane, winv, acc);
                     acc0 = acc[0];
                     acc1 = acc[1];
                 }
@@ -287,7 +293,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             {
                 const int r0 = kq * 4 + (c < 8 ? 0 : 2);
                 u64* dst = out_buf + r0 * H + unit;
-                if (!(ablate & 16)) {
+                if constexpr (SPLIT) {
+                    split_granule_store(dst, step + 1, hlast.x, same_xcd);
+                    split_granule_store(dst + H, step + 1, hlast.y, same_xcd);
+                } else if (!(ablate & 16)) {
                     if (same_xcd) {
                         granule_store_l2(dst, step + 1, hlast.x);
                         granule_store_l2(dst + H, step + 1, hlast.y);

@@ -755,3 +755,27 @@ def adam_step(p, g, m, v, sumsq, max_grad_norm, lr, step, beta1=0.9, beta2=0.999
     check(_lib.load().gnnpn_adam_step_f32(dev_ptr(p, F32, "p"), dev_ptr(g, F32, "g"), dev_ptr(m, F32, "m"), dev_ptr(v, F32, "v"),
                                           p.numel(), dev_ptr(sumsq, F64, "sumsq"), float(max_grad_norm), float(lr), float(beta1),
                                           float(beta2), float(eps), int(step), stream_ptr()), "gnnpn_adam_step_f32")
+
+
+def split3_pieces(x, scale_log2=0):
+    """The three fp16 pieces (as int16 bit patterns, [3, n]) of x * 2^scale_log2 as the recurrent kernels form them
+    (GNNPN_PREC_SPLIT; csrc/coop_common.h::split3)."""
+    x = x.contiguous().view(-1)
+    out = torch.empty((3, x.numel()), dtype=torch.int16, device=x.device)
+    check(_lib.load().gnnpn_split3_pieces_f32(dev_ptr(x, F32, "x"), x.numel(), int(scale_log2), out[0].data_ptr(), out[1].data_ptr(),
+                                              out[2].data_ptr(), stream_ptr()), "gnnpn_split3_pieces_f32")
+    return out
+
+
+def recurrent_product(whh_packed, h, precision="f32"):
+    """gates [16, 4H] = h [16, H] . W_hh^T (H = 256; W_hh packed by pack_lstm_weight) by the fp32 MFMA chain or the exact
+    split of the cooperative kernels -> (gates, col_inv [4H] or None)."""
+    if h.shape != (16, 256) or whh_packed.numel() != 4 * 256 * 256:
+        raise GnnpnError("recurrent_product: h [16,256] and a packed [64,4,256,4] W_hh expected")
+    h, whh_packed = h.contiguous(), whh_packed.contiguous()
+    gates = torch.empty((16, 1024), dtype=F32, device=h.device)
+    prec = _PRECISIONS[precision]
+    inv = torch.empty(1024, dtype=F32, device=h.device) if prec == 2 else None
+    check(_lib.load().gnnpn_recurrent_product_f32(dev_ptr(whh_packed, F32, "whh"), dev_ptr(h, F32, "h"), prec, dev_ptr(gates, F32, "gates"),
+                                                  inv.data_ptr() if inv is not None else None, stream_ptr()), "gnnpn_recurrent_product_f32")
+    return gates, inv

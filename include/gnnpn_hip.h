@@ -207,8 +207,11 @@ typedef struct {
 /* precision: operands of the recurrent W_hh.h product (accumulation, cell, outputs are fp32 in every mode)
  *   GNNPN_PREC_F32   fp32 (the parity path)
  *   GNNPN_PREC_F16   fp16 operands, encoder only: opt-in reduced precision (BASELINE configs[4])
- *   GNNPN_PREC_SPLIT every operand as an fp16 pair (hi, lo*2^11), product = hi.hi + (hi.lo + lo.hi)/2^11 with fp32
- *                    accumulation — measured as accurate as the fp32 chain against an fp64 LSTM
+ *   GNNPN_PREC_SPLIT every operand as THREE fp16 pieces that reproduce the fp32 value bit for bit (x 2^s = p0 + p1/2^11 +
+ *                    p2/2^22), every cross term that can reach 2^-24 of a product kept (6 products on the fp16 matrix
+ *                    cores), fp32 accumulation in three magnitude classes: fp32 operands, fp32 result, no operand bit
+ *                    dropped; error bound <= the fp32 fma chain's (gnnpn_split3_pieces_f32 and
+ *                    gnnpn_recurrent_product_f32 below expose the arithmetic to the tests)
  * F16/SPLIT need the cooperative form (H = 256 and a workspace): GNNPN_E_UNSUP otherwise. */
 #define GNNPN_PREC_F32 0
 #define GNNPN_PREC_F16 1
@@ -494,6 +497,18 @@ int gnnpn_bce_sigmoid_f32(const float* p, const float* y, int64_t n, float* dz, 
 int gnnpn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 int gnnpn_embed_grad_f32(const float* dh, int64_t ldh, const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t vocab,
                          float* dtable, void* stream);
+
+/* ---- the exact-split arithmetic on its own (what GNNPN_PREC_SPLIT computes; used by tests/test_split3.py) ----
+ * The reference multiplies W_hh and h in fp32 inside nn.LSTM (/root/reference/src/models/modelPN.py:157-158,191,205); these two
+ * entry points run the device functions the cooperative kernels inline, nothing else:
+ * gnnpn_split3_pieces_f32: the three fp16 pieces (bit patterns) of x[i] * 2^scale_log2; their sum p0 + p1/2^11 + p2/2^22 is
+ *   x[i] * 2^scale_log2 exactly whenever x[i] 2^scale_log2 lies in [2^-23, 65504] in magnitude or is zero.
+ * gnnpn_recurrent_product_f32: gates[16][4H] = h[16][H] . W_hh^T, H = 256, W_hh in the packed recurrent layout
+ *   ([H/4][4 gates][H][4]), with the fp32 MFMA chain (GNNPN_PREC_F32) or the exact split (GNNPN_PREC_SPLIT; col_inv [4H]
+ *   receives each gate column's un-scaling factor 2^-(15+s)). */
+int gnnpn_split3_pieces_f32(const float* x, int64_t n, int32_t scale_log2, uint16_t* p0, uint16_t* p1, uint16_t* p2, void* stream);
+int gnnpn_recurrent_product_f32(const float* whh_packed, const float* h, int32_t precision, float* gates, float* col_inv,
+                                void* stream);
 
 #ifdef __cplusplus
 }

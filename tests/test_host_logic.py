@@ -211,6 +211,55 @@ def test_all_gather_of_indices_gloo_world2():
     assert res == [(0, True, True, 2.0), (1, True, True, 2.0)]
 
 
+def _gloo8_worker(rank, world, port, q):
+    """What a bench.py rank does around its steps at N = 8 (bench.py::main): environment as torchrun / self_launch set it,
+    strong-scaling shard of the global batch, the asynchronous equal-shard all-gather of idx [B/N, T] -> [B, T], the
+    barrier + MAX-over-ranks timing reduction."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
+    from gnnpn_sc_amd import dist
+    dist.init_process_group("gloo")
+    G, T = 64, 47                                                     # global batch of a strong-scaling step, QWS steps
+    full = (torch.arange(G * T, dtype=torch.int32) * 7 % 235).view(G, T)
+    lo, hi = dist.shard_range(G, rank, world)
+    out, work = dist.all_gather_indices_async(full[lo:hi].clone())
+    if work is not None:
+        work.wait()
+    out2, _ = dist.all_gather_indices_async(full[lo:hi].clone(), out)     # the gathered buffer is reused step after step
+    dist.barrier(world)
+    t = dist.max_over_ranks(0.001 * (rank + 1), torch.device("cpu"), world)
+    q.put((rank, tuple(out.shape), torch.equal(out, full), out2 is out or torch.equal(out2, full), round(t, 6)))
+    dist.destroy(world)
+
+
+def test_eight_rank_launch_path_gloo():
+    """The N = 8 run belongs to the driver's 8-GPU node; its launch-side logic is rehearsed here with eight gloo ranks:
+    rank environment, shard ranges that tile the global batch, all-gather shape [8 * B/8, T] in rank order, max-over-ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    world = 8
+    procs = [ctx.Process(target=_gloo8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, (64, 47), True, True, 0.008) for r in range(world)]
+
+
+def test_numa_binding_reads_sysfs_only(monkeypatch):
+    """bench.bind_to_gpu_numa_node: no GPU in this container -> it reports why it did not bind, and it never raises."""
+    import importlib
+    import sys
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    info = bench.bind_to_gpu_numa_node(3)
+    assert info["bound"] in (True, False) and ("why" in info or "numa_node" in info)
+    assert bench.usable_cpus() >= 1
+
+
 def test_batch_shard_is_a_partition():
     import gnnpn_sc_amd.synth as synth
     from gnnpn_sc_amd.pipeline import DeviceBatch

@@ -1,0 +1,177 @@
+"""The exact-split precision (GNNPN_PREC_SPLIT): operand decomposition and recurrent product on their own.
+
+VERDICT r2 item 2 asked for (i) sum(pieces) == operand bit for bit over random and adversarial operands, on the CPU
+restatement and on the GPU; (ii) an error bound no larger than the fp32 fma chain's, checked against exact dot products.
+The CPU tests pin oracle/split3.py (numpy float16 = IEEE round-to-nearest-even); the GPU tests pin the device functions
+the cooperative kernels inline (csrc/coop_common.h) to that oracle bit for bit and measure the product's error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import split3 as o3
+
+U = 2.0 ** -24          # unit roundoff of fp32
+
+
+def _bits(f):
+    return np.asarray(f, dtype=np.float32).view(np.uint32)
+
+
+def _adversarial(rng):
+    """fp32 values inside the exact domain of the decomposition (|x| in [2^-23, 65504], or 0)."""
+    v = []
+    v += [0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 2.0 ** -23, -(2.0 ** -23), 2.0 ** -14, 2.0 ** -15, 2.0 ** 15]
+    v += [np.float32(1.0) + np.float32(2.0 ** -23), np.float32(2.0) - np.float32(2.0 ** -23)]            # 1 + ulp, all-ones mantissa
+    for e in (-22, -14, -13, -1, 0, 7, 14, 15):                                                           # per binade
+        for m in (0x7FFFFF, 0x555555, 0x2AAAAA, 0x000001, 0x001000, 0x000FFF, 0x001001, 0x0017FF, 0x001800, 0x001801,
+                  0x7FF000, 0x7FEFFF, 0x7FF001, 0x400000, 0x3FFFFF, 0x000800, 0x0007FF, 0x000801):
+            x = np.array([((127 + e) << 23) | m], dtype=np.uint32).view(np.float32)[0]
+            if abs(float(x)) <= 65504.0:
+                v += [x, -x]
+    # ties of the first and of the second rounding: p0 +- half an fp16 ulp (+- one fp32 ulp), and the same one level down
+    for p0 in (1.0, 1.5, 1024.0, 0.333251953125, 32752.0):
+        h16 = float(np.spacing(np.float16(p0))) / 2
+        for d in (-1, 0, 1):
+            x = np.float32(p0 + h16)
+            x = np.nextafter(x, np.float32(np.inf)) if d > 0 else (np.nextafter(x, np.float32(-np.inf)) if d < 0 else x)
+            v += [x, -x]
+            y = np.float32(p0 + h16 / 2048 * 1.0)
+            v += [y, -y]
+    r = rng.standard_normal(20000).astype(np.float32) * np.float32(0.1)                                   # weight-like
+    v += list(r[np.abs(r) >= 2.0 ** -23])
+    r = (rng.random(20000, dtype=np.float32) * 2 - 1) * np.exp2(rng.integers(-22, 16, 20000)).astype(np.float32)
+    v += list(r[(np.abs(r) >= 2.0 ** -23) & (np.abs(r) <= 65504)])
+    bits = rng.integers(0, 2 ** 32, 40000, dtype=np.uint64).astype(np.uint32).view(np.float32)           # random bit patterns
+    ok = np.isfinite(bits) & (np.abs(bits) >= 2.0 ** -23) & (np.abs(bits) <= 65504)
+    v += list(bits[ok])
+    return np.array(v, dtype=np.float32)
+
+
+def test_pieces_sum_to_the_operand_bit_for_bit():
+    rng = np.random.default_rng(0)
+    x = _adversarial(rng)
+    p0, p1, p2 = o3.pieces(x)
+    assert np.isfinite(p0.astype(np.float64)).all()
+    back = o3.recompose(p0, p1, p2)
+    assert np.array_equal(back, x.astype(np.float64))                       # every bit of every operand
+    nz = x != 0
+    assert np.array_equal(_bits(back.astype(np.float32))[nz], _bits(x)[nz])
+    # the third piece is zero or ONE power of two wherever the first piece is a normal fp16 number ...
+    normal = np.abs(x) >= 2.0 ** -14
+    m2 = np.frexp(np.abs(p2[normal].astype(np.float64)))[0]
+    assert np.isin(m2, (0.0, 0.5)).all()
+    # ... so the byte the kernels keep of a WEIGHT's third piece loses nothing there
+    assert np.array_equal(o3.third_piece_byte(p2[normal]), p2[normal])
+    assert (p2 != 0).mean() > 0.1                                           # and it is not vacuous: the third piece is used
+
+
+def test_scaled_operands_as_the_kernels_scale_them():
+    """h in [-1, 1] is scaled by 2^15, a weight column by 2^s with its largest element in [2^14, 2^15): every element
+    within 2^-38 (h) / 2^-29 (W, third piece kept as a byte) of the maximum is exact; below that the error is < 2^-52 of the
+    maximum — the domain edges the header documents."""
+    rng = np.random.default_rng(1)
+    h = np.concatenate([rng.random(5000, dtype=np.float32) * 2 - 1, [1.0, -1.0, 2.0 ** -38, 3e-12, 1e-7, 0.99999994],
+                        np.exp2(rng.integers(-37, 0, 2000)).astype(np.float32) * (rng.random(2000, dtype=np.float32) + 1) / 2]).astype(np.float32)
+    p = o3.pieces(h, o3.H_SCALE_LOG2)
+    assert np.array_equal(o3.recompose(*p), h.astype(np.float64) * 2.0 ** 15)
+    for cmax in (0.0625, 1e-20, 3.7e4, 1.0, 5e-3):
+        col = (rng.standard_normal(256) * cmax / 4).astype(np.float32)
+        col[0] = np.float32(cmax)
+        col[1] = np.float32(cmax * 2.0 ** -28.5)                            # near the byte-exact edge, inside
+        col[2] = np.float32(cmax * 2.0 ** -37)                              # outside it: rounded third piece
+        s = o3.column_scale_log2(col)
+        assert 2.0 ** 14 <= float(np.abs(col).max()) * 2.0 ** s < 2.0 ** 15
+        q0, q1, q2 = o3.pieces(col, s)
+        scaled = col.astype(np.float64) * 2.0 ** s
+        exact = np.abs(scaled) >= 2.0 ** -14
+        assert np.array_equal(o3.recompose(q0, q1, o3.third_piece_byte(q2))[exact], scaled[exact])
+        err = np.abs(o3.recompose(q0, q1, o3.third_piece_byte(q2)) - scaled)
+        assert err.max() <= 2.0 ** -37                                      # = 2^-52 of the scaled maximum 2^15
+
+
+def _exact_product(W, h):
+    return (h.astype(np.longdouble) @ W.astype(np.longdouble).T).astype(np.float64)
+
+
+def _cases(rng):
+    H = 256
+    out = {}
+    W = ((rng.random((4 * H, H), dtype=np.float32) * 2 - 1) / 16).astype(np.float32)           # nn.LSTM default init
+    h = np.tanh(rng.standard_normal((16, H))).astype(np.float32)
+    out["default_init"] = (W, h)
+    out["saturated_h"] = (W, np.sign(rng.standard_normal((16, H))).astype(np.float32))
+    Wc = np.tile(np.array([0.0625, -0.0625], dtype=np.float32), (4 * H, H // 2)) * (1 + rng.integers(0, 2 ** 12, (4 * H, H)).astype(np.float32) * np.float32(2.0 ** -23))
+    out["cancelling_columns"] = (Wc.astype(np.float32), np.full((16, H), 0.7853982, dtype=np.float32))
+    Ws = W * np.exp2(rng.integers(-60, 14, (4 * H, 1))).astype(np.float32)                        # every column its own scale
+    out["column_scales_2^-64..2^10"] = (Ws.astype(np.float32), h)
+    hb = (h * np.exp2(rng.integers(-20, 1, (16, H)))).astype(np.float32)
+    out["wide_range_h"] = (W, hb)
+    allones = np.array([0x3D7FFFFF], dtype=np.uint32).view(np.float32)[0]                          # 0.0625 - ulp: 24 one-bits
+    out["all_mantissa_bits"] = (np.full((4 * H, H), allones, dtype=np.float32), np.full((16, H), np.float32(0.99999994)))
+    return out
+
+
+def test_kept_terms_reach_2e_minus_32():
+    """The six kept products with EXACT accumulation: what is dropped is below 2^-32 of sum |h w| (the fp32 chain's own
+    rounding is 2^-24 of its partial sums, 256 times)."""
+    rng = np.random.default_rng(2)
+    for name, (W, h) in _cases(rng).items():
+        got = o3.recurrent_product(W[:64], h)
+        ref = _exact_product(W[:64], h)
+        mag = np.abs(h).astype(np.float64) @ np.abs(W[:64]).astype(np.float64).T
+        assert (np.abs(got - ref) <= 2.0 ** -32 * mag + 1e-300).all(), name
+
+
+@pytest.fixture
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_gpu_pieces_equal_the_oracle_bit_for_bit(dev):
+    from gnnpn_sc_amd import ops
+    rng = np.random.default_rng(0)
+    x = _adversarial(rng)
+    for s in (0, 15, -3):
+        xs = x[(np.abs(x.astype(np.float64)) * 2.0 ** s <= 65504) & ((np.abs(x.astype(np.float64)) * 2.0 ** s >= 2.0 ** -23) | (x == 0))]
+        got = ops.split3_pieces(torch.from_numpy(xs).to(dev), s).cpu().numpy().view(np.uint16)
+        want = o3.pieces(xs, s)
+        for i in range(3):                                                  # bit patterns (a zero piece may carry either sign)
+            g, w = got[i], want[i].view(np.uint16)
+            assert np.array_equal(np.where((g & 0x7fff) == 0, 0, g), np.where((w & 0x7fff) == 0, 0, w)), (s, i)
+        assert np.array_equal(o3.recompose(*[g.view(np.float16) for g in got]), xs.astype(np.float64) * 2.0 ** s)
+
+
+@pytest.mark.gpu
+def test_gpu_recurrent_product_error_against_the_fp32_chain(dev):
+    """W_hh.h from the exact split against the exact dot product, beside the fp32 MFMA chain (the parity path): the a-priori
+    bounds (163 u sum|h w| for the split, 256 u sum|h w| for the chain) hold on every entry, the split's
+    measured error is not larger than the chain's, and the result equals the exactly-accumulated six-term product up to the
+    accumulation error alone."""
+    from conftest import record_agreement
+    from gnnpn_sc_amd import ops
+    rng = np.random.default_rng(2)
+    rec = {}
+    for name, (W, h) in _cases(rng).items():
+        Wp = ops.pack_lstm_weight(torch.from_numpy(W)).to(dev)
+        hd = torch.from_numpy(h).to(dev)
+        g32, _ = ops.recurrent_product(Wp, hd, "f32")
+        gsp, inv = ops.recurrent_product(Wp, hd, "split")
+        g32, gsp, inv = g32.cpu().numpy().astype(np.float64), gsp.cpu().numpy().astype(np.float64), inv.cpu().numpy()
+        want_inv = np.array([2.0 ** -(15 + o3.column_scale_log2(W[c])) for c in range(W.shape[0])], dtype=np.float32)
+        assert np.array_equal(inv, want_inv), name
+        ref = _exact_product(W, h)
+        mag = np.abs(h).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1e-300
+        e32, esp = np.abs(g32 - ref) / (U * mag), np.abs(gsp - ref) / (U * mag)
+        ideal = o3.recurrent_product(W, h)
+        rec[name] = {"fp32_chain_max_u": float(e32.max()), "fp32_chain_mean_u": float(e32.mean()),
+                     "split_max_u": float(esp.max()), "split_mean_u": float(esp.mean()),
+                     "split_vs_exactly_accumulated_terms_max_u": float((np.abs(gsp - ideal) / (U * mag)).max())}
+        assert e32.max() <= 256.0, (name, rec[name])
+        assert esp.max() <= 163.0, (name, rec[name])
+        assert esp.mean() <= 1.25 * e32.mean() + 0.05, (name, rec[name])
+        assert esp.max() <= 1.5 * e32.max() + 1.0, (name, rec[name])
+    record_agreement("split3_recurrent_product_error_in_u_sum_abs", rec)
