@@ -574,7 +574,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
         // lstm_ablate bit 6 keeps it on this kernel (A/B runs of tools/ and the both-kernels test)
         bool any_sample0 = false;
         for (int n = 0; n < n_nets; ++n) any_sample0 |= args.net[n].sample != 0;
-        if (fold && !any_sample0 && !(gnnpn_option_lstm_ablate() & (32 | 64)) && args.K <= 16)
+        if (fold && !any_sample0 && !(gnnpn_option_lstm_ablate() & 64) && args.K <= 16)
             return gnnpn_launch_decode_lean(args, n_nets, precision, shared_cu, opts, workspace, workspace_bytes, s);
     }
     const int n_tiles = (args.B + ROWS - 1) / ROWS;
@@ -602,7 +602,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    const int abl = (gnnpn_option_lstm_ablate() & ~64) | (opts.write_through ? 128 : 0);
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);
     unsigned* p_s = opts.sticky;
     const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))

@@ -58,10 +58,29 @@ __device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t r, unsigned
     if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
     else __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX_SC1);
 }
+// failure record of a timed-out sweep (read by gnnpn_decode_diag; layout: decode_coop.hip) — failure path only
+__device__ __forceinline__ void record_failure(unsigned* diag, const unsigned* err, int group, int member, int tile, int k, int wave,
+                                               unsigned tag, unsigned h_miss, unsigned p_miss, unsigned l_miss, int gpx) {
+    if ((threadIdx.x & 63) != 0 || !diag) return;
+    const unsigned n = atomicAdd(diag, 1u);
+    if (n >= 31) return;
+    unsigned* rec = diag + 16 * (n + 1);
+    const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
+    unsigned c0 = 0, c1 = 0;
+    for (int x = 0; x < 4; ++x) {
+        c0 |= (cnt[x] & 0xffu) << (8 * x);
+        c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
+    }
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    rec[0] = group; rec[1] = member; rec[2] = tile; rec[3] = k; rec[4] = wave; rec[5] = tag;
+    rec[6] = h_miss; rec[7] = p_miss; rec[8] = l_miss; rec[9] = c0; rec[10] = c1;
+    rec[11] = (unsigned)t; rec[12] = (unsigned)(t >> 32); rec[13] = gpx; rec[14] = blockIdx.x; rec[15] = err[0];
+}
 }  // namespace
 
 // EVH: lanes per (row, candidate) in the partial dots: 2 (n_per <= 8: 16 floats of the slice each) or 1 (n_per <= 16)
-template <bool SPLIT, int OCC, int EVH>
+// DIAG: the diagnostic build with phase stamps (tools/stamp_decode.py; lstm_ablate bit 11) — timing only, never a measured run
+template <bool SPLIT, int OCC, int EVH, bool DIAG = false>
 __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArgs a, u64* xh, u64* xp,
                                                                      u64* xl, unsigned* __restrict__ err,
                                                                      unsigned* __restrict__ sticky, int n_nets, int groups_per_net,
@@ -178,24 +197,98 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
 
         for (int k = 0; k <= T; ++k) {
             float axf0 = 0.0f, axf1 = 0.0f;
+            u64 st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (DIAG) st[0] = st[1] = st[2] = st[3] = st[4] = st[5] = phase_stamp();
+            const unsigned tag = step;                           // publish #(step-1) carries tag `step`
+            const unsigned par = (step - 1) & 1;
+            const unsigned so_k = (unsigned)k * (unsigned)K;
+            float4 ev[EVN];
+            f32x4 ah[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+            // ---- (1) h_{k-1}: peers published it BEFORE their partial dots, so it is (nearly) there when this member has
+            // published its own; the W_hh.h products start on it while the partial dots are still in flight
+            if (k < T) {
+                if (k > 0) {
+                    const unsigned so_h0 = par * (ROWS * H * 8) + wave * (4 * H * 8);
+                    u32x4 vh[8];
+                    bool ok = false;
+                    unsigned h_miss = 0;
+                    for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
+                        // The scalar offset passes through an empty asm every pass: the optimiser must not treat a sweep load
+                        // as loop-invariant (the first build's ISA had the h loads hoisted ABOVE the polling loop — a pass that
+                        // came too early was then repeated over stale registers until the spin bound).
+                        unsigned so_h = so_h0;
+                        asm volatile("" : "+s"(so_h));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) vh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, vo_sweep + 1024 * j, so_h, AUX_SC1);
+                        bool good = true;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if constexpr (SPLIT) good &= split_pair_tagged(vh[j], tag);
+                            else good &= (vh[j].y == tag) & (vh[j].w == tag);
+                        }
+                        if (__all(good)) {
+                            ok = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if constexpr (DIAG) st[1] = phase_stamp();
+                    if (!ok) {   // failure path only: whose h is missing (pair j of lane l: member 4 (j & 1) + l / 16)
+                        abort_flag = 1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            bool bad;
+                            if constexpr (SPLIT) bad = !split_pair_tagged(vh[j], tag);
+                            else bad = (vh[j].y != tag) | (vh[j].w != tag);
+                            const unsigned long long bm = __ballot(bad);
+                            for (int q = 0; q < 4; ++q)
+                                if ((bm >> (16 * q)) & 0xffffull) h_miss |= 1u << (4 * (j & 1) + q);
+                        }
+                        record_failure(diag, err, group, member, tile, k, wave, tag, h_miss, 0u, 0u, gpx);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 2 * (j * 64 + lane);          // even: units i and i + 1 of one row
+                        if constexpr (SPLIT) {
+                            split_pair_to_lds(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), vh[j]);
+                        } else {
+                            float* d = &hs[ht_index(wave * 4 + (i >> 8), i & 255)];   // 64 floats apart (k-quarter-major)
+                            d[0] = __uint_as_float(vh[j].x);
+                            d[64] = __uint_as_float(vh[j].z);
+                        }
+                    }
+                    __syncthreads();   // the h tile of every wave is complete
+                    if (abort_flag) break;
+                }
+                if constexpr (DIAG) st[2] = phase_stamp();
+                // this step's window: enc_out rows against the own 32-unit slice (consumed after the cell update)
+                if (pdot) {
+#pragma unroll
+                    for (int j = 0; j < EVN; ++j) {
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev + 16 * j, so_k * (H * 4), 0);
+                        ev[j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                    }
+                }
+                // ---- (2) W_hh.h (the folded input side follows the pick, below)
+                if constexpr (SPLIT) split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, wt_lane, winv, ah);
+                else mfma_chain_pair<LDT, OCC == 2 ? 8 : 16, true>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah[0], ah[1]);
+                if constexpr (DIAG) {
+                    asm volatile("" ::"v"(ah[0][0]), "v"(ah[1][0]));
+                    st[3] = phase_stamp();
+                }
+            }
+
+            // ---- (3) the partial dots of publish #(step-1) (+ Low's window logits): they crossed while (2) ran
             if (k > 0) {
-                // ---- hand-off of publish #(step-1): h_{k-1}, the partial dots, Low's window logits — one sweep
-                const unsigned tag = step;
-                const unsigned par = (step - 1) & 1;
-                const unsigned so_h0 = par * (ROWS * H * 8) + wave * (4 * H * 8);
                 const unsigned so_p0 = par * (XP_GRANULES * 8) + wave * (4 * KW * G * 8);
                 const unsigned so_l0 = (unsigned)(((k - 1) * ROWS + wave * 4) * K) * 8u;
-                u32x4 vh[8], vp[4];
+                u32x4 vp[4];
                 u32x2 vl = {0u, 1u};
                 bool ok = false;
                 for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
-                    // The scalar offsets pass through an empty asm every pass: the optimiser must not treat a sweep load as
-                    // loop-invariant (the first build's ISA had the h loads hoisted ABOVE the polling loop — a pass that came
-                    // too early was then repeated over stale registers until the spin bound).
-                    unsigned so_h = so_h0, so_p = so_p0, so_l = so_l0;
-                    asm volatile("" : "+s"(so_h), "+s"(so_p), "+s"(so_l));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, vo_sweep + 1024 * j, so_h, AUX_SC1);
+                    unsigned so_p = so_p0, so_l = so_l0;
+                    asm volatile("" : "+s"(so_p), "+s"(so_l));
                     bool good = true;
                     if (live) {
 #pragma unroll
@@ -205,62 +298,22 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                         for (int j = 0; j < 4; ++j) good &= (vp[j].y == tag) & (vp[j].w == tag);
                         good &= vl.y == 1u;
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if constexpr (SPLIT) good &= split_pair_tagged(vh[j], tag);
-                        else good &= (vh[j].y == tag) & (vh[j].w == tag);
-                    }
                     if (__all(good)) {
                         ok = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (!ok) {   // failure path only: who was missing (read by gnnpn_decode_diag; layout: decode_coop.hip)
+                if constexpr (DIAG) st[4] = phase_stamp();
+                if (!ok) {
                     abort_flag = 1;
-                    unsigned h_miss = 0, p_miss = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {               // pair j of lane l: units 128 (j & 1) + 2 l, i.e. member 4 (j & 1) + l / 16
-                        bool bad;
-                        if constexpr (SPLIT) bad = !split_pair_tagged(vh[j], tag);
-                        else bad = (vh[j].y != tag) | (vh[j].w != tag);
-                        const unsigned long long bm = __ballot(bad);
-                        for (int q = 0; q < 4; ++q)
-                            if ((bm >> (16 * q)) & 0xffffull) h_miss |= 1u << (4 * (j & 1) + q);
-                    }
+                    unsigned p_miss = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (__ballot(live && vp[j].y != tag)) p_miss |= 1u << (2 * j);
                         if (__ballot(live && vp[j].w != tag)) p_miss |= 1u << (2 * j + 1);
                     }
-                    const unsigned long long l_miss = __ballot(live && vl.y != 1u);
-                    if (lane == 0 && diag) {
-                        const unsigned n = atomicAdd(diag, 1u);
-                        if (n < 31) {
-                            unsigned* rec = diag + 16 * (n + 1);
-                            const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
-                            unsigned c0 = 0, c1 = 0;
-                            for (int x = 0; x < 4; ++x) {
-                                c0 |= (cnt[x] & 0xffu) << (8 * x);
-                                c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
-                            }
-                            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-                            rec[0] = group; rec[1] = member; rec[2] = tile; rec[3] = k; rec[4] = wave; rec[5] = tag;
-                            rec[6] = h_miss; rec[7] = p_miss; rec[8] = (unsigned)__popcll(l_miss); rec[9] = c0; rec[10] = c1;
-                            rec[11] = (unsigned)t; rec[12] = (unsigned)(t >> 32); rec[13] = gpx; rec[14] = blockIdx.x; rec[15] = err[0];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = 2 * (j * 64 + lane);          // even: units i and i + 1 of one row
-                    if constexpr (SPLIT) {
-                        split_pair_to_lds(reinterpret_cast<_Float16*>(hs) + (wave * 4 + (i >> 8)) * LDH16 + (i & 255), vh[j]);
-                    } else {
-                        float* d = &hs[ht_index(wave * 4 + (i >> 8), i & 255)];   // 64 floats apart (k-quarter-major)
-                        d[0] = __uint_as_float(vh[j].x);
-                        d[64] = __uint_as_float(vh[j].z);
-                    }
+                    record_failure(diag, err, group, member, tile, k, wave, tag, 0u, p_miss, (unsigned)__popcll(__ballot(live && vl.y != 1u)), gpx);
                 }
 
                 // ---- logits and first-max argmax: lane (rq, r) = (row 4 wave + rq, candidate r)
@@ -295,7 +348,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                         if (first) __builtin_amdgcn_raw_buffer_store_b32((unsigned)((k - 1) * K + pick_r), r_idx, vo_idx, (unsigned)(k - 1) * 4u, 0);
                     }
                 }
-                __syncthreads();   // the h tile of every wave, sel[] (and win[], written a step ago) are complete
+                __syncthreads();   // sel[] is complete (win[] was written a step ago)
                 if (abort_flag) break;
                 // raw 8-feature row of the pick as MFMA A-fragments (row c, k = 4 kk2 + kq) out of the staged window
                 axf0 = win[c][sel[c]][kq];
@@ -305,25 +358,12 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(axf1), r_act, vo_act + 16, (unsigned)(k - 1) * 32u, 0);
                 }
                 if (k == T) break;
+                if constexpr (DIAG) st[5] = phase_stamp();
             }
 
-            // this step's window: enc_out rows against the own 32-unit slice, and the raw rows for the next pick
-            const unsigned so_k = (unsigned)k * (unsigned)K;
-            float4 ev[EVN];
-            if (pdot) {
-#pragma unroll
-                for (int j = 0; j < EVN; ++j) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev + 16 * j, so_k * (H * 4), 0);
-                    ev[j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-                }
-            }
-
-            // ---- decoder LSTM cell: W_hh.h and the folded input side as independent chains per gate column
-            f32x4 ah[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            if constexpr (SPLIT) split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, wt_lane, winv, ah);
-            else mfma_chain_pair<LDT, OCC == 2 ? 8 : 16, true>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah[0], ah[1]);
-            // the raw rows of this step's window (the next pick's decoder input comes out of them): requested behind the
-            // MFMA chain — they are consumed at the end of the step — so that they are not live across it
+            // ---- (4) folded input side, cell update, publish h_k
+            // the raw rows of this step's window (the next pick's decoder input comes out of them): requested here — they are
+            // consumed at the end of the step — so that they are not live across the products
             u32x4 wv0 = {0u, 0u, 0u, 0u}, wv1 = {0u, 0u, 0u, 0u};
             if (wr_live) {
                 wv0 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u, 0);
@@ -373,8 +413,12 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hl.y), r_q, vo_q + (unsigned)T * (H * 4), (unsigned)k * (H * 4), 0);
                 }
             }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(hl.y));
+                st[6] = phase_stamp();
+            }
             __syncthreads();   // hsl is complete; every wave has read its picks' rows out of win[]
-            // ---- partial attention dots of the step-k window against the own h_k slice
+            // ---- (5) partial attention dots of the step-k window against the own h_k slice
             {
                 float p = 0.0f;
                 if (pdot) {
@@ -395,6 +439,20 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             if (wr_live) {
                 *reinterpret_cast<u32x4*>(&win[wr_row][wr_cand][0]) = wv0;
                 *reinterpret_cast<u32x4*>(&win[wr_row][wr_cand][4]) = wv1;
+            }
+            if constexpr (DIAG) {
+                st[7] = phase_stamp();
+                if (blockIdx.x == 0 && tid == 0 && k > 0) {   // sums live in the status area (u64 words 4..)
+                    u64* prof = reinterpret_cast<u64*>(err) + 4;
+                    prof[0] += st[1] - st[0];   // sweep of h: wait for the tags
+                    prof[1] += st[2] - st[1];   // LDS fill of h + barrier
+                    prof[2] += st[3] - st[2];   // window loads issued + W_hh.h products
+                    prof[3] += st[4] - st[3];   // sweep of the partial dots: wait
+                    prof[4] += st[5] - st[4];   // logits, argmax, barrier, pick's row
+                    prof[5] += st[6] - st[5];   // input side, cell, publish h
+                    prof[6] += st[7] - st[6];   // barrier, partial dots + publish, window rows to LDS
+                    prof[7] += 1;
+                }
             }
             ++step;
         }
@@ -471,12 +529,16 @@ int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, 
     static unsigned* p_diag = gnnpn_decode_diag_buffer();   // failure record (written on a timed-out sweep only)
     const int wt = opts.write_through ? 1 : 0;
     const int lds_kb = opts.lds_kb;
-#define GNNPN_LEAN(SPLIT_, OCC_, EVH_)                                                                                       \
-    hipLaunchKernelGGL((pointer_decode_lean_kernel<SPLIT_, OCC_, EVH_>), dim3(COOP_OVERSUB * groups * G), dim3(256),         \
-                       coop_lds_padding((const void*)pointer_decode_lean_kernel<SPLIT_, OCC_, EVH_>, lds_kb), s, args, p_h, p_p, \
+#define GNNPN_LEAN(SPLIT_, OCC_, EVH_, ...)                                                                                  \
+    hipLaunchKernelGGL((pointer_decode_lean_kernel<SPLIT_, OCC_, EVH_, ##__VA_ARGS__>), dim3(COOP_OVERSUB * groups * G), dim3(256), \
+                       coop_lds_padding((const void*)pointer_decode_lean_kernel<SPLIT_, OCC_, EVH_, ##__VA_ARGS__>, lds_kb), s, args, p_h, p_p, \
                        p_l, p_err, opts.sticky, n_nets, groups_per_net, gpx, wt, p_seats, p_diag)
     const bool wide = args.K > 8;
-    if (split && shared_cu && wide) GNNPN_LEAN(true, 2, 1);
+    if (gnnpn_option_lstm_ablate() & 0x800) {       // phase stamps (1-per-CU builds, n_per <= 8): a decoder-only bit
+        if (wide) GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the stamped build exists for n_per <= 8");
+        if (split) GNNPN_LEAN(true, 1, 2, true);
+        else GNNPN_LEAN(false, 1, 2, true);
+    } else if (split && shared_cu && wide) GNNPN_LEAN(true, 2, 1);
     else if (split && shared_cu) GNNPN_LEAN(true, 2, 2);
     else if (split && wide) GNNPN_LEAN(true, 1, 1);
     else if (split) GNNPN_LEAN(true, 1, 2);

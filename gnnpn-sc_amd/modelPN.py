@@ -177,15 +177,16 @@ class PointerNet(nn.Module):
         return self._packed
 
     def check_precision(self, precision):
-        """fp16-operand modes hold W_hh as fp16 (pairs): refuse weights outside fp16's finite range."""
-        if precision != "f32":
+        """"f16" holds W_hh as plain fp16: refuse weights outside fp16's finite range.  The exact split ("split") scales every
+        gate column by its own power of two (csrc/coop_common.h) and takes any finite weight, as fp32 does."""
+        if precision == "f16":
             w = self.packed()
-            if w["whh_absmax"] is None:          # largest |W_hh|: the fp16-operand precisions need it inside fp16's range
+            if w["whh_absmax"] is None:          # largest |W_hh|
                 w["whh_absmax"] = float(max(self.encoder.weight_hh_l0.detach().abs().max(),
                                             self.decoder.weight_hh_l0.detach().abs().max()))
             m = w["whh_absmax"]
             if not m < 6.0e4:
-                raise ops.GnnpnError(f"precision={precision!r}: max |W_hh| = {m:g} does not fit fp16 operands; use 'f32'")
+                raise ops.GnnpnError(f"precision={precision!r}: max |W_hh| = {m:g} does not fit fp16 operands; use 'f32' or 'split'")
 
     def encode_args(self, inputs, fold=None):
         """One entry of the ``nets`` list of ops.lstm_encode (+ the embedded tensor when the literal
@@ -341,8 +342,9 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
     action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
     win_high_raw + win_low (modelPN.py:216).
-    precision: "f32" (default) | "split" (fp16 hi+lo operands in both W_hh.h products, fp32 accumulate: measured as
-    accurate as the fp32 chain) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
+    precision: "f32" (default here) | "split" (both W_hh.h products from fp32 operands split EXACTLY into three fp16 pieces,
+    six products per term on the fp16 matrix cores, fp32 accumulate: no operand bit dropped, error bound below the fp32
+    chain's) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
     sample_high_seed: the High level DRAWS its picks from that stream instead of taking the argmax — the forward of the
     PNHigh training step (trainPNHigh.py:83-84: Low greedy -> latent, High sample='sample'); the Low level stays greedy.
     decode_impl / lds_kb / write_through / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,

@@ -402,7 +402,7 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
     sample_seed (the pick of every step is drawn from the window softmax: gnnpn_decode_net_t.sample).
     Returns one dict per net: idx [B,T] i32, win_logits [B,T,K], pick_prob [B,T], actions [B,T,8],
     queries [B,T,H] | None.
-    precision="split": the W_hh.h product with fp16 hi+lo operands (cooperative, folded form only); "f16" is an
+    precision="split": the W_hh.h product from exact three-piece fp16 operands (cooperative, folded form only); "f16" is an
     encoder-only mode and leaves the decoder in fp32.
     impl: 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 (16-CU groups), 4 (8-CU groups, 256-register build for two
     workgroups per CU); lds_kb / write_through / ws as for lstm_encode."""

@@ -188,8 +188,16 @@ class PipelinedRunner:
         # Placement: the cooperative kernels claim one CU per workgroup at run time (csrc/coop_common.h, coop_place), so
         # the two slots' launches share every CU one workgroup each whatever the dispatcher does; the LDS-footprint
         # padding round 1 steered the dispatcher with (100 / 56 KB) is no longer needed and stays as an option only.
+        # Exact-split precision: the recurrent kernels hold the third weight piece in LDS (60 KB encoder, 69 KB decoder).  Two
+        # such workgroups fit a CU's 160 KB, but LDS is allocated in CONTIGUOUS ranges: with unequal footprints a freed 60 KB
+        # hole does not take the next 69 KB workgroup while the neighbour's range sits in the middle, the launch stays
+        # under-staffed, and two launches can starve each other until the bounded spins give up (seen: bench.py, precision
+        # split, two slots: members missing at the first sweep, 20 of 32 seats of an XCD staffed after 0.3 s).  Every
+        # cooperative launch of a multi-slot runner is therefore padded to ONE footprint, 78 KB: any freed range fits any
+        # waiting workgroup.  (f32: 19 / 27 KB — nothing to equalise.)
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
-        self.lds_kb = [int(v) for v in env.split(",")] if env else [0] * self.n_slots
+        equal = 78 if (getattr(pipe, "precision", "f32") == "split" and self.n_slots > 1) else 0
+        self.lds_kb = [int(v) for v in env.split(",")] if env else [equal] * self.n_slots
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(self.n_slots)]
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],

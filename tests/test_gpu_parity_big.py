@@ -40,14 +40,15 @@ def _slice(fx, lo, hi):
 
 def _graph_pair(low, high, xs, precision):
     """What bench.py times: the two-level decode of TWO batches as two captured HIP graphs replayed concurrently on two
-    streams — decoder build 4 (two workgroups per CU), LDS footprints 100 / 56 KB, private workspaces."""
+    streams — decoder build 4 (two workgroups per CU), private workspaces, the LDS footprints PipelinedRunner gives its
+    slots (none in f32; one equal footprint of 78 KB in the exact-split precision, pipeline.py)."""
     from gnnpn_sc_amd import ops
     from gnnpn_sc_amd.modelPN import two_level_greedy
     dev = xs[0].device
     streams, graphs, outs, wss = [], [], [], []
     for s, x in enumerate(xs):
         ws = ops.new_workspaces(dev)
-        kw = dict(precision=precision, decode_impl=4, lds_kb=(100, 56)[s], ws=ws)
+        kw = dict(precision=precision, decode_impl=4, lds_kb=78 if precision == "split" else 0, ws=ws)
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):

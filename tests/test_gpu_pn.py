@@ -25,7 +25,7 @@ def build(fx_or_cfg, dev):
 @pytest.mark.parametrize("name,precision", [("small", "f32"), ("dummy", "f32"), ("qws", "f32"), ("normal", "f32"),
                                             ("qws", "split"), ("normal", "split")])
 def test_two_level_greedy_golden(dev, name, precision):
-    """precision="split" (fp16 hi+lo operands in the encoder's recurrent product, fp32 accumulate) is held to
+    """precision="split" (the recurrent products from exact three-piece fp16 operands, fp32 accumulate) is held to
     exactly the same bar against the reference's golden vectors as the fp32 path."""
     from gnnpn_sc_amd.modelPN import two_level_greedy
     fx = golden(f"pn_{name}.npz")
@@ -397,19 +397,25 @@ def test_split_precision_needs_the_cooperative_form(dev):
     ops.check_status(dev)
 
 
-def test_split_precision_refuses_weights_outside_fp16_range(dev):
+def test_weights_outside_fp16_range(dev):
+    """A recurrent weight beyond fp16's largest finite number: the plain-fp16 encoder ("f16") refuses it; the exact split
+    scales every gate column by its own power of two and takes it, as fp32 does — same picks, logits within 1e-5."""
     from gnnpn_sc_amd import ops
     from gnnpn_sc_amd.modelPN import two_level_greedy
     cfg = {"hidden": 256, "n_cat": 3, "n_per": 2, "seed_low": 1, "seed_high": 2}
     low, high = build(cfg, dev)
     with torch.no_grad():
         high.actor.decoder.weight_hh_l0[5, 7] = 7.0e4
+        low.actor.encoder.weight_hh_l0[300, 9] = -1.0e5
+        low.actor.encoder.weight_hh_l0[301, :] *= 1e-9               # and a column 2^-30 below the others
     x = torch.rand(4, 6, 8).to(dev)
-    for precision in ("split", "f16"):
-        with pytest.raises(ops.GnnpnError):
-            two_level_greedy(low, high, x, precision=precision)
-    two_level_greedy(low, high, x)      # plain fp32 takes any finite weight
+    with pytest.raises(ops.GnnpnError):
+        two_level_greedy(low, high, x, precision="f16")
+    a = two_level_greedy(low, high, x)      # plain fp32 takes any finite weight
+    b = two_level_greedy(low, high, x, precision="split")
     ops.check_status(dev)
+    assert torch.equal(a["idx_low"], b["idx_low"]) and torch.equal(a["idx_high"], b["idx_high"])
+    assert float((a["win_low"] - b["win_low"]).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("name", ["small", "qws"])

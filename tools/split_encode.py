@@ -6,8 +6,8 @@ from gnnpn_sc_amd import ops
 from gnnpn_sc_amd.modelPN import two_level_greedy
 from bench import build_models
 dev = torch.device("cuda:0")
-T, K, B = 47, 5, 256
-net, low, high = build_models(T, 2507, K, dev)
+T, K, B = int(os.environ.get("SE_T", 47)), int(os.environ.get("SE_K", 5)), int(os.environ.get("SE_B", 256))   # SE_T=1000 SE_B=32: L = 5000
+net, low, high = build_models(T, 2507 if T == 47 else 5 * T, K, dev)
 scale = float(os.environ.get("WHH_SCALE", "1"))          # stress: larger recurrent weights (saturating gates)
 if scale != 1:
     with torch.no_grad():
@@ -23,7 +23,7 @@ xd = x.to(dev)
 
 # fp64 reference of the Low encoder on the first 32 problems
 sd = {k: v.detach().cpu().double() for k, v in low.state_dict().items()}
-nb = 32
+nb = min(32, B)
 emb = x[:nb].double() @ sd["actor.embedding2.weight"].T + sd["actor.embedding2.bias"]
 lstm = torch.nn.LSTM(256, 256, batch_first=True).double()
 lstm.load_state_dict({k.replace("actor.encoder.", ""): v for k, v in sd.items() if k.startswith("actor.encoder.")})
@@ -48,7 +48,7 @@ for name in ("f32", "split", "f16"):
     for _ in range(10): enc, h_n, c_n = ops.lstm_encode([el, eh], precision=name)
     e1.record(); torch.cuda.synchronize()
     err = (enc[0][:nb].double().cpu() - ref).abs()
-    print(f"{name:6s} encoder {e0.elapsed_time(e1) / 10:.3f} ms   two-level pass {res[name][1]:.3f} ms   "
+    print(f"L={T * K} {name:6s} encoder {e0.elapsed_time(e1) / 10:.3f} ms   two-level pass {res[name][1]:.3f} ms   "
           f"enc_out vs fp64: max {err.max():.3e} mean {err.mean():.3e}  (last step max {err[:, -1].max():.3e})")
 ops.check_status(dev)
 a = res["f32"][0]

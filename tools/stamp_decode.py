@@ -10,11 +10,18 @@ net, low, high = build_models(T, 2507, K, dev)
 g = torch.Generator().manual_seed(0)
 x = torch.rand(B, T * K, 8, generator=g).to(dev)
 for _ in range(3): two_level_greedy(low, high, x)
-ops.set_option("lstm_ablate", 32)
+ops.set_option("lstm_ablate", 0x800)
 two_level_greedy(low, high, x); torch.cuda.synchronize()
 ws = ops.workspaces(dev).decode(B, T, K)
 prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
 n = max(prof[7], 1)
-names = ["sweep+fill", "logits/argmax (3 barriers)", "W_hh.h MFMA", "x embed->LDS", "W_ih.x MFMA", "cell+publish h", "partial dots"]
-print({k: round(v / n) for k, v in zip(names, prof[:7])}, "steps", n, "total", round(sum(prof[:7]) / n))
+names = ["sweep wait", "LDS fill + logits + argmax", "barrier + pick row", "window loads + W_hh.h", "input side + cell + publish h", "barrier",
+         "partial dots + publish"]
+print("f32  ", {k: round(v / n) for k, v in zip(names, prof[:7])}, "steps", n, "total", round(sum(prof[:7]) / n))
+for _ in range(2): two_level_greedy(low, high, x, precision="split")
+torch.cuda.synchronize()
+ws = ops.workspaces(dev).decode(B, T, K)
+prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
+n = max(prof[7], 1)
+print("split", {k: round(v / n) for k, v in zip(names, prof[:7])}, "steps", n, "total", round(sum(prof[:7]) / n))
 ops.set_option("lstm_ablate", 0)
