@@ -364,7 +364,7 @@ int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision,
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_e = reinterpret_cast<unsigned*>(base);
-    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);
     unsigned* p_s = opts.sticky;
     if (precision == GNNPN_PREC_SPLIT) return GNNPN_E_UNSUP;   // the exact-split product lives in the 8-member builds (decode_coop.hip); callers fall back to them
     const int lds_kb = opts.lds_kb;

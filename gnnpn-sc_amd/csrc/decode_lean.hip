@@ -202,7 +202,17 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             const unsigned tag = step;                           // publish #(step-1) carries tag `step`
             const unsigned par = (step - 1) & 1;
             const unsigned so_k = (unsigned)k * (unsigned)K;
-            float4 ev[EVN];
+            // Destinations of the loads requested half-way through the products.  They are "defined" without an instruction and
+            // not touched until their real use: a register copy or an initialising move next to the loads makes the compiler
+            // wait for them on the spot (vmcnt), in the middle of the chain.  Lanes that do not load never look at them.
+            u32x4 ev[EVN];                                       // raw bits of the window's enc_out slice
+            u32x4 vp[4];                                         // the lane's 8 partials {value, tag} x 2
+            u32x2 vl;                                            // Low's window logit {value, tag}
+#pragma unroll
+            for (int j = 0; j < EVN; ++j) asm volatile("" : "=v"(ev[j]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(vp[j]));
+            asm volatile("" : "=v"(vl));
             f32x4 ah[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
             // ---- (1) h_{k-1}: peers published it BEFORE their partial dots, so it is (nearly) there when this member has
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                         unsigned so_h = so_h0;
                         asm volatile("" : "+s"(so_h));
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) vh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, vo_sweep + 1024 * j, so_h, AUX_SC1);
+                        for (int j = 0; j < 8; ++j) vh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, vo_sweep, so_h + 1024u * j, AUX_SC1);   // the constant part rides the SCALAR offset: no per-load address register
                         bool good = true;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -262,17 +272,29 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                     if (abort_flag) break;
                 }
                 if constexpr (DIAG) st[2] = phase_stamp();
-                // this step's window: enc_out rows against the own 32-unit slice (consumed after the cell update)
-                if (pdot) {
+                // ---- (2) W_hh.h (the folded input side follows the pick, below).  Half-way through, the first pass over the
+                // partial dots of publish #(step-1) is requested: they were published a hand-off time ago, and the loads' own
+                // round trip (~700 cycles) then lies under the second half of the products instead of behind them.
+                // This step's window (enc_out rows against the own 32-unit slice, consumed after the cell update) is requested in
+                // (4), behind the barrier that follows the argmax: every __syncthreads waits for ALL outstanding vector-memory
+                // operations (s_waitcnt vmcnt(0) in front of s_barrier), and so does the guard the compiler puts in front of the
+                // chain's first LDS reads — an HBM load in flight across either is an HBM round trip per step on the critical
+                // path (seen in the ISA and the stamps: 5.4 k cycles for 4.1 k cycles of MFMAs with the loads in front of the
+                // chain, 0.9 k cycles of "argmax" with them in front of the barrier).  From (4) they have the cell update.
+                // (The 2-per-CU builds request them behind the products instead: 18 more live registers across the second half do
+                // not fit 256, and there the other resident workgroup covers the round trip.)
+                constexpr bool EARLY_P = OCC == 1;
+                auto request_p = [&]() {
+                    if (EARLY_P && k > 0 && live) {
+                        const unsigned so_p = par * (XP_GRANULES * 8) + wave * (4 * KW * G * 8);
 #pragma unroll
-                    for (int j = 0; j < EVN; ++j) {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev + 16 * j, so_k * (H * 4), 0);
-                        ev[j] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                        for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p, so_p + 16u * j, AUX_SC1);
+                        if (latent_in_launch)
+                            vl = __builtin_amdgcn_raw_buffer_load_b64(r_lat, vo_lat, (unsigned)(((k - 1) * ROWS + wave * 4) * K) * 8u, AUX_SC1);
                     }
-                }
-                // ---- (2) W_hh.h (the folded input side follows the pick, below)
-                if constexpr (SPLIT) split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, wt_lane, winv, ah);
-                else mfma_chain_pair<LDT, OCC == 2 ? 8 : 16, true>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah[0], ah[1]);
+                };
+                if constexpr (SPLIT) split_chain(reinterpret_cast<const _Float16*>(hs) + c * LDH16 + 8 * kq, wH16, wL16, wt_lane, winv, ah, request_p);
+                else mfma_chain_pair<LDT, OCC == 2 ? 8 : 16, true>(hs, c, kq, wBh[0], wBh[SPLIT ? 0 : 1], ah[0], ah[1], request_p);
                 if constexpr (DIAG) {
                     asm volatile("" ::"v"(ah[0][0]), "v"(ah[1][0]));
                     st[3] = phase_stamp();
@@ -283,20 +305,24 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             if (k > 0) {
                 const unsigned so_p0 = par * (XP_GRANULES * 8) + wave * (4 * KW * G * 8);
                 const unsigned so_l0 = (unsigned)(((k - 1) * ROWS + wave * 4) * K) * 8u;
-                u32x4 vp[4];
-                u32x2 vl = {0u, 1u};
                 bool ok = false;
                 for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
-                    unsigned so_p = so_p0, so_l = so_l0;
-                    asm volatile("" : "+s"(so_p), "+s"(so_l));
+                    // pass 0 looks at what (2) requested half-way through the products (k == T: nothing was requested);
+                    // every further pass loads again
+                    if (spins > 0 || k == T || OCC != 1) {
+                        unsigned so_p = so_p0, so_l = so_l0;
+                        asm volatile("" : "+s"(so_p), "+s"(so_l));
+                        if (live) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p, so_p + 16u * j, AUX_SC1);
+                            if (latent_in_launch) vl = __builtin_amdgcn_raw_buffer_load_b64(r_lat, vo_lat, so_l, AUX_SC1);
+                        }
+                    }
                     bool good = true;
                     if (live) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p + 16 * j, so_p, AUX_SC1);
-                        if (latent_in_launch) vl = __builtin_amdgcn_raw_buffer_load_b64(r_lat, vo_lat, so_l, AUX_SC1);
-#pragma unroll
                         for (int j = 0; j < 4; ++j) good &= (vp[j].y == tag) & (vp[j].w == tag);
-                        good &= vl.y == 1u;
+                        if (latent_in_launch) good &= vl.y == 1u;
                     }
                     if (__all(good)) {
                         ok = true;
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                         if (__ballot(live && vp[j].y != tag)) p_miss |= 1u << (2 * j);
                         if (__ballot(live && vp[j].w != tag)) p_miss |= 1u << (2 * j + 1);
                     }
-                    record_failure(diag, err, group, member, tile, k, wave, tag, 0u, p_miss, (unsigned)__popcll(__ballot(live && vl.y != 1u)), gpx);
+                    record_failure(diag, err, group, member, tile, k, wave, tag, 0u, p_miss, (unsigned)__popcll(__ballot(live && latent_in_launch && vl.y != 1u)), gpx);
                 }
 
                 // ---- logits and first-max argmax: lane (rq, r) = (row 4 wave + rq, candidate r)
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                 axf1 = win[c][sel[c]][4 + kq];
                 if (first && wave == 0) {                        // ... the same registers ARE the action row
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(axf0), r_act, vo_act, (unsigned)(k - 1) * 32u, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(axf1), r_act, vo_act + 16, (unsigned)(k - 1) * 32u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(axf1), r_act, vo_act, (unsigned)(k - 1) * 32u + 16u, 0);
                 }
                 if (k == T) break;
                 if constexpr (DIAG) st[5] = phase_stamp();
@@ -364,10 +390,15 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             // ---- (4) folded input side, cell update, publish h_k
             // the raw rows of this step's window (the next pick's decoder input comes out of them): requested here — they are
             // consumed at the end of the step — so that they are not live across the products
-            u32x4 wv0 = {0u, 0u, 0u, 0u}, wv1 = {0u, 0u, 0u, 0u};
+            if (pdot) {   // this step's window of enc_out (see the note at the products): it has the cell update to arrive
+#pragma unroll
+                for (int j = 0; j < EVN; ++j) ev[j] = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev, so_k * (H * 4) + 16u * j, 0);
+            }
+            u32x4 wv0, wv1;   // "defined" without an instruction: an initialising move behind the loads above makes the compiler wait
+            asm volatile("" : "=v"(wv0), "=v"(wv1));   // for them on the spot (it guards the register against the previous step's load)
             if (wr_live) {
                 wv0 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u, 0);
-                wv1 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win + 16, so_k * 32u, 0);
+                wv1 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u + 16u, 0);
             }
             float gx[2][4];
             if (k > 0) {
@@ -401,16 +432,16 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                 const unsigned so_pub = (step & 1) * (ROWS * H * 8);
                 if constexpr (SPLIT) {
                     store_granule(r_h, vo_hpub, so_pub, split_granule(step + 1, hl.x), same_xcd);
-                    store_granule(r_h, vo_hpub + H * 8, so_pub, split_granule(step + 1, hl.y), same_xcd);
+                    store_granule(r_h, vo_hpub, so_pub + H * 8, split_granule(step + 1, hl.y), same_xcd);
                 } else {
                     store_granule(r_h, vo_hpub, so_pub, ((u64)(step + 1) << 32) | __float_as_uint(hl.x), same_xcd);
-                    store_granule(r_h, vo_hpub + H * 8, so_pub, ((u64)(step + 1) << 32) | __float_as_uint(hl.y), same_xcd);
+                    store_granule(r_h, vo_hpub, so_pub + H * 8, ((u64)(step + 1) << 32) | __float_as_uint(hl.y), same_xcd);
                 }
                 hsl[own0][wave * 8 + (c & 7)] = hl.x;
                 hsl[own0 + 1][wave * 8 + (c & 7)] = hl.y;
                 if (net.queries) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hl.x), r_q, vo_q, (unsigned)k * (H * 4), 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hl.y), r_q, vo_q + (unsigned)T * (H * 4), (unsigned)k * (H * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hl.y), r_q, vo_q, (unsigned)(k + T) * (H * 4), 0);
                 }
             }
             if constexpr (DIAG) {
@@ -425,10 +456,10 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
 #pragma unroll
                     for (int j = 0; j < EVN; ++j) {
                         const float4 hv = *reinterpret_cast<const float4*>(&hsl[prow][phalf * (4 * EVN) + 4 * j]);
-                        p = fmaf(ev[j].x, hv.x, p);
-                        p = fmaf(ev[j].y, hv.y, p);
-                        p = fmaf(ev[j].z, hv.z, p);
-                        p = fmaf(ev[j].w, hv.w, p);
+                        p = fmaf(__uint_as_float(ev[j].x), hv.x, p);
+                        p = fmaf(__uint_as_float(ev[j].y), hv.y, p);
+                        p = fmaf(__uint_as_float(ev[j].z), hv.z, p);
+                        p = fmaf(__uint_as_float(ev[j].w), hv.w, p);
                     }
                 }
                 if constexpr (EVH == 2)   // lanes 2p, 2p+1 hold the two halves of the slice: low half + high half

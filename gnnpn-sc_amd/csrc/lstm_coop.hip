@@ -537,7 +537,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: cannot query the device");
     const int n_tiles = (B + ROWS - 1) / ROWS;
     if (opts.impl == 3) {   // 16-member groups (one workgroup per CU from this launch; three such launches fit a CU)
-        if (precision != 0 || (gnnpn_option_lstm_ablate() & ~128) != 0)
+        if (precision != 0 || (gnnpn_option_lstm_ablate() & ~(128 | 64 | 0x800)) != 0)
             GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the 16-member form is built for fp32 operands, no diagnostics");
         for (int n = 0; n < n_nets; ++n)
             if (nets.pregates[n] != nullptr) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the 16-member form is built for the folded input side");
@@ -585,16 +585,18 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
-    const int abl = gnnpn_option_lstm_ablate() | (opts.write_through ? 128 : 0);
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(COOP_OVERSUB * groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
                        p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl, p_seats)
-    if ((abl & ~128) != 0) {   // diagnostic build (fp32, folded form only)
-        if (prec != 0 || pre) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the fp32 folded form");
-        GNNPN_ENC(0, false, true);
+    if ((abl & ~128) != 0) {   // diagnostic build (folded form; fp32 with every switch, exact split with the phase stamps)
+        if (prec == 1 || pre || (prec == 2 && (abl & ~(128 | 32)) != 0))
+            GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the folded form (fp32: all switches; split: stamps only)");
+        if (prec == 2) GNNPN_ENC(2, false, true);
+        else GNNPN_ENC(0, false, true);
     } else if (prec == 2 && pre) GNNPN_ENC(2, true, false);
     else if (prec == 2) GNNPN_ENC(2, false, false);
     else if (prec == 1 && pre) GNNPN_ENC(1, true, false);

@@ -12,13 +12,12 @@ from .modelPN import two_level_greedy
 
 class SCDataset(torch.utils.data.Dataset):
     """trainPNHigh.py:15-41.  ``dataset`` = loadDataPN rows [P][L][9]; with embeddingTag=False column 0
-    (the category id) is dropped -> FloatTensor [L,8] per problem."""
+    (the category id) is dropped -> FloatTensor [L,8] per problem; with embeddingTag=True the rows stay [L,9] (:26-29) for
+    a CombinatorialRL built with embedding_size != 0."""
 
     def __init__(self, dataset, targets, embeddingTag=False):
         super().__init__()
-        if embeddingTag:
-            raise NotImplementedError("embeddingTag=1 is outside the ML+2PN inference configuration")
-        self.data_set = [torch.FloatTensor([row[1:] for row in rows]) for rows in dataset]
+        self.data_set = [torch.FloatTensor([row if embeddingTag else row[1:] for row in rows]) for rows in dataset]
         self.label = list(targets)
         self.serviceNumbers = [0] * len(self.data_set)
         self.size = len(self.data_set)

@@ -81,9 +81,6 @@ class Net(nn.Module):
     def __init__(self, hiddenChannels, outChannels, embeddingChannels, numLayersGIN, numLayersGCN,
                  isServices=True, dropout=0.0, vocab=100):
         super().__init__()
-        if not isServices:
-            raise NotImplementedError("isServices=False (noServicesLins branch, modelML.py:157-162) is not on the "
-                                      "ML+2PN path (trainML.py:125-126 always passes True)")
         self.numLayersGIN, self.numLayersGCN = numLayersGIN, numLayersGCN
         self.dropout, self.outChannels = dropout, outChannels
         self.reqAndServiceChannels = embeddingChannels
@@ -104,7 +101,7 @@ class Net(nn.Module):
             self.serviceConvs.append(GCNConv(c + self.qosNumber if i == 0 else 2 * h, 2 * h))
             self.serviceBatchNorms.append(nn.BatchNorm1d(2 * h))
         self.serviceLin = nn.Linear(2 * h, h)                                      # :106
-        self.noServicesLins = nn.ModuleList(                                       # :108-115 (state_dict parity)
+        self.noServicesLins = nn.ModuleList(                                       # :108-115 (isServices=False branch)
             nn.Linear(c + self.qosNumber if i == 0 else 2 * h, 2 * h) for i in range(numLayersGCN))
         self._prep = None
         self.fuse_request_branch = os.environ.get("GNNPN_LAYERED_GIN") != "1"   # one-launch GIN branch for small workflow graphs
@@ -156,6 +153,8 @@ class Net(nn.Module):
             a, b = _bn_affine(bn)
             p["gcn"].append({"wt": f(conv.weight.detach().t()), "bias": f(conv.bias), "a": a.to(device),
                              "s": b.to(device)})
+        p["nolin"] = [{"w": f(lin.weight), "bias": f(lin.bias), "a": g["a"], "s": g["s"]}
+                      for lin, g in zip(self.noServicesLins, p["gcn"])]
         p["nodeLin"] = (f(self.nodeLin.weight), f(self.nodeLin.bias))
         if self.nodeLin.weight.shape[0] % 16 == 0:
             p["nodeLin_p"] = ops.pack_mfma_b(p["nodeLin"][0])
@@ -195,6 +194,10 @@ class Net(nn.Module):
         edge weights -> [S, hidden]."""
         p = self.prepared(x_service.device)
         xs = torch.ops.gnnpn.embed_concat(x_service, p["service_table"])                                    # :146-149
+        if not self.isService:                                                                  # :157-162 graph-free ablation
+            for lp in p["nolin"]:
+                xs = torch.ops.gnnpn.linear(xs, lp["w"], lp["bias"], lp["a"], lp["s"], ACT_RELU)
+            return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                             # :164
         norm = torch.ops.gnnpn.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
         for lp in p["gcn"]:                                                                     # :152-155
             xw = torch.ops.gnnpn.linear(xs, lp["wt"])                                                       # transform first

@@ -108,9 +108,6 @@ class PointerNet(nn.Module):
     def __init__(self, embedding_size, hidden_size, seq_len, n_glimpses, tanh_exploration, use_tanh, attention,
                  sNumber, sCategory, use_cuda=True, level="low", mask=False):
         super().__init__()
-        if embedding_size != 0:
-            raise NotImplementedError("embedding_size != 0 (embeddingTag=1) is outside the ML+2PN inference "
-                                      "configuration (environment.ini:50,66)")
         if n_glimpses < 0:
             raise ValueError("n_glimpses >= 0")
         self.embedding_size, self.hidden_size, self.n_glimpses = embedding_size, hidden_size, n_glimpses
@@ -120,6 +117,8 @@ class PointerNet(nn.Module):
         self.seq_len, self.use_cuda, self.level = seq_len, use_cuda, level
         self.serNumber, self.serCategory = sNumber, sCategory
         self.C, self.use_tanh, self.mask = float(tanh_exploration), bool(use_tanh), mask
+        if embedding_size != 0:                                                        # :153-154 (embeddingTag=1: rows [cat | 8 floats])
+            self.embedding1 = nn.Embedding(sCategory, embedding_size)
         self.embedding2 = nn.Linear(embedding_size + qosandcons, hidden_size)          # :155
         self.encoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :157 (container)
         self.decoder = nn.LSTM(hidden_size, hidden_size, batch_first=True)             # :158 (container)
@@ -162,6 +161,9 @@ class PointerNet(nn.Module):
             # arithmetic every committed parity record was measured with); while a trainer steps the weights
             # (``fold_on_device``, set by trainPNHigh.ActorAdam) the same fp64 products run on the device instead of a
             # 1 MB round trip through the host per step.
+            if self.embedding_size != 0:     # the folded input side needs W_e [H, 8]: with the category embedding the literal order runs
+                self._packed["whh_absmax"] = None
+                return self._packed
             where = (lambda t: t.detach().double()) if self.fold_on_device else (lambda t: t.detach().double().cpu())
             dev = self.embedding2.weight.device
             back = lambda t: t.float().contiguous().to(dev)   # noqa: E731
@@ -195,6 +197,17 @@ class PointerNet(nn.Module):
         assert L == self.seq_len                                                        # :182
         w = self.packed()
         fold = FOLD_INPUT_PROJECTION if fold is None else fold
+        if self.embedding_size != 0:
+            # :183-190 — x1 = embedding1(inputs[:, :, 0]); embedded = embedding2(cat(x1, inputs[:, :, 1:])): the lookup + concat
+            # kernel of the GNN front end (gnnpn_embed_concat_f32), then the literal two-stage order (the folded [4H, 8] matrix
+            # has no place for a per-row table entry)
+            if F != 1 + qosandcons:
+                raise ops.GnnpnError(f"embedding_size != 0: rows [category | {qosandcons} floats] expected, got {F} columns")
+            flat = torch.ops.gnnpn.embed_concat(inputs.reshape(B * L, F), self.embedding1.weight.detach().float().contiguous())
+            embedded = torch.ops.gnnpn.linear(flat, w["emb_w"], w["emb_b"])
+            pregates = torch.ops.gnnpn.linear(embedded, w["enc_wih"], w["enc_bih"])
+            return {"pregates": pregates.view(B, L, 4 * self.hidden_size), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
+                embedded.view(B, L, self.hidden_size)
         if fold:
             return {"inputs": inputs, "w_in": w["enc_wfold"], "b_in": w["enc_bfold"], "whh": w["enc_whh"],
                     "bhh": w["enc_bhh"]}, None
@@ -225,6 +238,11 @@ class PointerNet(nn.Module):
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
         enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
+        if self.embedding_size != 0:          # the decode kernels gather 8-feature action rows: the category column rejoins below
+            if sample_seed is not None:
+                raise NotImplementedError("sampling with embedding_size != 0: the cooperative sampling build is the folded one")
+            rows9, inputs = inputs, inputs[:, :, 1:].contiguous()
+            fold = False
         if self.general:
             if sample_seed is not None:
                 raise NotImplementedError("sampling with 'Bahdanau' attention / glimpses: the general decode kernel is greedy")
@@ -234,12 +252,19 @@ class PointerNet(nn.Module):
                 inputs, self.serCategory, self.serNumber, self.attention, self.n_glimpses, self.pointer.side(),
                 self.glimpse.side(), self.C, self.use_tanh, want_queries)
             out["enc_out"] = enc[0]
-            return out
+            return self._with_category(out, rows9) if self.embedding_size != 0 else out
         out = custom_ops.pointer_decode(
             [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
                               _window_tensor(latent, self.serCategory, self.serNumber), fold=fold, sample_seed=sample_seed)],
             inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
         out["enc_out"] = enc[0]
+        return self._with_category(out, rows9) if self.embedding_size != 0 else out
+
+    @staticmethod
+    def _with_category(out, rows9):
+        """actions = inputs[b, idx, :] (modelPN.py:293-295) keeps the category column when the rows carry one."""
+        cat = torch.gather(rows9[:, :, 0], 1, out["idx"].long()).unsqueeze(-1)
+        out["actions"] = torch.cat([cat, out["actions"]], dim=2)
         return out
 
     def forward(self, inputs, latent, sample="sample"):
@@ -294,9 +319,10 @@ def reward(sample_solution, optSolutions, sCategory, USE_CUDA=False, level="Low"
            verbose=False):
     """reward (modelPN.py:35-72): list of T ``[B, 8]`` action tensors -> FloatTensor [B].
     The reference prints the whole list (:67); here only with ``verbose=True``."""
-    if embedding_size != 0:
-        raise NotImplementedError("embedding_size != 0 is outside the ML+2PN inference configuration")
-    actions = torch.stack(list(sample_solution), dim=1).contiguous()
+    actions = torch.stack(list(sample_solution), dim=1)
+    if actions.shape[-1] == 1 + qosandcons:          # embedding_size != 0: tag = 1 (modelPN.py:42-45), the category column in front
+        actions = actions[..., 1:]
+    actions = actions.contiguous()
     R = torch.ops.gnnpn.qos_reward(actions, 0 if level == "Low" else 1)
     if verbose:
         lst = R.tolist()
@@ -351,12 +377,13 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
-    if la.general or ha.general:   # 'Bahdanau' attention / glimpses: one net per call of the general kernel
+    if la.general or ha.general or la.embedding_size != 0 or ha.embedding_size != 0:
+        # 'Bahdanau' attention / glimpses / the category embedding (embeddingTag=1): one net per call
         if sample_high_seed is not None or precision != "f32":
-            raise NotImplementedError("the general attention forms decode greedily in fp32")
+            raise NotImplementedError("the general attention forms and the embedding form decode greedily in fp32")
         dl = la.run(inputs, None, fold=fold)
         dh = ha.run(inputs, LatentWindows(dl["win_logits"], dl["idx"], None, None, la.C, la.use_tanh), fold=fold)
-        R = torch.ops.gnnpn.qos_reward(dh["actions"], 0 if high.level == "Low" else 1)
+        R = torch.ops.gnnpn.qos_reward(dh["actions"][..., -qosandcons:].contiguous(), 0 if high.level == "Low" else 1)
         return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
                 "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}
     # the two decoders run in ONE launch with one (C, use_tanh, window shape): the reference applies each PointerNet's

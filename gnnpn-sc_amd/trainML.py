@@ -90,6 +90,9 @@ def _bn_fwd(x, bn, relu=True):
 
 def ml_forward_backward(net, b):
     """Forward in training mode, BCE loss, backward.  -> (loss [1] device tensor, scores [B,S], {parameter name: gradient})."""
+    if not net.isService:
+        raise NotImplementedError("ml_forward_backward: training of the isServices=False ablation (modelML.py:157-162) is not "
+                                  "built — trainML.py:125-126 always trains with the service graph; inference of it is")
     c = net.reqAndServiceChannels
     g = {}
     # ---------------- forward: workflow branch (modelML.py:133-143,165-166)

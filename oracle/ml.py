@@ -76,7 +76,7 @@ def make_state_dict(hidden=128, emb=20, n_gin=2, n_gcn=2, seed=0, vocab=100, ran
         sd[f"serviceConvs.{i}.weight"] = u((in_f, 2 * hidden), bound)    # stored in x out (PyG 1.7)
         sd[f"serviceConvs.{i}.bias"] = u((2 * hidden,), 0.1)
         bn(f"serviceBatchNorms.{i}", 2 * hidden, sd)
-        lin(f"noServicesLins.{i}", 2 * hidden, in_f, sd)                 # :108-115 (unused, isServices=True)
+        lin(f"noServicesLins.{i}", 2 * hidden, in_f, sd)                 # :108-115 (the isServices=False branch)
     lin("serviceLin", hidden, 2 * hidden, sd)                            # :106
     return sd
 
@@ -141,13 +141,17 @@ def gcn_conv(x, edge_index, edge_weight, weight, bias):
 
 
 @torch.no_grad()
-def service_embedding(sd, x_service, edge_index_service, edge_attr_service, n_gcn):
-    """The service branch of Net.forward (modelML.py:145-156,164): [S,5] -> [S,hidden]."""
+def service_embedding(sd, x_service, edge_index_service, edge_attr_service, n_gcn, is_services=True):
+    """The service branch of Net.forward (modelML.py:145-164): [S,5] -> [S,hidden].  ``is_services`` False is the
+    graph-free ablation (:157-162): a Linear per layer in place of the GCNConv, same batch norms."""
     ids = x_service[:, 0].long()
     xs = torch.cat([sd["serviceEncoder.embeddings.0.weight"][ids], x_service[:, 1:]], -1)  # :146-149
-    for i in range(n_gcn):                                                                  # :152-155
-        xs = gcn_conv(xs, edge_index_service, edge_attr_service,
-                      sd[f"serviceConvs.{i}.weight"], sd[f"serviceConvs.{i}.bias"])
+    for i in range(n_gcn):
+        if is_services:                                                                     # :152-155
+            xs = gcn_conv(xs, edge_index_service, edge_attr_service,
+                          sd[f"serviceConvs.{i}.weight"], sd[f"serviceConvs.{i}.bias"])
+        else:                                                                               # :158-159
+            xs = F.linear(xs, sd[f"noServicesLins.{i}.weight"], sd[f"noServicesLins.{i}.bias"])
         xs = F.relu(_bn(xs, sd, f"serviceBatchNorms.{i}"))
     return F.linear(xs, sd["serviceLin.weight"], sd["serviceLin.bias"])                     # :164
 
@@ -165,11 +169,11 @@ def request_embedding(sd, x, edge_index, batch, n_graphs, n_gin):
 
 
 @torch.no_grad()
-def net_forward(sd, data, n_gin, n_gcn):
+def net_forward(sd, data, n_gin, n_gcn, is_services=True):
     """Net.forward (modelML.py:131-176) -> sigmoid scores [B,S]."""
     n_graphs = int(data.batch.max()) + 1
     xr = request_embedding(sd, data.x, data.edge_index, data.batch, n_graphs, n_gin)
-    xs = service_embedding(sd, data.x_service, data.edge_index_service, data.edge_attr_service, n_gcn)
+    xs = service_embedding(sd, data.x_service, data.edge_index_service, data.edge_attr_service, n_gcn, is_services)
     return torch.sigmoid(torch.matmul(xr, xs.t()))                                          # :173-176
 
 

@@ -23,7 +23,7 @@ CONS_NUM = 2   # modelPN.py:12
 NEG_INF = float("-inf")
 
 
-def make_state_dict(hidden, seed, in_features=8, attention="Dot"):
+def make_state_dict(hidden, seed, in_features=8, attention="Dot", embedding_size=0, n_cat=0):
     """Deterministic weights in the reference's state_dict layout (PyTorch default-init
     ranges: U(-1/sqrt(H), 1/sqrt(H)) for LSTM and decoder_start_input, modelPN.py:163;
     U(-1/sqrt(in), 1/sqrt(in)) for the Linear).  Build-owned generator so that fixtures
@@ -34,6 +34,7 @@ def make_state_dict(hidden, seed, in_features=8, attention="Dot"):
         return (torch.rand(shape, generator=g) * 2 - 1) * bound
 
     kh = 1.0 / math.sqrt(hidden)
+    in_features = in_features + embedding_size          # embedding2 = Linear(embedding_size + 8, H) (modelPN.py:155)
     ke = 1.0 / math.sqrt(in_features)
     sd = {
         "actor.decoder_start_input": u((hidden,), kh),
@@ -45,6 +46,8 @@ def make_state_dict(hidden, seed, in_features=8, attention="Dot"):
         sd[f"actor.{name}.weight_hh_l0"] = u((4 * hidden, hidden), kh)
         sd[f"actor.{name}.bias_ih_l0"] = u((4 * hidden,), kh)
         sd[f"actor.{name}.bias_hh_l0"] = u((4 * hidden,), kh)
+    if embedding_size:                     # embedding1 = nn.Embedding(sCategory, embedding_size) (modelPN.py:153-154); drawn after the rest
+        sd["actor.embedding1.weight"] = torch.randn((n_cat, embedding_size), generator=g)
     if attention == "Bahdanau":            # Attention.__init__ (modelPN.py:82-90); drawn after everything else
         for name in ("pointer", "glimpse"):
             sd[f"actor.{name}.W_query.weight"] = u((hidden, hidden), kh)
@@ -157,7 +160,12 @@ def pointer_forward(sd, inputs, n_cat, n_per, latent=None, C=10.0, use_tanh=True
     enc = _lstm_module(sd, "encoder", hidden)
     dec = _lstm_module(sd, "decoder", hidden)
 
-    embedded = F.linear(inputs, sd["actor.embedding2.weight"], sd["actor.embedding2.bias"])  # :190
+    if "actor.embedding1.weight" in sd:                                                      # :183-188 (embedding_size != 0)
+        x1 = F.embedding(inputs[:, :, 0].long(), sd["actor.embedding1.weight"])
+        embedded = torch.cat((x1, inputs[:, :, 1:]), 2)
+    else:
+        embedded = inputs.clone()
+    embedded = F.linear(embedded, sd["actor.embedding2.weight"], sd["actor.embedding2.bias"])  # :190
     enc_out, (h, c) = enc(embedded)                                                        # :191
 
     chosen = torch.zeros(B, L, dtype=torch.bool)                                           # :196
@@ -238,7 +246,7 @@ def combinatorial_forward(sd, inputs, n_cat, n_per, latent=None, level="Low", tr
     actions = [inputs[rows, i, :] for i in idxs]                                            # :293-295
     action_probs = [p[rows, i] for p, i in zip(probs, idxs)]                                # :297-299
     if training == "RL":
-        R = reward(actions, level=level)                                                    # :301-304
+        R = reward(actions, level=level, tag=1 if "actor.embedding1.weight" in sd else 0)   # :301-304, tag: :42-45
         return R, action_probs, actions, idxs, logits
     return probs, action_probs, actions, idxs, logits
 

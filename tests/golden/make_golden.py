@@ -138,6 +138,42 @@ def gen_pn_attn(modelPN, name, H, T, K, B, seed, attention, n_glimpses):
           f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
 
 
+def gen_pn_embed(modelPN, name, H, T, K, B, seed, E):
+    """embedding_size != 0 (embeddingTag=1; modelPN.py:153-154, 183-188, reward's tag :42-45): rows [category | 8 floats], the
+    category embedded and concatenated in front of embedding2 — run through the REAL modules, Low ("SL") -> latent -> High."""
+    sd_low = opn.make_state_dict(H, seed, embedding_size=E, n_cat=T)
+    sd_high = opn.make_state_dict(H, seed + 1, embedding_size=E, n_cat=T)
+    L = T * K
+
+    def build(level, sd):
+        m = modelPN.CombinatorialRL(E, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+
+    low, high = build("Low", sd_low), build("High", sd_high)
+    x8 = pn_inputs(B, T, K, seed + 2, 0)
+    cat = torch.arange(T).repeat_interleave(K).float().view(1, L, 1).expand(B, L, 1)     # loadData.py:130-148: column 0 = the category
+    x = torch.cat([cat, x8], 2).contiguous()
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        _, _, _, idx_low, latent = low(x, None, sample="greedy", training="SL")
+        R, probs, actions, idx_high, logits_high = high(x, None, latent, sample="greedy")
+    ref = {
+        "idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
+        "actions": torch.stack(actions, 1), "action_probs": torch.stack(probs, 1),
+        "win_low": torch.stack([latent[k][:, k * K:(k + 1) * K] for k in range(T)], 1),
+        "win_high": torch.stack([(logits_high[k] + latent[k])[:, k * K:(k + 1) * K] for k in range(T)], 1),
+    }
+    orc = opn.two_level_greedy(sd_low, sd_high, x, T, K)
+    for key in ("idx_low", "idx_high", "R", "actions", "action_probs", "win_low", "win_high"):
+        assert torch.equal(ref[key], orc[key]), f"oracle != reference on {key} ({name})"
+    out = {k: v.numpy() for k, v in ref.items()}
+    out.update(inputs=x.numpy(), hidden=H, n_cat=T, n_per=K, seed_low=seed, seed_high=seed + 1, embedding_size=E,
+               margin_low=orc["margin_low"].numpy(), margin_high=orc["margin_high"].numpy())
+    np.savez_compressed(os.path.join(HERE, f"pn_embed_{name}.npz"), **out)
+    print(f"pn_embed_{name}: E={E} B={B} T={T} K={K} H={H}; min margin low/high = "
+          f"{float(orc['margin_low'].min()):.3e} / {float(orc['margin_high'].min()):.3e}")
+
+
 def gen_pn_sample(modelPN, name, H, T, K, B, seed, sample_seed):
     """The sampling mode (modelPN.py:227-228) of the REAL reference — Low greedy -> latent, High with sample='sample', the
     forward of a PNHigh training step (trainPNHigh.py:83-84) — with ``Tensor.multinomial`` routed to the counter-based
@@ -378,11 +414,11 @@ def gen_data(loadData_mod, ML2PN_mod):
     print("data_small: check score", fx["check"]["score"])
 
 
-def gen_ml(modelML, name, hidden, emb, n_gin, n_gcn, T, S, B, seed, n_t=3, degree=6):
+def gen_ml(modelML, name, hidden, emb, n_gin, n_gcn, T, S, B, seed, n_t=3, degree=6, is_services=True):
     table = synth.make_service_table(T, S, seed, degree=degree)
     batch = synth.make_problem_batch(table, B, seed + 1, tasks_per_problem=n_t)
     sd = oml.make_state_dict(hidden, emb, n_gin, n_gcn, seed + 2)
-    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=True, dropout=0.0)
+    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=is_services, dropout=0.0)
     net.load_state_dict(sd, strict=True)        # pins key names + shapes
     net.eval()
     # what a PyG batch of B graphs holds (trainML.py:109-114): B copies of the service graph
@@ -395,12 +431,12 @@ def gen_ml(modelML, name, hidden, emb, n_gin, n_gcn, T, S, B, seed, n_t=3, degre
     with torch.no_grad():
         ref = net(data)
     one = oml.make_data(data.x, data.edge_index, data.batch, xs, eis, eas)
-    orc = oml.net_forward(sd, one, n_gin, n_gcn)
+    orc = oml.net_forward(sd, one, n_gin, n_gcn, is_services)
     err = float((ref - orc).abs().max())
     assert err <= 1e-6, f"oracle Net != reference glue: {err}"
     np.savez_compressed(
         os.path.join(HERE, f"ml_{name}.npz"), scores=ref.numpy(), ranking=oml.rank_services(ref).numpy(),
-        hidden=hidden, emb=emb, n_gin=n_gin, n_gcn=n_gcn, T=T, S=S, B=B, seed=seed, n_t=n_t, degree=degree,
+        is_services=is_services, hidden=hidden, emb=emb, n_gin=n_gin, n_gcn=n_gcn, T=T, S=S, B=B, seed=seed, n_t=n_t, degree=degree,
         x=batch.x, edge_index=batch.edge_index, batch=batch.batch, x_service=table.x_service,
         edge_index_service=table.edge_index, edge_attr_service=table.edge_attr)
     print(f"ml_{name}: B={B} S={S} max|ref-oracle|={err:.2e}")
@@ -555,11 +591,15 @@ def main():
     gen_pn_attn(modelPN, "bahdanau_g2_small", H=32, T=6, K=3, B=6, seed=115, attention="Bahdanau", n_glimpses=2)
     gen_pn_attn(modelPN, "dot_g1_qws", H=256, T=47, K=5, B=16, seed=117, attention="Dot", n_glimpses=1)
     gen_pn_attn(modelPN, "bahdanau_g1_qws", H=256, T=47, K=5, B=16, seed=119, attention="Bahdanau", n_glimpses=1)
+    gen_pn_embed(modelPN, "small", H=32, T=6, K=3, B=6, seed=141, E=4)
+    gen_pn_embed(modelPN, "qws", H=256, T=47, K=5, B=16, seed=145, E=20)
     gen_reward(modelPN)
     gen_data(loadData_mod, ML2PN_mod)
     gen_ml(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, B=2, seed=51)
     gen_ml(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, B=2, seed=61, n_t=10, degree=8)
     gen_ml(modelML, "normal", hidden=128, emb=20, n_gin=2, n_gcn=4, T=50, S=250, B=1, seed=71, n_t=10, degree=8)
+    gen_ml(modelML, "noservices", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, B=3, seed=81, n_t=10, degree=8,
+           is_services=False)                                                     # modelML.py:157-162
     gen_ml_pygbatch(modelML, "pygbatch", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=81, n_t=10, degree=8)
     gen_ml_train(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, seed=121, lr=1e-3, steps=3)
     gen_ml_train(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=131, lr=1e-3, n_t=10, degree=8, steps=1)

@@ -16,13 +16,14 @@ SCORE_ATOL = 1e-5
 
 def make_net(fx, dev, vocab=100):
     from gnnpn_sc_amd.modelML import Net
-    net = Net(int(fx["hidden"]), int(fx["S"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]), vocab=vocab)
+    net = Net(int(fx["hidden"]), int(fx["S"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]), vocab=vocab,
+              isServices=bool(fx["is_services"]) if "is_services" in fx else True)
     net.load_state_dict(oml.make_state_dict(int(fx["hidden"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]),
                                             int(fx["seed"]) + 2, vocab=vocab), strict=True)
     return net.to(dev).eval()
 
 
-@pytest.mark.parametrize("name", ["tiny", "qws", "normal"])
+@pytest.mark.parametrize("name", ["tiny", "qws", "normal", "noservices"])
 def test_net_forward_golden(dev, name):
     fx = golden(f"ml_{name}.npz")
     net = make_net(fx, dev)
@@ -73,10 +74,7 @@ def test_net_forward_on_a_pyg_style_batch(dev):
         net(bad)                                                  # neither one copy nor one copy per graph
 
 
-def test_net_rejects_training_and_noservices(dev):
-    from gnnpn_sc_amd.modelML import Net
-    with pytest.raises(NotImplementedError):
-        Net(16, 40, 8, 2, 2, isServices=False)
+def test_net_rejects_training(dev):
     fx = golden("ml_tiny.npz")
     net = make_net(fx, dev).train()
     with pytest.raises(NotImplementedError):

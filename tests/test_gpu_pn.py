@@ -80,6 +80,37 @@ def test_attention_forms_golden(dev, name):
     assert torch.equal(R, out["R"])
 
 
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_category_embedding_golden(dev, name):
+    """embedding_size != 0 (embeddingTag=1; modelPN.py:153-154,183-188): rows [category | 8 floats], the category embedded and
+    concatenated in front of embedding2 (gnnpn_embed_concat_f32 + the literal two-stage input side), against fixtures the
+    real modelPN.py produced — picks by the per-decision rule, action rows WITH their category column, R, logits."""
+    from conftest import record_agreement
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
+    fx = golden(f"pn_embed_{name}.npz")
+    H, T, K, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["embedding_size"])
+    nets = []
+    for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
+        m = CombinatorialRL(E, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed, embedding_size=E, n_cat=T), strict=True)
+        nets.append(m.to(dev).eval())
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    out = two_level_greedy(nets[0], nets[1], x)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, f"embed/{name}", rows=fx["inputs"])
+    s = rec["same_mask"]
+    assert s.sum() >= 0.7 * len(s), rec
+    assert np.abs(out["win_low"].cpu().numpy()[s] - fx["win_low"][s]).max() < LOGIT_ATOL
+    assert np.abs((out["win_high_raw"] + out["win_low"]).cpu().numpy()[s] - fx["win_high"][s]).max() < LOGIT_ATOL
+    assert_R_parity(out["R"], fx["R"], f"embed/{name}", mask=s)
+    assert out["actions"].shape[2] == 9 and np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
+    record_agreement(f"category_embedding/{name}", rec)
+    # reference-style calls (CombinatorialRL.forward, Low "SL" -> latent -> High) give the same picks and reward
+    _, _, _, idx_l, latent = nets[0](x, None, sample="greedy", training="SL")
+    R, _, actions, idx_h, _ = nets[1](x, None, latent, sample="greedy")
+    assert torch.equal(torch.stack(idx_l, 1).int(), out["idx_low"]) and torch.equal(torch.stack(idx_h, 1).int(), out["idx_high"])
+    assert torch.equal(R, out["R"]) and actions[0].shape == (x.shape[0], 9)
+
+
 def test_general_kernel_on_the_shipped_configuration_equals_the_streaming_decoder(dev):
     """'Dot' without glimpses through the general kernel is the streaming decoder's arithmetic: same picks, same window
     logits bit for bit (the two kernels share the cell, the dot order and the argmax rule)."""
@@ -135,8 +166,11 @@ def test_reference_style_calls(dev, name):
 
 def test_unsupported_modes_fail_loudly(dev):
     from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
+    e = CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)      # the category embedding decodes greedily only
+    xe = torch.cat([torch.arange(6.0).repeat_interleave(3).view(1, 18, 1).expand(2, 18, 1), torch.rand(2, 18, 8)], 2).to(dev)
     with pytest.raises(NotImplementedError):
-        CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6)
+        e(xe, None)                                                             # default sample="sample"
+    assert e(xe, None, sample="greedy")[2][0].shape == (2, 9)
     with pytest.raises(NotImplementedError):
         CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Luong", 3, 6)             # modelPN.py:116-117
     g = CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Bahdanau", 3, 6).to(dev)  # the general forms decode greedily only

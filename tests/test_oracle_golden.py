@@ -57,6 +57,24 @@ def test_pn_oracle_attention_forms_reproduce_reference(name):
     assert all(torch.equal(plain[k], sds[0][k]) for k in plain)
 
 
+@pytest.mark.parametrize("name", ["small", "qws"])
+def test_pn_oracle_category_embedding_reproduces_reference(name):
+    """pn_embed_*.npz: the real modelPN.py with embedding_size != 0 (embeddingTag=1; modelPN.py:153-154,183-188, reward's
+    tag :42-45): rows [category | 8 floats]."""
+    fx = golden(f"pn_embed_{name}.npz")
+    torch.set_num_threads(1)
+    H, T, K, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["embedding_size"])
+    sds = [opn.make_state_dict(H, int(fx[k]), embedding_size=E, n_cat=T) for k in ("seed_low", "seed_high")]
+    assert fx["inputs"].shape[2] == 9 and sds[0]["actor.embedding2.weight"].shape == (H, E + 8)
+    out = opn.two_level_greedy(sds[0], sds[1], torch.from_numpy(fx["inputs"]), T, K)
+    for key in ("idx_low", "idx_high", "actions"):
+        assert np.array_equal(out[key].numpy(), fx[key]), key
+    assert out["actions"].shape[2] == 9                                   # the action rows keep the category column (:293-295)
+    assert np.allclose(out["R"].numpy(), fx["R"], rtol=0, atol=1e-6)
+    assert np.allclose(out["win_low"].numpy(), fx["win_low"], rtol=0, atol=2e-5)
+    assert np.allclose(out["win_high"].numpy(), fx["win_high"], rtol=0, atol=2e-5)
+
+
 def test_lstm_cell_explicit_matches_nn_lstm():
     """Documents the cell arithmetic the kernels implement (gate order i,f,g,o)."""
     sd = opn.make_state_dict(32, 3)
@@ -110,7 +128,7 @@ def test_data_oracle_reproduces_reference():
     assert abs(odata.check(k1, ds["minCostList"], fx["check"]["actions"], T) - fx["check"]["score"]) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["tiny", "qws", "normal"])
+@pytest.mark.parametrize("name", ["tiny", "qws", "normal", "noservices"])
 def test_ml_oracle_reproduces_reference_glue(name):
     fx = golden(f"ml_{name}.npz")
     torch.set_num_threads(1)
@@ -118,9 +136,12 @@ def test_ml_oracle_reproduces_reference_glue(name):
     t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
     data = oml.make_data(t("x"), t("edge_index"), t("batch"), t("x_service"), t("edge_index_service"),
                          t("edge_attr_service"))
-    scores = oml.net_forward(sd, data, int(fx["n_gin"]), int(fx["n_gcn"]))
+    is_services = bool(fx["is_services"]) if "is_services" in fx else True      # modelML.py:151 / :157
+    scores = oml.net_forward(sd, data, int(fx["n_gin"]), int(fx["n_gcn"]), is_services)
     assert float((scores - t("scores")).abs().max()) <= 1e-6
     assert torch.equal(oml.rank_services(t("scores")), t("ranking"))
+    if not is_services:          # the fixture must really take the other branch
+        assert float((oml.net_forward(sd, data, int(fx["n_gin"]), int(fx["n_gcn"]), True) - t("scores")).abs().max()) > 1e-3
 
 
 def test_hand_graph():

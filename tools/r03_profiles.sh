@@ -25,7 +25,7 @@ fi
 cd /tmp && export TMPDIR=/tmp
 SOLO="--min-time 0 --no-cpu-baseline --no-kernel-timers --no-other-precision --graph 0 --inflight 1"
 if [ $PART = all ] || [ $PART = 2 ]; then
-for wl in qws normal synth4 synth5; do
+for wl in ${WLS:-qws normal synth4 synth5}; do
   st=20; [ $wl = normal ] && st=8; [ $wl = synth4 ] && st=3; [ $wl = synth5 ] && st=2
   for pr in split f32; do
     timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_${wl}_$pr -- python3 $R/bench.py --workload $wl --precision $pr --steps $st --warmup 2 $SOLO > $O/stats_${wl}_$pr.log 2>&1
@@ -36,7 +36,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_syn
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_qws_default -- python3 $R/bench.py --steps 20 --warmup 3 --min-time 0 --no-cpu-baseline --no-kernel-timers --no-other-precision > $O/stats_qws_default.log 2>&1
 fi
 if [ $PART = all ] || [ $PART = 3 ]; then
-for wl in qws normal synth4 synth5; do
+for wl in ${WLS:-qws normal synth4 synth5}; do
   for pr in split f32; do
     timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_${wl}_$pr -- python3 $R/bench.py --workload $wl --precision $pr --steps 2 --warmup 1 $SOLO > $O/fetch_${wl}_$pr.log 2>&1
     timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_${wl}_$pr -- python3 $R/bench.py --workload $wl --precision $pr --steps 2 --warmup 1 $SOLO > $O/write_${wl}_$pr.log 2>&1

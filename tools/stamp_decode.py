@@ -15,8 +15,8 @@ two_level_greedy(low, high, x); torch.cuda.synchronize()
 ws = ops.workspaces(dev).decode(B, T, K)
 prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
 n = max(prof[7], 1)
-names = ["sweep wait", "LDS fill + logits + argmax", "barrier + pick row", "window loads + W_hh.h", "input side + cell + publish h", "barrier",
-         "partial dots + publish"]
+names = ["sweep of h: wait", "h to LDS + barrier", "window loads + W_hh.h", "sweep of the partial dots: wait", "logits, argmax, barrier, pick's row",
+         "input side + cell + publish h", "barrier + partial dots + publish"]
 print("f32  ", {k: round(v / n) for k, v in zip(names, prof[:7])}, "steps", n, "total", round(sum(prof[:7]) / n))
 for _ in range(2): two_level_greedy(low, high, x, precision="split")
 torch.cuda.synchronize()
