@@ -145,10 +145,15 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     const int own0 = kq * 4 + (c < 8 ? 0 : 2);           // this lane finishes rows own0, own0+1 of unit `unit`
     const int vo_hpub = (int)(own0 * H + unit) * 8u;
     const int vo_sweep = 16 * lane;                // h pairs: + 1024 j
-    const int vo_p = 64 * lane;                    // lane (rq, r): its 8 partials = 4 pairs, 64 contiguous bytes
+    // Lanes that have nothing to load load anyway, from an offset past every resource (reads as zero, moves no data): a
+    // load under a lane mask is a branch around it, and at the join the compiler's vmcnt bookkeeping — in-order counting —
+    // can no longer tell how many operations are in flight: it then waits for the loads of the step's window right where
+    // they were issued (seen in the ISA: s_waitcnt vmcnt(2)/(1)/(0) directly behind them).
+    constexpr int VO_NONE = (int)0xFFFFFF00u;
     const int rq = kq, r = c;                            // argmax view of the lane: row 4 wave + rq, candidate r
     const bool live = r < K;
-    const int vo_lat = (int)(rq * K + r) * 8u;
+    const int vo_p = live ? 64 * lane : VO_NONE;   // lane (rq, r): its 8 partials = 4 pairs, 64 contiguous bytes
+    const int vo_lat = live ? (int)(rq * K + r) * 8u : VO_NONE;
     const int vo_wl = (int)((wave * 4 + rq) * T * K + r) * 4u;     // win_logits / latent_win [row][T][K]
     const int vo_idx = (int)((wave * 4 + rq) * T) * 4u;            // idx [row][T]
     const int vo_act = (int)(c * T * 8 + kq) * 4u;                 // actions [row c][T][8], features kq and 4 + kq
@@ -157,11 +162,11 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     const int ppair = tid / EVH, phalf = tid - ppair * EVH;
     const int prow = ppair / K, pcand = ppair - prow * K;
     const bool pdot = ppair < ROWS * K;
-    const int vo_ev = (int)(((size_t)prow * L + pcand) * H + member * UNITS + phalf * (4 * EVN)) * 4u;
+    const int vo_ev = pdot ? (int)(((size_t)prow * L + pcand) * H + member * UNITS + phalf * (4 * EVN)) * 4u : VO_NONE;
     const int vo_ppub = (int)((prow * KW + pcand) * G + member) * 8u;
     const int wr_row = tid >> 4, wr_cand = tid & 15;     // window-row staging: thread (row, candidate) moves 32 bytes
     const bool wr_live = wr_cand < K;
-    const int vo_win = (int)(((size_t)wr_row * L + wr_cand) * 8) * 4u;
+    const int vo_win = wr_live ? (int)(((size_t)wr_row * L + wr_cand) * 8) * 4u : VO_NONE;
 
     __amdgpu_buffer_rsrc_t r_h = make_rsrc(xh + (size_t)group * (2 * ROWS * H), 2 * ROWS * H * 8);
     __amdgpu_buffer_rsrc_t r_p = make_rsrc(xp + (size_t)group * (2 * XP_GRANULES), 2 * XP_GRANULES * 8);
@@ -215,6 +220,17 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             asm volatile("" : "=v"(vl));
             f32x4 ah[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
+            // This step's window of enc_out (rows of the window against the own 32-unit slice; consumed in (5)).  It does not
+            // depend on the picks, only on k; it comes from HBM (enc_out of a launch is tens of MB).  vmcnt counts in order, so a
+            // request must sit behind every load whose result is needed EARLIER: the one-per-CU builds request it right behind
+            // the sweep of h — it then has the products, the argmax and the cell update to arrive (32 more live registers at
+            // most) — and the two-per-CU builds, which have no registers for that, in (4), where the other resident workgroup
+            // covers the round trip.
+            constexpr bool EV_EARLY = OCC == 1;
+            auto request_ev = [&]() {
+#pragma unroll
+                for (int j = 0; j < EVN; ++j) ev[j] = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev, so_k * (H * 4) + 16u * j, 0);
+            };
             // ---- (1) h_{k-1}: peers published it BEFORE their partial dots, so it is (nearly) there when this member has
             // published its own; the W_hh.h products start on it while the partial dots are still in flight
             if (k < T) {
@@ -268,24 +284,19 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                             d[64] = __uint_as_float(vh[j].z);
                         }
                     }
+                    if constexpr (EV_EARLY) request_ev();
                     __syncthreads();   // the h tile of every wave is complete
                     if (abort_flag) break;
+                } else if constexpr (EV_EARLY) {
+                    request_ev();
                 }
                 if constexpr (DIAG) st[2] = phase_stamp();
                 // ---- (2) W_hh.h (the folded input side follows the pick, below).  Half-way through, the first pass over the
                 // partial dots of publish #(step-1) is requested: they were published a hand-off time ago, and the loads' own
                 // round trip (~700 cycles) then lies under the second half of the products instead of behind them.
-                // This step's window (enc_out rows against the own 32-unit slice, consumed after the cell update) is requested in
-                // (4), behind the barrier that follows the argmax: every __syncthreads waits for ALL outstanding vector-memory
-                // operations (s_waitcnt vmcnt(0) in front of s_barrier), and so does the guard the compiler puts in front of the
-                // chain's first LDS reads — an HBM load in flight across either is an HBM round trip per step on the critical
-                // path (seen in the ISA and the stamps: 5.4 k cycles for 4.1 k cycles of MFMAs with the loads in front of the
-                // chain, 0.9 k cycles of "argmax" with them in front of the barrier).  From (4) they have the cell update.
-                // (The 2-per-CU builds request them behind the products instead: 18 more live registers across the second half do
-                // not fit 256, and there the other resident workgroup covers the round trip.)
                 constexpr bool EARLY_P = OCC == 1;
                 auto request_p = [&]() {
-                    if (EARLY_P && k > 0 && live) {
+                    if (EARLY_P && k > 0) {
                         const unsigned so_p = par * (XP_GRANULES * 8) + wave * (4 * KW * G * 8);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p, so_p + 16u * j, AUX_SC1);
@@ -312,11 +323,9 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                     if (spins > 0 || k == T || OCC != 1) {
                         unsigned so_p = so_p0, so_l = so_l0;
                         asm volatile("" : "+s"(so_p), "+s"(so_l));
-                        if (live) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p, so_p + 16u * j, AUX_SC1);
-                            if (latent_in_launch) vl = __builtin_amdgcn_raw_buffer_load_b64(r_lat, vo_lat, so_l, AUX_SC1);
-                        }
+                        for (int j = 0; j < 4; ++j) vp[j] = __builtin_amdgcn_raw_buffer_load_b128(r_p, vo_p, so_p + 16u * j, AUX_SC1);
+                        if (latent_in_launch) vl = __builtin_amdgcn_raw_buffer_load_b64(r_lat, vo_lat, so_l, AUX_SC1);
                     }
                     bool good = true;
                     if (live) {
@@ -388,18 +397,12 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             }
 
             // ---- (4) folded input side, cell update, publish h_k
+            if constexpr (!EV_EARLY) request_ev();
             // the raw rows of this step's window (the next pick's decoder input comes out of them): requested here — they are
             // consumed at the end of the step — so that they are not live across the products
-            if (pdot) {   // this step's window of enc_out (see the note at the products): it has the cell update to arrive
-#pragma unroll
-                for (int j = 0; j < EVN; ++j) ev[j] = __builtin_amdgcn_raw_buffer_load_b128(r_enc, vo_ev, so_k * (H * 4) + 16u * j, 0);
-            }
-            u32x4 wv0, wv1;   // "defined" without an instruction: an initialising move behind the loads above makes the compiler wait
-            asm volatile("" : "=v"(wv0), "=v"(wv1));   // for them on the spot (it guards the register against the previous step's load)
-            if (wr_live) {
-                wv0 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u, 0);
-                wv1 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u + 16u, 0);
-            }
+            u32x4 wv0, wv1;
+            wv0 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u, 0);
+            wv1 = __builtin_amdgcn_raw_buffer_load_b128(r_in, vo_win, so_k * 32u + 16u, 0);
             float gx[2][4];
             if (k > 0) {
                 f32x4 ax0 = {0.f, 0.f, 0.f, 0.f}, ax1 = ax0;
