@@ -53,7 +53,7 @@ def _prepare(services, constraints, solution, patches=()):
     return cats, len0, start, rows, bounds
 
 
-def fine_tune(problems, popSize=100, MAX_Iter=500, seeds=None, device=None, patches=()):
+def fine_tune(problems, popSize=100, MAX_Iter=500, seeds=None, device=None, patches=(), wide=None):
     """ES-WOA over many problems in ONE launch.  problems: iterable of (services, constraints, solution | None) with the
     same number of categories.  Returns a list of dicts: bestFitness, bestSolutions (rows), bestPops, bestFitnesses, draws."""
     problems = list(problems)
@@ -67,7 +67,7 @@ def fine_tune(problems, popSize=100, MAX_Iter=500, seeds=None, device=None, patc
         out = [None] * len(problems)
         for T in sorted(set(sizes)):
             idx = [i for i, n in enumerate(sizes) if n == T]
-            for i, r in zip(idx, fine_tune([problems[i] for i in idx], popSize, MAX_Iter, seeds[idx], device, patches)):
+            for i, r in zip(idx, fine_tune([problems[i] for i in idx], popSize, MAX_Iter, seeds[idx], device, patches, wide)):
                 out[i] = r
         return out
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -85,7 +85,7 @@ def fine_tune(problems, popSize=100, MAX_Iter=500, seeds=None, device=None, patc
     t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(dev)      # noqa: E731
     fit, pos, hist, draws = ops.eswoa(t(ptr, torch.int32), t(len0, torch.int32), t(flat, torch.float64).reshape(-1, 4),
                                       t(bounds, torch.float64), t(start, torch.int32), popSize, MAX_Iter,
-                                      torch.from_numpy(seeds.view(np.int64).copy()).to(dev), T)
+                                      torch.from_numpy(seeds.view(np.int64).copy()).to(dev), T, wide)
     fit, pos, hist, draws = fit.cpu().tolist(), pos.cpu().tolist(), hist.cpu().tolist(), draws.cpu().tolist()
     out = []
     for p, (cats, _l0, st, _rows, _b) in enumerate(prep):

@@ -506,49 +506,73 @@ __device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&
     f32x4 a0[NT], a0b[NT], a1[NT], a2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) a0[n] = a0b[n] = a1[n] = a2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Fragment schedule (registers are short: two workgroups per CU).  Per k-block the six products run in the order
+    // Fragment schedule (registers are short: two workgroups per CU).  Per k-block the twelve products run in the order
     //   h1.w1 -> a2 | h1.w0 -> a1 | h0.w2 -> a2 | h0.w0 -> a0 | h2.w0 -> a2 | h0.w1 -> a1        (each for both tiles)
-    // so that an accumulator is reused after >= 3 other MFMAs, and every single-buffered piece (h1, h2, the third-piece bytes)
-    // is re-requested right after its last use with >= 4 pairs (128 cycles) of products before its next one; h0, used three
-    // times per block, is the one double-buffered piece.  The scheduling fences pin that order: left alone the compiler sinks
-    // every LDS read down to its first use (fewest live registers) and the wave then waits out a full LDS latency several times
-    // per block — the first build of this function spent 3.5 k cycles on 1.5 k cycles of MFMAs (tools/stamp_decode.py).
+    // one per line below, every line ending in a scheduling fence.  A 16x16x32 product occupies the matrix pipe for 16
+    // cycles and the SIMD's vector issue for 8 of them (MI355X_MICROARCH.md, cycle constants): the eight v_perm that expand
+    // the block's third-piece bytes are dealt two per gap to the first four gaps, and every single-buffered piece (h1, h2,
+    // the bytes) is re-requested in the gap behind its last use, >= 7 products (112 cycles) ahead of its next one; h0, used
+    // three times per block, is the one double-buffered piece.  Left alone the compiler sinks every LDS read down to its
+    // first use (fewest live registers) and the wave waits out a full LDS latency several times per block — the first build
+    // of this function spent 3.5 k cycles on 1.5 k cycles of MFMAs (tools/stamp_decode.py).  Measured: the bare chain runs
+    // at 17.4-18.1 ticks per product (tools/probes/mfma_chain_rate.hip: registers only / with these LDS reads and v_perm);
+    // inside the kernels the phase takes 2.4 k ticks for 96 products.  Dealing the v_perm out instead of one burst of eight
+    // per block changed nothing for a lone workgroup (2440 vs 2420) and gave +2 % on the two-slot pipeline (the partner
+    // wave's vector instructions find the issue slots).
     f16x8 h0[2];
     h0[0] = *reinterpret_cast<const f16x8*>(base);
     f16x8 h1 = *reinterpret_cast<const f16x8*>(base + SPLIT_TILE);
     f16x8 h2 = *reinterpret_cast<const f16x8*>(base + 2 * SPLIT_TILE);
     u32x4 t = *reinterpret_cast<const u32x4*>(wt);
+#define GNNPN_FENCE __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int nx = 32 * (kk + 1), cur = kk & 1;
+        u32x4 e0, e1;                                                       // the expanded third pieces of tiles 0 and 1
         if (kk < 7) h0[cur ^ 1] = *reinterpret_cast<const f16x8*>(base + nx);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w1[n][kk], a2[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w0[n][kk], a1[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk < 7) h1 = *reinterpret_cast<const f16x8*>(base + SPLIT_TILE + nx);
-        const f16x8 w2[NT] = {split_expand(t.x, t.y), split_expand(t.z, t.w)};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w2[n], a2[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk < 7) t = *reinterpret_cast<const u32x4*>(wt + 4 * 64 * (kk + 1));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            if (kk < 4) a0[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[n][kk], a0[n], 0, 0, 0);
-            else a0b[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[n][kk], a0b[n], 0, 0, 0);
+        GNNPN_FENCE;
+        a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w1[0][kk], a2[0], 0, 0, 0);
+        e0.x = __builtin_amdgcn_perm(0u, t.x, 0x010c000cu);
+        e0.y = __builtin_amdgcn_perm(0u, t.x, 0x030c020cu);
+        GNNPN_FENCE;
+        a2[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w1[1][kk], a2[1], 0, 0, 0);
+        e0.z = __builtin_amdgcn_perm(0u, t.y, 0x010c000cu);
+        e0.w = __builtin_amdgcn_perm(0u, t.y, 0x030c020cu);
+        GNNPN_FENCE;
+        a1[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w0[0][kk], a1[0], 0, 0, 0);
+        e1.x = __builtin_amdgcn_perm(0u, t.z, 0x010c000cu);
+        e1.y = __builtin_amdgcn_perm(0u, t.z, 0x030c020cu);
+        GNNPN_FENCE;
+        a1[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, w0[1][kk], a1[1], 0, 0, 0);
+        e1.z = __builtin_amdgcn_perm(0u, t.w, 0x010c000cu);
+        e1.w = __builtin_amdgcn_perm(0u, t.w, 0x030c020cu);
+        GNNPN_FENCE;
+        if (kk < 7) {
+            h1 = *reinterpret_cast<const f16x8*>(base + SPLIT_TILE + nx);
+            t = *reinterpret_cast<const u32x4*>(wt + 4 * 64 * (kk + 1));
         }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2, w0[n][kk], a2[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], __builtin_bit_cast(f16x8, e0), a2[0], 0, 0, 0);
+        GNNPN_FENCE;
+        a2[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], __builtin_bit_cast(f16x8, e1), a2[1], 0, 0, 0);
+        GNNPN_FENCE;
+        if (kk < 4) a0[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[0][kk], a0[0], 0, 0, 0);
+        else a0b[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[0][kk], a0b[0], 0, 0, 0);
+        GNNPN_FENCE;
+        if (kk < 4) a0[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[1][kk], a0[1], 0, 0, 0);
+        else a0b[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w0[1][kk], a0b[1], 0, 0, 0);
+        GNNPN_FENCE;
+        a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2, w0[0][kk], a2[0], 0, 0, 0);
+        GNNPN_FENCE;
+        a2[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2, w0[1][kk], a2[1], 0, 0, 0);
+        GNNPN_FENCE;
         if (kk < 7) h2 = *reinterpret_cast<const f16x8*>(base + 2 * SPLIT_TILE + nx);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) a1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w1[n][kk], a1[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        a1[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w1[0][kk], a1[0], 0, 0, 0);
+        GNNPN_FENCE;
+        a1[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0[cur], w1[1][kk], a1[1], 0, 0, 0);
+        GNNPN_FENCE;
         if (kk == 3) mid();
     }
+#undef GNNPN_FENCE
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll

@@ -553,10 +553,12 @@ def debug_cell_activations(x):
     return sig, th
 
 
-def eswoa(cand_ptr, len_init, cand, bounds, start_pos, pop, max_iter, seeds, n_cat):
-    """ES-WOA fine-tuning of P problems in one launch (gnnpn_eswoa_f64; reference src/baselines/WOA.py:8-162).
+def eswoa(cand_ptr, len_init, cand, bounds, start_pos, pop, max_iter, seeds, n_cat, wide=None):
+    """ES-WOA fine-tuning of P problems in one launch (gnnpn_eswoa_f64 for T <= 64 categories, gnnpn_eswoa_wide_f64 above;
+    reference src/baselines/WOA.py:8-162).
     cand_ptr [P*T+1] i32, len_init [P*T] i32, cand [n,4] f64, bounds [P,4] f64, start_pos [P*T] i32 (first entry of a
-    problem < 0: no seed solution), seeds [P] int64 (bit pattern of the uint64 seed).  Returns (best_fitness [P] f64,
+    problem < 0: no seed solution), seeds [P] int64 (bit pattern of the uint64 seed); ``wide`` True forces the any-T kernel
+    for T <= 64 as well (tests: both forms give the same run).  Returns (best_fitness [P] f64,
     best_pos [P,T] i32, history [P,max_iter] f64, draws [P] i64)."""
     dev = cand.device
     T = int(n_cat)
@@ -566,6 +568,18 @@ def eswoa(cand_ptr, len_init, cand, bounds, start_pos, pop, max_iter, seeds, n_c
     best_pos = torch.empty(P, T, dtype=I32, device=dev)
     history = torch.empty(P, max(int(max_iter), 1), dtype=torch.float64, device=dev)
     draws = torch.empty(P, dtype=I64, device=dev)
+    if T > 64 or wide:      # one workgroup per problem, positions in a workspace (csrc/woa.hip: eswoa_wide_kernel)
+        lib = _lib.load()
+        nbytes = int(lib.gnnpn_eswoa_wide_workspace_bytes(P, T, int(pop)))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=I32, device=dev)
+        check(lib.gnnpn_eswoa_wide_f64(P, T, dev_ptr(cand_ptr, I32, "cand_ptr"), dev_ptr(len_init, I32, "len_init"),
+                                       dev_ptr(cand, torch.float64, "cand"), dev_ptr(bounds, torch.float64, "bounds"),
+                                       dev_ptr(start_pos, I32, "start_pos"), int(pop), int(max_iter),
+                                       dev_ptr(seeds, I64, "seeds"), dev_ptr(ws, I32, "workspace"), nbytes,
+                                       dev_ptr(best_fit, torch.float64, "best_fitness"), dev_ptr(best_pos, I32, "best_pos"),
+                                       dev_ptr(history, torch.float64, "history"), dev_ptr(draws, I64, "draws"), stream_ptr()),
+              "gnnpn_eswoa_wide_f64")
+        return best_fit, best_pos, history[:, :int(max_iter)], draws
     per_problem = cand_ptr[T::T] - cand_ptr[:-1:T] if P else cand_ptr[:0]
     max_cand = int(per_problem.max().item()) if P else 1
     check(_lib.load().gnnpn_eswoa_f64(P, T, dev_ptr(cand_ptr, I32, "cand_ptr"), dev_ptr(len_init, I32, "len_init"),

@@ -467,11 +467,23 @@ int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t 
  *   max_cand         : the largest cand_ptr[(p+1)*T] - cand_ptr[p*T] (sizes the LDS)
  * Outputs: best_fitness [P], best_pos [P*T] (may be negative: Python list positions), history [P*max_iter] (best
  * fitness after every iteration, WOA.py:128,161), draws [P] (stream positions consumed).
- * GNNPN_E_UNSUP: T outside 1..64, or a problem that does not fit a CU's LDS. */
+ * GNNPN_E_UNSUP: T outside 1..64 (one category per lane: use gnnpn_eswoa_wide_f64), or a problem that does not fit a CU's LDS. */
 int gnnpn_eswoa_f64(int32_t P, int32_t T, const int32_t* cand_ptr, const int32_t* len_init, const double* cand,
                     const double* bounds, const int32_t* start_pos, int32_t pop, int32_t max_iter, const uint64_t* seeds,
                     int32_t max_cand, double* best_fitness, int32_t* best_pos, double* history, int64_t* draws,
                     void* stream);
+
+/* The same search for ANY number of categories (the 1000- and 2000-task configurations): one workgroup per problem, the
+ * population's positions in `workspace` (gnnpn_eswoa_wide_workspace_bytes = P * pop * T int32), the three QoS columns of
+ * the composition under evaluation in LDS (24 T + 8 T bytes: T <= ~5000).  Same draws, same float64 evaluation orders
+ * (np.cumprod sequential; np.sum pairwise — for n > 128 numpy's recursion: halves rounded down to a multiple of 8), so a
+ * run equals gnnpn_eswoa_f64's wherever both apply and the oracle's (oracle/woa.py) everywhere.
+ * GNNPN_E_UNSUP: the columns do not fit a CU's LDS. */
+int64_t gnnpn_eswoa_wide_workspace_bytes(int32_t P, int32_t T, int32_t pop);
+int gnnpn_eswoa_wide_f64(int32_t P, int32_t T, const int32_t* cand_ptr, const int32_t* len_init, const double* cand,
+                         const double* bounds, const int32_t* start_pos, int32_t pop, int32_t max_iter, const uint64_t* seeds,
+                         void* workspace, int64_t workspace_bytes, double* best_fitness, int32_t* best_pos, double* history,
+                         int64_t* draws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training step of the GNN candidate-ranking model.  Replaces the autograd graph of

@@ -59,10 +59,66 @@ def test_eswoa_batch_vs_live_oracle(dev):
         assert [tuple(r) for r in got[p]["bestSolutions"]] == [tuple(r[:4]) for r in want["best_rows"]], p
 
 
+def _random_problems(g, T, n, max_cand=8):
+    problems = []
+    for p in range(n):
+        services = [[tuple(float(v) for v in np.r_[g.random(2), 1.0 - g.random(2) * 0.2 / T]) for _ in range(int(g.integers(1, max_cand)))]
+                    for _ in range(T)]
+        lo = float(g.choice([0.5, 0.95]))                     # products of T factors in (1 - 0.2/T, 1]: within [0.8, 1]
+        cons = [[[lo, 1.0]], [[lo, 1.0]]]
+        sol = None if p % 4 == 3 else [list(cat[int(g.integers(0, len(cat)))]) for cat in services]
+        if sol is not None and p % 3 == 0:
+            sol[p % T] = [float(v) for v in np.r_[g.random(2), 1.0 - g.random(2) * 0.2 / T]]           # foreign pick
+        problems.append((services, cons, sol))
+    return problems
+
+
+def _assert_run_equals_oracle(got, problems, seeds, pop, iters):
+    for p, (services, cons, sol) in enumerate(problems):
+        want = owoa.eswoa(services, cons, copy.deepcopy(sol), pop, iters, owoa.DrawStream(seeds[p]))
+        assert got[p]["draws"] == want["draws"], p
+        assert got[p]["bestFitnesses"] == want["history"], p
+        assert got[p]["bestFitness"] == want["best_fitness"], p
+        assert [int(v) for v in got[p]["bestPops"]] == [int(v) for v in want["best_pos"]], p
+        assert [tuple(r) for r in got[p]["bestSolutions"]] == [tuple(r[:4]) for r in want["best_rows"]], p
+
+
+@pytest.mark.parametrize("T,n,pop,iters", [(65, 6, 12, 10), (127, 4, 10, 8), (128, 3, 8, 6), (129, 3, 8, 6), (300, 4, 10, 8),
+                                          (1000, 3, 8, 5), (2000, 2, 6, 4)])
+def test_eswoa_wide_vs_live_oracle(dev, T, n, pop, iters):
+    """More than 64 categories (the 1000- and 2000-task configurations): the workgroup-per-problem kernel against the oracle
+    run live — same draws, same float64 history bit for bit (np.sum's pairwise recursion sets in above 128 terms: 129, 300,
+    1000 and 2000 cut the column differently), same final composition."""
+    from gnnpn_sc_amd import WOA
+    g = np.random.default_rng(100 + T)
+    problems = _random_problems(g, T, n)
+    seeds = [5000 + 7 * p + T for p in range(n)]
+    got = WOA.fine_tune(problems, popSize=pop, MAX_Iter=iters, seeds=seeds, device=dev)
+    _assert_run_equals_oracle(got, problems, seeds, pop, iters)
+
+
+def test_eswoa_wide_equals_the_lane_per_category_form(dev):
+    """Where both kernels apply (T <= 64) they produce the same run, and the reference's golden runs hold for the wide one."""
+    from gnnpn_sc_amd import WOA
+    g = np.random.default_rng(9)
+    for T in (1, 7, 8, 33, 64):
+        problems = _random_problems(g, T, 5)
+        seeds = [77 + p for p in range(5)]
+        a = WOA.fine_tune(problems, popSize=20, MAX_Iter=25, seeds=seeds, device=dev)
+        b = WOA.fine_tune(problems, popSize=20, MAX_Iter=25, seeds=seeds, device=dev, wide=True)
+        assert a == b, T
+    for c in _cases():
+        got = WOA.fine_tune([([[tuple(s) for s in cat] for cat in c["services"]], c["constraints"], copy.deepcopy(c["solution"]))],
+                            popSize=c["pop_size"], MAX_Iter=c["max_iter"], seeds=[c["seed"]], device=dev, wide=True)[0]
+        assert got["bestFitness"] == c["expected"]["best_fitness"], c["name"]
+        assert got["bestFitnesses"] == c["expected"]["history"], c["name"]
+        assert [int(v) for v in got["bestPops"]] == c["expected"]["best_pos"], c["name"]
+
+
 def test_eswoa_rejects_what_it_does_not_implement(dev):
     from gnnpn_sc_amd import WOA, ops
-    services = [[(0.5, 0.5, 0.95, 0.95)] for _ in range(65)]
-    with pytest.raises(ops.GnnpnError):                       # more categories than lanes
+    services = [[(0.5, 0.5, 0.95, 0.95)] for _ in range(7000)]
+    with pytest.raises(ops.GnnpnError):                       # three float64 columns of 7000 categories exceed a CU's LDS
         WOA.fine_tune([(services, [[[0.0, 1.0]], [[0.0, 1.0]]], None)], popSize=4, MAX_Iter=2, seeds=[1], device=dev)
     with pytest.raises(ops.GnnpnError):                       # two pairs for one product constraint
         WOA.fine_tune([(services[:3], [[[0.0, 1.0], [0.1, 1.0]], [[0.0, 1.0]]], None)], popSize=4, MAX_Iter=2, seeds=[1], device=dev)

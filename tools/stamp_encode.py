@@ -3,7 +3,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnpn_sc_amd import ops
 dev = torch.device("cuda:0")
-B, L, H = 256, 235, 256
+B, L, H = int(os.environ.get("SE_B", 256)), int(os.environ.get("SE_L", 235)), 256
 g = torch.Generator().manual_seed(0)
 x = torch.rand(B, L, 8, generator=g).to(dev)
 nets = []
@@ -16,6 +16,12 @@ names = ["input copy + hand-off sweep + LDS fill", "barrier", "prefetch issue + 
          "cell update + publish", None, "(of the MFMA phase: prefetch issue + flush)"]
 for prec in ("f32", "split"):
     for _ in range(3): ops.lstm_encode(nets, precision=prec)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): ops.lstm_encode(nets, precision=prec)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(prec, f"B={B} L={L}: {ms:.3f} ms per launch (production build), {ms / L * 1e3:.3f} us per step", flush=True)
     ops.set_option("lstm_ablate", 32)
     ops.lstm_encode(nets, precision=prec); torch.cuda.synchronize()
     ws = ops.workspaces(dev).encode()
