@@ -592,7 +592,7 @@ def main():
                      "identical_decisions": round(float(same.float().mean()), 5),
                      "mean_abs_R_diff": round(float((ref["R"] - r32["R"]).abs().mean()), 6)}
     if runner is not None:
-        for s in range(n_slots):
+        for s in range(runner.n_slots):
             o = runner.graphs[s].outputs
             rj = pipe.run(svc, batches[last[(id(runner), s)]], decode_impl=decode_impl)
             if not (torch.equal(o["idx_high"], rj["idx_high"]) and torch.equal(o["R"], rj["R"])):
@@ -720,8 +720,10 @@ def main():
         "data": "synthetic", "timing": timing,
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
                    "resident_batches": len(batches),
-                   "launch": (f"{'hipGraph replay' if args.graph else 'eager'}, {n_slots} independent step(s) "
-                              f"in flight on separate HIP streams"),
+                   "launch": ("eager, one stream" if runner is None else
+                              "hipGraph replay, one step in flight, its recurrent part as two half-batches side by side on two HIP "
+                              "streams (cooperative launches paired on every CU)" if runner.halves else
+                              f"hipGraph replay, {runner.n_slots} independent step(s) in flight on separate HIP streams"),
                    "kernel_timing": ("HIP events in a separate single-stream pass" if args.graph else
                                      "HIP events inside the timed region (durations include overlap with the "
                                      "other in-flight step)"),

@@ -90,6 +90,7 @@ class ML2PNPipeline:
         self.net, self.low, self.high, self.n_per = net, low, high, n_per
         self.precision = precision       # "f16": opt-in fp16-operand encoder (not parity-exact)
         self.cache_service_embedding = True   # False: re-evaluate the GCN branch in every pass (round-1 behaviour)
+        self._side_streams = {}
 
     @torch.no_grad()
     def service_embedding(self, services):
@@ -118,11 +119,35 @@ class ML2PNPipeline:
 
     @torch.no_grad()
     def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None):
-        """One pass.  decode_impl / lds_kb / ws: launch options of the recurrent kernels (modelPN.two_level_greedy)."""
+        """One pass.  decode_impl / lds_kb / ws: launch options of the recurrent kernels (modelPN.two_level_greedy).
+        ``ws`` = a PAIR of workspaces: the recurrent part runs as two half-batches side by side, the second on a side
+        stream (fork / join, capturable) — the problems are independent, and two cooperative launches of one workgroup
+        per CU each share every CU for their whole length (encoder beside encoder, decoder beside decoder), which two
+        whole batches in flight on two slots do only where their timelines happen to line up."""
         scores = self.scores(services, batch)
         rows, ids = self.candidates(services, batch, scores)
-        out = two_level_greedy(self.low, self.high, rows, precision=self.precision, decode_impl=decode_impl,
-                               lds_kb=lds_kb, ws=ws)
+        if isinstance(ws, (tuple, list)):
+            B = rows.shape[0]
+            half = ((B + 31) // 32) * 16                      # whole tiles of 16 problems to either side
+            if len(ws) != 2 or not 0 < half < B:
+                raise ops.GnnpnError(f"ML2PNPipeline.run: two half-batches need 2 workspaces and more than 16 problems (got {len(ws)}, {B})")
+            cur = torch.cuda.current_stream(rows.device)
+            side = self._side_streams.get(rows.device)
+            if side is None:
+                side = self._side_streams[rows.device] = torch.cuda.Stream(rows.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out_b = two_level_greedy(self.low, self.high, rows[half:], precision=self.precision, decode_impl=decode_impl,
+                                         lds_kb=lds_kb, ws=ws[1])
+            out_a = two_level_greedy(self.low, self.high, rows[:half], precision=self.precision, decode_impl=decode_impl,
+                                     lds_kb=lds_kb, ws=ws[0])
+            cur.wait_stream(side)
+            for v in out_b.values():
+                v.record_stream(cur)
+            out = {k: torch.cat([out_a[k], out_b[k]]) for k in out_a}
+        else:
+            out = two_level_greedy(self.low, self.high, rows, precision=self.precision, decode_impl=decode_impl,
+                                   lds_kb=lds_kb, ws=ws)
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
@@ -134,6 +159,7 @@ class ML2PNPipeline:
         at the same time on different streams (independent batches pipelined); it is frozen — the graph
         holds its addresses — and lives as long as the returned callable."""
         ws = ops.new_workspaces(batch.x.device) if ws is None else ws
+        all_ws = list(ws) if isinstance(ws, (tuple, list)) else [ws]
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
@@ -144,7 +170,8 @@ class ML2PNPipeline:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.run(services, batch, decode_impl, lds_kb, ws)
-        ws.frozen = True
+        for w in all_ws:
+            w.frozen = True
 
         def replay():
             graph.replay()
@@ -178,13 +205,23 @@ class PipelinedRunner:
     tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
     """
 
-    def __init__(self, pipe, services, example_batch, slots=2):
-        self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
+    def __init__(self, pipe, services, example_batch, slots=2, halves=None):
+        # Batches of 512 problems and more: ONE batch in flight, its recurrent part as two half-batches side by side
+        # (ML2PNPipeline.run with a pair of workspaces).  A cooperative launch has one workgroup per CU and two of them
+        # fill a CU's registers, so nothing else runs beside a co-resident pair; with two WHOLE batches in flight on two
+        # slots the pairing is left to chance — one slot's front half waits for the other's 25 ms encoder, encoders meet
+        # decoders — and the 1000-task shape ran 28.3 ms per batch where its recurrent kernels, always paired, need 21.1
+        # (tools/bench_slot_parts.py).  Below 512 problems a half-batch launch no longer fills the chip: two slots.
+        n = example_batch.n_problems
+        self.halves = bool(halves) if halves is not None else (n >= 512 and int(slots) > 1 and
+                                                               os.environ.get("GNNPN_PIPE_HALVES", "1") != "0")
+        self.pipe, self.services, self.n_slots = pipe, services, (1 if self.halves else max(1, int(slots)))
         self.streams = [torch.cuda.Stream() for _ in range(self.n_slots)]
         # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
         # 228 k vs 221 k problems/s in fp32, 353 k vs 316 k with the split precision.
         shared = 4
-        self.decode_impl = int(os.environ.get("GNNPN_PIPE_DECODE_IMPL", shared if self.n_slots > 1 else 0))
+        paired = self.n_slots > 1 or self.halves      # two cooperative launches share every CU
+        self.decode_impl = int(os.environ.get("GNNPN_PIPE_DECODE_IMPL", shared if paired else 0))
         # Placement: the cooperative kernels claim one CU per workgroup at run time (csrc/coop_common.h, coop_place), so
         # the two slots' launches share every CU one workgroup each whatever the dispatcher does; the LDS-footprint
         # padding round 1 steered the dispatcher with (100 / 56 KB) is no longer needed and stays as an option only.
@@ -196,13 +233,26 @@ class PipelinedRunner:
         # cooperative launch of a multi-slot runner is therefore padded to ONE footprint, 78 KB: any freed range fits any
         # waiting workgroup.  (f32: 19 / 27 KB — nothing to equalise.)
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
-        equal = 78 if (getattr(pipe, "precision", "f32") == "split" and self.n_slots > 1) else 0
+        equal = 78 if (getattr(pipe, "precision", "f32") == "split" and paired) else 0
         self.lds_kb = [int(v) for v in env.split(",")] if env else [equal] * self.n_slots
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
-        self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(self.n_slots)]
+        self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=self.workspaces[s]) for s in range(self.n_slots)]
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s])
+                       for s in range(self.n_slots)]
         self.count = 0
+        # Two slots, long recurrent kernels: start the two replays of a pair TOGETHER (slot 1 waits for the start of slot 0's
+        # replay, slot 0's next replay for the end of slot 1's).  Free-running slots drift apart by the difference of their
+        # step times; a cooperative launch that arrives while the other slot is between two of its launches finds some CUs
+        # full for longer than its reserve's 2 ms, seats workgroups off their canonical CUs, and from there on both slots'
+        # launches run at the speed of one — the 2000-task shape then alternated between 41 and 62 ms per step (spread 37-48 %
+        # over rounds; tools/slot_overlap.py shows the seats).  A pair started together is in the position of the first pair
+        # after a synchronisation, which never showed it.  The wait costs the tail by which the two replays differ (2 % at
+        # that shape); short steps (QWS, Normal) keep running free.
+        env = os.environ.get("GNNPN_PIPE_LOCKSTEP")
+        long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
+        self.lockstep = self.n_slots == 2 and (env == "1" or (env is None and long_steps))
+        self._open_leader, self._last_done = None, [None, None]
 
     @staticmethod
     def _clone(b):
@@ -228,7 +278,28 @@ class PipelinedRunner:
                     if a.shape != b.shape:
                         raise ops.GnnpnError(f"PipelinedRunner: batch shape {tuple(b.shape)} != captured {tuple(a.shape)}")
                     a.copy_(b, non_blocking=True)
+            leader = False
+            if self.lockstep:
+                # A submission joins the leader that is waiting for a partner (and starts with it) if that leader has not
+                # finished yet — the host runs ahead of the device, so back-to-back submissions always pair —; otherwise it
+                # leads a new pair, behind whatever the other slot ran last.
+                st, lead = self.streams[s], self._open_leader
+                if lead is not None and lead[0] != s and not lead[2].query():
+                    st.wait_event(lead[1])
+                    self._open_leader = None
+                else:
+                    leader = True
+                    if self._last_done[1 - s] is not None:
+                        st.wait_event(self._last_done[1 - s])
+                    started = torch.cuda.Event()
+                    started.record(st)
             out = self.graphs[s]()
+            if self.lockstep:
+                done = torch.cuda.Event()
+                done.record(self.streams[s])
+                self._last_done[s] = done
+                if leader:
+                    self._open_leader = (s, started, done)
         return out, s
 
     def stream(self, slot):
@@ -236,7 +307,7 @@ class PipelinedRunner:
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
-        return self.pipe.run(self.services, self.batches[slot], decode_impl=self.decode_impl)
+        return self.pipe.run(self.services, self.batches[slot], decode_impl=self.decode_impl)   # one launch per kernel, whole batch
 
     def synchronize(self, check=True):
         """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a

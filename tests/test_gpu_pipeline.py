@@ -253,6 +253,41 @@ def test_pipelined_runner_matches_single_stream(dev):
         runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
 
 
+@pytest.mark.parametrize("B,precision", [(88, "f32"), (88, "split"), (50, "split"), (33, "f32")])
+def test_half_batches_side_by_side_match_the_whole_batch(dev, B, precision):
+    """The runner's form for batches of 512 problems and more — the recurrent part as two half-batches on two streams,
+    private workspaces, joined before the reward — forced on at small sizes (whole tiles, a ragged last tile, a second half
+    of one ragged tile): graph replays give, batch by batch, the bits of the plain one-stream run of the whole batch."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K = 47, 940, 5
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K, precision=precision)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=20 + i, tasks_per_problem=10), dev)
+               for i in range(3)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2, halves=True)
+    assert runner.halves and runner.n_slots == 1 and len(runner.workspaces) == 2
+    keys = ("idx_low", "idx_high", "R", "actions", "action_probs", "win_low", "win_high_raw", "candidate_ids")
+    got = []
+    for b in batches:
+        out, slot = runner.submit(b)
+        with torch.cuda.stream(runner.stream(slot)):
+            got.append({k: out[k].clone() for k in keys})
+    runner.synchronize(check=True)
+    ops.check_status(dev)
+    for b, g in zip(batches, got):
+        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)
+        for k in keys:
+            assert g[k].shape == ref[k].shape and torch.equal(g[k], ref[k]), k
+    with pytest.raises(ops.GnnpnError):                     # nothing to put on the second stream
+        pipe.run(svc, DeviceBatch.from_problems(synth.make_problem_batch(table, 16, seed=3, tasks_per_problem=10), dev),
+                 ws=(ops.new_workspaces(dev), ops.new_workspaces(dev)))
+
+
 def test_all_gather_indices_rccl_world1(dev):
     """The one collective of the path on its real backend (backend "nccl" is RCCL on ROCm), world size 1: the equal-shard
     and the ragged form of dist.all_gather_indices on device tensors.  (World 2 runs on CPU with gloo, test_host_logic.)"""
@@ -406,7 +441,8 @@ def test_two_slots_beside_long_ordinary_kernels(dev):
     pipe = ML2PNPipeline(net, low, high, K)
     svc = DeviceServices.from_table(table, dev)
     batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=4, tasks_per_problem=T), dev)
-    runner = PipelinedRunner(pipe, svc, batch, slots=2)
+    runner = PipelinedRunner(pipe, svc, batch, slots=2, halves=False)      # two whole batches in flight (the default at this size pairs half-batches)
+    assert runner.n_slots == 2 and runner.lockstep                       # 5000 recurrent steps: pairs start together
     ref = pipe.run(svc, batch, decode_impl=runner.decode_impl)
     for _ in range(24):
         runner.submit()
