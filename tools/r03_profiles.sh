@@ -21,6 +21,13 @@ GNNPN_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 4 --batch 64 --steps 
 timeout 300 python tools/bench_aggregate.py > $O/aggregate.jsonl 2> /dev/null
 timeout 300 python tools/bench_slot_parts.py > $O/slot_parts_qws.txt 2>&1
 timeout 120 python tools/stamp_decode.py > $O/stamps_decode.txt 2>&1
+timeout 100 python tools/stamp_encode.py > $O/stamps_encode.txt 2>&1
+timeout 200 python tools/bench_slot_parts.py --workload synth4 --iters 4 > $O/slot_parts_synth4.txt 2>&1
+timeout 120 python tools/split_encode.py > $O/split_encode_qws.txt 2>&1
+SE_T=1000 SE_B=32 timeout 200 python tools/split_encode.py > $O/split_encode_t1000.txt 2>&1
+GNNPN_PIPE_LOCKSTEP=0 timeout 100 python tools/slot_overlap.py --rounds 8 > $O/slot_overlap_synth5_free.txt 2>&1
+timeout 100 python tools/slot_overlap.py --rounds 6 > $O/slot_overlap_synth5_paired.txt 2>&1
+timeout 60 ./tools/probes/mfma_chain_rate > $O/mfma_chain_rate.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 SOLO="--min-time 0 --no-cpu-baseline --no-kernel-timers --no-other-precision --graph 0 --inflight 1"

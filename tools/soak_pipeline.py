@@ -1,5 +1,6 @@
 """Soak test of the two-slot pipeline: N steps with a different batch every step, every output compared with a
-single-stream run of the same batch (bit for bit), hand-off status checked at the end.  Usage: soak_pipeline.py [N] [precision]"""
+single-stream run of the same batch (bit for bit), hand-off status checked at the end.
+Usage: soak_pipeline.py [N] [precision] [workload] [batch]   (batches of 512 and more exercise the half-batch pairing)"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnpn_sc_amd import ops, synth
@@ -8,7 +9,9 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
 dev = torch.device("cuda:0")
-w = bench.WORKLOADS["qws"]
+w = dict(bench.WORKLOADS[sys.argv[3] if len(sys.argv) > 3 else "qws"])
+if len(sys.argv) > 4:
+    w["B"] = int(sys.argv[4])
 table = synth.make_service_table(w["T"], w["S"], seed=0, degree=32)
 net, low, high = bench.build_models(w["T"], w["S"], w["K"], dev, w["n_gcn"])
 pipe = ML2PNPipeline(net, low, high, w["K"], precision=prec)
@@ -28,7 +31,7 @@ for i in range(N):
     ev = torch.cuda.Event(); ev.record(runner.stream(s))
     snap = None
     pending.append((i, s, v, ev, out))
-    if len(pending) == 2:                             # check the older step before its slot is reused
+    if len(pending) == runner.n_slots:                # check the oldest step before its slot is reused
         j, sj, vj, evj, oj = pending.pop(0)
         evj.synchronize()
         for k in keys:
