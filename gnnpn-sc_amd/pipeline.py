@@ -83,6 +83,13 @@ class DeviceBatch:
                            self.global_bounds[lo:hi].contiguous(), self.max_nodes)
 
 
+def half_batch_split(n_problems):
+    """Where a batch is cut for the two half-batches that run side by side: whole tiles of 16 problems to the first half,
+    the (possibly ragged) rest to the second; 0 when there is nothing to put on the second stream."""
+    half = ((int(n_problems) + 31) // 32) * 16
+    return half if 0 < half < n_problems else 0
+
+
 class ML2PNPipeline:
     """net: modelML.Net; low/high: modelPN.CombinatorialRL (levels "Low"/"High")."""
 
@@ -128,8 +135,8 @@ class ML2PNPipeline:
         rows, ids = self.candidates(services, batch, scores)
         if isinstance(ws, (tuple, list)):
             B = rows.shape[0]
-            half = ((B + 31) // 32) * 16                      # whole tiles of 16 problems to either side
-            if len(ws) != 2 or not 0 < half < B:
+            half = half_batch_split(B)
+            if len(ws) != 2 or not half:
                 raise ops.GnnpnError(f"ML2PNPipeline.run: two half-batches need 2 workspaces and more than 16 problems (got {len(ws)}, {B})")
             cur = torch.cuda.current_stream(rows.device)
             side = self._side_streams.get(rows.device)

@@ -377,3 +377,15 @@ def test_bench_strong_scaling_partition_is_the_same_global_set():
     assert not np.array_equal(whole[0].local_bounds, whole[1].local_bounds)       # resident batches differ
     b0 = whole[0]
     assert b0.batch.max() == 31 and b0.edge_index.max() == b0.x.shape[0] - 1       # offsets of the merged chunks
+
+
+def test_half_batch_split_keeps_whole_tiles_in_the_first_half():
+    """pipeline.half_batch_split: the cut the paired half-batches use (tiles of 16 problems never straddle it; both halves
+    non-empty; the halves differ by at most one tile)."""
+    from gnnpn_sc_amd.pipeline import half_batch_split
+    assert [half_batch_split(b) for b in (0, 1, 16)] == [0, 0, 0]
+    for b in list(range(17, 200)) + [256, 512, 520, 528, 1024, 4096, 4097]:
+        h = half_batch_split(b)
+        assert 0 < h < b and h % 16 == 0, (b, h)
+        assert abs(h - (b - h)) <= 16 + 15, (b, h)
+        assert -(-h // 16) + -(-(b - h) // 16) == -(-b // 16), (b, h)     # no extra tile
