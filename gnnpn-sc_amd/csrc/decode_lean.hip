@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                 // ---- (2) W_hh.h (the folded input side follows the pick, below).  Half-way through, the first pass over the
                 // partial dots of publish #(step-1) is requested: they were published a hand-off time ago, and the loads' own
                 // round trip (~700 cycles) then lies under the second half of the products instead of behind them.
-                constexpr bool EARLY_P = OCC == 1;
+                constexpr bool EARLY_P = OCC == 1 || !SPLIT;   // the two-per-CU exact-split builds have no 18 registers to spare across the second half
                 auto request_p = [&]() {
                     if (EARLY_P && k > 0) {
                         const unsigned so_p = par * (XP_GRANULES * 8) + wave * (4 * KW * G * 8);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
                 for (unsigned spins = 0; spins <= SPIN_LIMIT; ++spins) {
                     // pass 0 looks at what (2) requested half-way through the products (k == T: nothing was requested);
                     // every further pass loads again
-                    if (spins > 0 || k == T || OCC != 1) {
+                    if (spins > 0 || k == T || (OCC != 1 && SPLIT)) {
                         unsigned so_p = so_p0, so_l = so_l0;
                         asm volatile("" : "+s"(so_p), "+s"(so_l));
 #pragma unroll
