@@ -503,7 +503,9 @@ def main():
     # separate eager pass on one stream right after the timed region; --graph 0 (eager, one stream)
     # records them inside the timed region instead.
     n_slots = max(1, args.inflight) if args.graph else 1
-    runner = PipelinedRunner(pipe, svc, batch, slots=n_slots) if args.graph else None
+    if share:       # ranks sharing ONE GPU (launch-path rehearsal): a CU holds two cooperative workgroups in all, so every rank
+        n_slots = 1  # runs one launch at a time — four launches of two processes would wait on each other past the spin bound
+    runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
     last = {}                                                   # slot -> index of the batch its outputs belong to
     gathers = {}                                                # (runner, slot) -> (gathered tensor, pending work)
 
@@ -646,7 +648,7 @@ def main():
                           "products per term (every cross term >= 2^-24 kept), fp32 accumulate; rest f32"}
     if other and args.graph and not args.no_split_line:
         pipe_s = ML2PNPipeline(net, low, high, K, precision=other)
-        runner_s = PipelinedRunner(pipe_s, svc, batch, slots=n_slots)
+        runner_s = PipelinedRunner(pipe_s, svc, batch, slots=n_slots, halves=False if share else None)
         gc.collect()
         gc.disable()
         for i in range(args.warmup):
