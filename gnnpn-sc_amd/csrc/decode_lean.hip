@@ -498,9 +498,19 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
 // pick_prob[b][t] = softmax of the step's window logits (+ the latent logits) at the pick = 1 / sum_j exp(v_j - v_pick):
 // the normaliser the decode kernel no longer forms per step (modelPN.py:224-226, 297-299 gather exactly this).  16 lanes
 // per (problem, step), the exponentials summed by the DPP rotations 8, 4, 2, 1 — the order decode_coop.hip uses in lane 0.
-__global__ __launch_bounds__(256) void pick_prob_kernel(const float* __restrict__ win, const float* __restrict__ lat,
-                                                       const int32_t* __restrict__ idx, float* __restrict__ out, int64_t rows,
-                                                       int T, int K) {
+struct PickProbArgs {
+    const float* win[2];
+    const float* lat[2];
+    const int32_t* idx[2];
+    float* out[2];
+};
+// blockIdx.y = net: both nets' normalisers in ONE launch
+__global__ __launch_bounds__(256) void pick_prob_kernel(PickProbArgs a, int64_t rows, int T, int K) {
+    const int net = blockIdx.y;
+    const float* __restrict__ win = a.win[net];
+    const float* __restrict__ lat = a.lat[net];
+    const int32_t* __restrict__ idx = a.idx[net];
+    float* __restrict__ out = a.out[net];
     const int64_t row = blockIdx.x * 16ll + (threadIdx.x >> 4);
     const int r = threadIdx.x & 15, lane = threadIdx.x & 63;
     const bool live = r < K && row < rows;
@@ -584,11 +594,17 @@ int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, 
     if (hipGetLastError() != hipSuccess) GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: launch of the cooperative kernel failed");
     // the softmax normaliser at the picks, from the stored window logits (Low's are the High net's latent logits)
     const int64_t rows = (int64_t)args.B * args.T;
-    for (int n = 0; n < n_nets; ++n) {
-        const DecodeNet& d = args.net[n];
-        const float* lat = d.latent_from >= 0 ? args.net[d.latent_from].win_logits : d.latent_win;
-        hipLaunchKernelGGL(pick_prob_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, d.win_logits, lat, d.idx, d.pick_prob,
-                           rows, args.T, args.K);
+    for (int n0 = 0; n0 < n_nets; n0 += 2) {
+        PickProbArgs pa = {};
+        const int cnt = n_nets - n0 < 2 ? n_nets - n0 : 2;
+        for (int n = 0; n < cnt; ++n) {
+            const DecodeNet& d = args.net[n0 + n];
+            pa.win[n] = d.win_logits;
+            pa.lat[n] = d.latent_from >= 0 ? args.net[d.latent_from].win_logits : d.latent_win;
+            pa.idx[n] = d.idx;
+            pa.out[n] = d.pick_prob;
+        }
+        hipLaunchKernelGGL(pick_prob_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)cnt), dim3(256), 0, s, pa, rows, args.T, args.K);
     }
     return GNNPN_OK;
 }
