@@ -151,6 +151,7 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
 // construction and no CU holds two members of a launch.  Two such launches on two streams then share every CU one
 // workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
 constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD seat counters, [1152,1184) arrivals, [2048,10240) CU claims
+constexpr unsigned COOP_LDS_UNITS = 640;    // a CU's 160 KB of LDS in the 256-byte units of HW_REG_LDS_ALLOC
 constexpr int COOP_XCDCNT_OFFSET = 1024;
 constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;
@@ -251,7 +252,25 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
                 const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
                 const unsigned prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);
-                if (prev == 0u) {                                // the first workgroup of this launch on this CU
+                // Where in the CU's LDS did the dispatcher put this workgroup?  LDS is handed out in contiguous ranges, and a
+                // workgroup that lands ABOVE a short-lived neighbour (an ordinary kernel's few KB) stays there when the neighbour
+                // has gone: a 78 KB footprint at, say, [25 KB, 103 KB) leaves two holes of 25 and 57 KB, and the partner launch's
+                // workgroup for this CU — same footprint — cannot be placed until this whole kernel has finished.  Two launches
+                // that start together can each hold a few CUs that way: both stay under-staffed, both wait, and the bounded spins
+                // end it 0.46 s later (seen: two slots started together at the 1000- and 2000-task shapes, 10 % of the steps;
+                // failure record: 33 of 96 workgroups of an XCD dispatched, 29 of 32 seats).  HW_REG_LDS_ALLOC holds base [11:0]
+                // and size [23:12] of the allocation in 256-byte units (tools/probes/lds_alloc_probe.hip).  An early arrival that
+                // would fragment the CU gives the seat back and leaves at once — a later one finds the neighbour gone and
+                // starts at 0; the reserve (the last arrivals) takes the seat wherever it is, so staffing still always completes.
+                const unsigned la = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));     // HW_REG_LDS_ALLOC
+                const unsigned lds_base = la & 0xfffu, lds_size = (la >> 12) & 0xfffu;
+                const bool fragments = lds_base != 0u && lds_base < lds_size && lds_base + 2u * lds_size > COOP_LDS_UNITS;
+                const bool reserve_arrival = arrival + target >= gridDim.x / 8;
+                if (prev == 0u && fragments && !reserve_arrival) {
+                    atomicSub(status + COOP_CLAIM_OFFSET / 4 + key, 1u);   // the next arrival on this CU is "first" again
+                    atomicAdd(status + 3, 1u);                                // statistics: seats declined for their LDS position
+                    g = -2;                                                   // leave without holding the slot
+                } else if (prev == 0u) {                         // the first workgroup of this launch on this CU
                     // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch)
                     unsigned s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (s == 0u) {
@@ -275,7 +294,9 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
             g = __shfl(g, 0, 64);
             m = __shfl(m, 0, 64);
             arrival = __shfl(arrival, 0, 64);
-            if (g < 0) {                                         // surplus (see above)
+            if (g == -2) {                                       // declined its seat: the slot (and its LDS range) is freed at once
+                g = -1;
+            } else if (g < 0) {                                  // surplus (see above)
                 const unsigned per_xcd = gridDim.x / 8;
                 const bool reserve = arrival + target >= per_xcd;
                 const unsigned long long patience = reserve ? COOP_RESERVE_WAIT_TICKS : COOP_SURPLUS_WAIT_TICKS;

@@ -21,6 +21,7 @@
 #include "recurrent.h"
 #include "lstm_shared.h"
 #include "coop_common.h"
+#include "decode_shared.h"   // gnnpn_decode_diag_buffer: the failure record both recurrent kernels write
 
 namespace {
 constexpr int H = 256;
@@ -100,7 +101,8 @@ template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, unsigned* __restrict__ sticky,
                                                                   int32_t B, int32_t L, int n_nets, int groups_per_net,
-                                                                  int gpx, int ablate_arg, unsigned* __restrict__ seats) {
+                                                                  int gpx, int ablate_arg, unsigned* __restrict__ seats,
+                                                                  unsigned* __restrict__ diag) {
     const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
     constexpr int HS_FLOATS = PREC == 2 ? 3 * SPLIT_TILE / 2 : ROWS * LDH16;
@@ -223,6 +225,26 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                 ok = sweep_quarter<PREC>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true, ablate & 4);
             }
             if (!ok) abort_flag = 1;
+            if constexpr (DIAG) {   // failure record of the diagnostic build (shared with the decoder's, gnnpn_decode_diag; p_missing =
+                if (!ok && lane == 0 && diag) {   // 0xE0C marks an encoder entry): seats taken and workgroups ARRIVED per XCD so far
+                    const unsigned n = atomicAdd(diag, 1u);
+                    if (n < 31) {
+                        unsigned* rec = diag + 16 * (n + 1);
+                        const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
+                        const unsigned* arr = err + COOP_ARRIVE_OFFSET / 4;
+                        unsigned c0 = 0, c1 = 0, a0 = 0, a1 = 0;
+                        for (int x = 0; x < 4; ++x) {
+                            c0 |= (cnt[x] & 0xffu) << (8 * x);
+                            c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
+                            a0 |= (arr[x] & 0xffu) << (8 * x);
+                            a1 |= (arr[4 + x] & 0xffu) << (8 * x);
+                        }
+                        rec[0] = group; rec[1] = member; rec[2] = tile; rec[3] = t; rec[4] = wave; rec[5] = step;
+                        rec[6] = 0; rec[7] = 0xE0Cu; rec[8] = 0; rec[9] = c0; rec[10] = c1; rec[11] = a0; rec[12] = a1;
+                        rec[13] = gpx; rec[14] = blockIdx.x; rec[15] = err[0];
+                    }
+                }
+            }
             if (stamps) s1 = phase_stamp();
             __syncthreads();
             if (abort_flag) break;
@@ -588,10 +610,11 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;
+    static unsigned* p_diag = gnnpn_decode_diag_buffer();   // failure record (diagnostic build, timed-out sweep only)
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(COOP_OVERSUB * groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
-                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl, p_seats)
+                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl, p_seats, p_diag)
     if ((abl & ~128) != 0) {   // diagnostic build (folded form; fp32 with every switch, exact split with the phase stamps)
         if (prec == 1 || pre || (prec == 2 && (abl & ~(128 | 32)) != 0))
             GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the folded form (fp32: all switches; split: stamps only)");

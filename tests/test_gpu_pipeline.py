@@ -452,6 +452,40 @@ def test_two_slots_beside_long_ordinary_kernels(dev):
         assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
 
 
+def test_two_slots_started_together_with_long_recurrences(dev):
+    """256 problems x 5000 recurrent steps, exact split (78 KB of LDS per cooperative workgroup), two slots whose replays
+    start together while the host consumes every result in between.  Before coop_place looked at WHERE in the CU's LDS a
+    workgroup had been put, a workgroup that landed above a short-lived neighbour of the other slot's front half kept its
+    78 KB in the middle of the CU, the partner launch's workgroup for that CU could not be placed, both launches stayed
+    under-staffed and one step in ten ended in a hand-off time-out (wrong picks, status 0x1).  60 steps: every result equal
+    to the single-stream run, no status raised."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 1000, 5000, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K, precision="split")
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=300 + i, tasks_per_problem=T), dev) for i in range(3)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    assert runner.n_slots == 2 and runner.lockstep and not runner.halves
+    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    pending, bad = [], []
+    for i in range(60):
+        out, s = runner.submit(batches[i % 3])
+        ev = torch.cuda.Event()
+        ev.record(runner.stream(s))
+        pending.append((i, ev, out))
+        if len(pending) == 2:
+            j, evj, oj = pending.pop(0)
+            evj.synchronize()
+            if not all(torch.equal(oj[k], refs[j % 3][k]) for k in ("idx_low", "idx_high", "R")):
+                bad.append(j)
+    runner.synchronize(check=True)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("precision", ["f32", "split"])
 def test_soak_two_slots(dev, precision):
     """2,000 pipelined steps, a different batch every step, eager work on the default stream in between (what recycled the

@@ -37,13 +37,18 @@ for i in range(N):
         for k in keys:
             if not torch.equal(oj[k], refs[vj][k]):
                 bad += 1
-                print(f"step {j} slot {sj} batch {vj}: {k} differs ({int((oj[k] != refs[vj][k]).sum())} elements)")
+                wsj = runner.workspaces[sj if not runner.halves else 0]
+                print(f"step {j} slot {sj} batch {vj}: {k} differs ({int((oj[k] != refs[vj][k]).sum())} elements); status areas of the slot's last launches "
+                      f"[error word, same-XCD workgroups, off-canonical seats, -]: enc {wsj.encode()[:16].view(torch.int32).tolist()} "
+                      f"dec {wsj._decode[:16].view(torch.int32).tolist()}; sticky {[int(x.status[0]) for x in runner.workspaces]}", flush=True)
                 break
 for j, sj, vj, evj, oj in pending:
     evj.synchronize()
     for k in keys:
         if not torch.equal(oj[k], refs[vj][k]):
             bad += 1; print(f"step {j}: {k} differs"); break
+if bad:
+    print("failure record (first entries):", ops.decode_failure_record(clear=False))
 ops.check_status(dev)
 print(f"{N} steps ({prec}), {bad} mismatching, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
