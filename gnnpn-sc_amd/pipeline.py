@@ -201,7 +201,9 @@ class ML2PNPipeline:
 
 
 class PipelinedRunner:
-    """Throughput mode: ``slots`` independent batches in flight on ``slots`` HIP streams.
+    """Throughput mode: ``slots`` independent batches in flight on ``slots`` HIP streams — or, for batches of 512 problems
+    and more, ONE batch in flight whose recurrent part runs as two half-batches side by side (``halves``); two slots with
+    recurrences of 2000 steps and more start their replays in pairs (``lockstep``).  See __init__.
 
     The recurrent kernels are step-latency-bound and leave most of the machine idle, so consecutive
     (independent) batches are overlapped: every slot owns one captured HIP graph of the whole pass, its
@@ -248,14 +250,14 @@ class PipelinedRunner:
                                     ws=tuple(self.workspaces) if self.halves else self.workspaces[s])
                        for s in range(self.n_slots)]
         self.count = 0
-        # Two slots, long recurrent kernels: start the two replays of a pair TOGETHER (slot 1 waits for the start of slot 0's
-        # replay, slot 0's next replay for the end of slot 1's).  Free-running slots drift apart by the difference of their
-        # step times; a cooperative launch that arrives while the other slot is between two of its launches finds some CUs
-        # full for longer than its reserve's 2 ms, seats workgroups off their canonical CUs, and from there on both slots'
-        # launches run at the speed of one — the 2000-task shape then alternated between 41 and 62 ms per step (spread 37-48 %
-        # over rounds; tools/slot_overlap.py shows the seats).  A pair started together is in the position of the first pair
-        # after a synchronisation, which never showed it.  The wait costs the tail by which the two replays differ (2 % at
-        # that shape); short steps (QWS, Normal) keep running free.
+        # Two slots, long recurrent kernels: start the two replays of a pair TOGETHER (a submission joins the leader that is
+        # still waiting for a partner, else it leads).  Free-running slots drift apart by the difference of their step
+        # times, and a cooperative launch that starts under the OTHER slot's front half finds every CU's LDS occupied by
+        # short-lived neighbours: its workgroups land above them (coop_place gives such seats back, up to a few hundred times
+        # per launch), seats are taken off their canonical CUs, and from there on both slots' launches run at the speed of
+        # one — the 2000-task shape alternated between 41 and 62 ms per step (spread 37-48 % over rounds; tools/slot_overlap.py).
+        # Started together, the two front halves run side by side and are gone when the encoders arrive.  The wait costs the
+        # tail by which the two replays differ (2 % at that shape); short steps (QWS, Normal) keep running free.
         env = os.environ.get("GNNPN_PIPE_LOCKSTEP")
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
         self.lockstep = self.n_slots == 2 and (env == "1" or (env is None and long_steps))
