@@ -38,6 +38,7 @@ _SIGNATURES = {
     "gnnpn_lstm_encode_workspace_bytes": (c_int64, []),
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
+    "gnnpn_coop_reset_staffing": (c_int, []),
     "gnnpn_bn_train_forward_f32": (c_int, [_P, c_int64, c_int32, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "gnnpn_bn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int, _P, _P, _P, _P]),
     "gnnpn_bce_sigmoid_f32": (c_int, [_P, _P, c_int64, _P, _P, _P]),
@@ -86,7 +87,7 @@ class Attention(ctypes.Structure):
 
 class LaunchOpts(ctypes.Structure):
     """gnnpn_launch_opts_t of include/gnnpn_hip.h (per-call implementation choice / placement / sticky status)."""
-    _fields_ = [("impl", c_int32), ("lds_kb", c_int32), ("write_through", c_int32), ("reserved", c_int32),
+    _fields_ = [("impl", c_int32), ("lds_kb", c_int32), ("write_through", c_int32), ("paired_start", c_int32),
                 ("sticky_status", _P)]
 
 

@@ -3,6 +3,7 @@
 #include <mutex>
 #include "lstm_shared.h"
 #include "decode_shared.h"
+#include "coop_common.h"
 
 thread_local char g_gnnpn_err[256] = "";
 
@@ -34,6 +35,16 @@ unsigned* gnnpn_cu_seat_table() {
         table[dev] = p;
     }
     return table[dev];
+}
+
+// after a launch that ended in a hand-off time-out without ever being staffed: it never left the count of launches that
+// are staffing (coop_common.h::coop_place), which would make every later launch decline badly placed seats for good
+extern "C" int gnnpn_coop_reset_staffing(void) {
+    unsigned* p = gnnpn_cu_seat_table();
+    if (!p) GNNPN_FAIL(GNNPN_E_LAUNCH, "coop_reset_staffing: no seat table");
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(p + COOP_STAFFING_WORD, 0, sizeof(unsigned)) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "coop_reset_staffing: memset failed");
+    return GNNPN_OK;
 }
 
 extern "C" int gnnpn_set_option(const char* name, int value) {

@@ -152,6 +152,7 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
 // workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
 constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD seat counters, [1152,1184) arrivals, [2048,10240) CU claims
 constexpr unsigned COOP_LDS_UNITS = 640;    // a CU's 160 KB of LDS in the 256-byte units of HW_REG_LDS_ALLOC
+constexpr int COOP_STAFFING_WORD = 8 * 256 + 8;   // in the per-device seat table (api.hip): cooperative launches that are staffing right now
 constexpr int COOP_XCDCNT_OFFSET = 1024;
 constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;
@@ -215,7 +216,9 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 //
 // Workgroup ids go round-robin over the XCDs, so each XCD receives per_xcd = gridDim.x / 8 = COOP_OVERSUB * target
 // workgroups of the launch and needs `target` of them seated.  Every arrival takes an arrival index a (per XCD):
-//   * first workgroup of the launch on its CU, the CU's canonical seat s below `target` -> seated (member s % G of the
+//   * an EARLY arrival (a < per_xcd - target) whose LDS allocation sits where it would leave no contiguous hole for a
+//     second workgroup of the same footprint leaves at once, seat untouched (see the note at HW_REG_LDS_ALLOC below);
+//   * the CU's canonical seat s is below `target` and still open -> seated (one compare-and-swap; member s % G of the
 //     XCD's group s / G);
 //   * otherwise it is surplus, and what it does with its CU slot decides whether the launch gets staffed:
 //     - the early ones (a < per_xcd - target) keep the slot for up to 16 us, or until staffing completes, and exit: while
@@ -230,8 +233,16 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 //   Measured need for the reserve: an ordinary kernel of the other stream whose workgroups fill a CU for longer than
 //   ~50 us (the front end at 5000 candidates x 512 problems) outlasted 64 surplus workgroups of 16 us each, the launch
 //   stayed one or two members short on some XCDs and its groups timed out (tools/repro_synth4.sh, record in DESIGN.md).
+// one lane, right after it has taken a seat: was that the launch's last one?  Then the launch leaves the per-device
+// count of launches that are staffing (status word 4: 0 not started, 1 counted, 2 staffed).
+__device__ __forceinline__ void coop_note_staffed(unsigned* status, const unsigned* count, unsigned target, unsigned* seats) {
+    bool all = true;
+    for (int x = 0; x < 8; ++x) all &= __hip_atomic_load(count + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+    if (all && atomicCAS(status + 4, 1u, 2u) == 1u) atomicSub(seats + COOP_STAFFING_WORD, 1u);
+}
 template <int G>
-__device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats) {
+__device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats,
+                                           bool paired_start = false) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned xcc = xcc_id();
@@ -251,7 +262,10 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 arrival = atomicAdd(arrive + xcc, 1u);
                 const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
                 const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
-                const unsigned prev = atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);
+                atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);      // statistics: workgroups of this launch that reached the CU
+                unsigned* staffing = seats + COOP_STAFFING_WORD;           // per device: launches that have started and are not staffed yet
+                if (atomicCAS(status + 4, 0u, 1u) == 0u) atomicAdd(staffing, 1u);   // this launch's first arrival
+                const bool another_staffing = __hip_atomic_load(staffing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1u;
                 // Where in the CU's LDS did the dispatcher put this workgroup?  LDS is handed out in contiguous ranges, and a
                 // workgroup that lands ABOVE a short-lived neighbour (an ordinary kernel's few KB) stays there when the neighbour
                 // has gone: a 78 KB footprint at, say, [25 KB, 103 KB) leaves two holes of 25 and 57 KB, and the partner launch's
@@ -260,18 +274,28 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 // end it 0.46 s later (seen: two slots started together at the 1000- and 2000-task shapes, 10 % of the steps;
                 // failure record: 33 of 96 workgroups of an XCD dispatched, 29 of 32 seats).  HW_REG_LDS_ALLOC holds base [11:0]
                 // and size [23:12] of the allocation in 256-byte units (tools/probes/lds_alloc_probe.hip).  An early arrival that
-                // would fragment the CU gives the seat back and leaves at once — a later one finds the neighbour gone and
+                // would fragment the CU does not take the seat and leaves at once — a later one finds the neighbour gone and
                 // starts at 0; the reserve (the last arrivals) takes the seat wherever it is, so staffing still always completes.
+                // All of this ONLY while another cooperative launch of the process is staffing too (a per-device count of
+                // launches between their first arrival and their last seat): a badly placed workgroup of the ONLY launch that
+                // is short of members can at worst delay a launch that arrives later — which is complete, runs and ends — and
+                // declining there costs dearly where ordinary kernels hold LDS for long (the RCCL all-gather of the multi-GPU
+                // path: 430 k -> 255-300 k problems/s with unconditional declines).
                 const unsigned la = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));     // HW_REG_LDS_ALLOC
                 const unsigned lds_base = la & 0xfffu, lds_size = (la >> 12) & 0xfffu;
-                const bool fragments = lds_base != 0u && lds_base < lds_size && lds_base + 2u * lds_size > COOP_LDS_UNITS;
+                // strict (every badly placed early arrival leaves) where the caller says that a partner launch starts TOGETHER with
+                // this one (gnnpn_launch_opts_t.paired_start: half-batches, slots started in pairs — nothing but the tails of the
+                // front halves is around then); otherwise only while another launch is staffing at this moment
+                const bool fragments = (paired_start || another_staffing) && lds_base != 0u && lds_base < lds_size &&
+                                       lds_base + 2u * lds_size > COOP_LDS_UNITS;
                 const bool reserve_arrival = arrival + target >= gridDim.x / 8;
-                if (prev == 0u && fragments && !reserve_arrival) {
-                    atomicSub(status + COOP_CLAIM_OFFSET / 4 + key, 1u);   // the next arrival on this CU is "first" again
-                    atomicAdd(status + 3, 1u);                                // statistics: seats declined for their LDS position
-                    g = -2;                                                   // leave without holding the slot
-                } else if (prev == 0u) {                         // the first workgroup of this launch on this CU
-                    // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch)
+                if (fragments && !reserve_arrival) {
+                    atomicAdd(status + 3, 1u);                                // statistics: arrivals that left because of their LDS position
+                    g = -2;                                                   // leave without holding the slot; the seat stays open
+                } else if (!(fragments && paired_start)) {       // (strict: a badly placed RESERVE arrival does not rush for the seat either: it
+                    //                                              waits with the reserve below and takes an open seat only if nobody better placed has)
+                    // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch); whoever of
+                    // this launch gets there first takes it (one compare-and-swap), every later arrival on the CU is surplus
                     unsigned s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (s == 0u) {
                         if (atomicCAS(seats + key, 0u, 0xffffffffu) == 0u) {
@@ -288,6 +312,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                         atomicAdd(count + xcc, 1u);
                         g = (int)xcc * gpx + (int)(seat / G);
                         m = (int)(seat % G);
+                        coop_note_staffed(status, count, target, seats);
                     }
                 }
             }
@@ -313,6 +338,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                                 atomicAdd(count + xcc, 1u);
                                 g = (int)xcc * gpx + (int)(seat / G);
                                 m = (int)(seat % G);
+                                coop_note_staffed(status, count, target, seats);
                                 atomicAdd(status + 2, 1u);       // statistics: seats taken off the canonical CU
                             }
                         }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, c = lane & 15;
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch
+    if (!coop_place<G>(err, gpx, place, group, member, seats, (write_through & 2) != 0)) return;   // surplus workgroup of the over-subscribed launch (bit 1: opts.paired_start)
     // seat numbers come out of LDS, i.e. in vector registers: say that they are uniform — every base address, resource and
     // scalar offset below then lives in SGPRs (a resource the compiler cannot prove uniform costs a waterfall loop per access)
     group = __builtin_amdgcn_readfirstlane(group);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     const DecodeNet& net = a.net[net_id];
     if (tid == 0) abort_flag = 0;
     __syncthreads();
-    const bool same_xcd = !write_through;
+    const bool same_xcd = !(write_through & 1);
     if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
@@ -571,7 +571,7 @@ int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, 
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
     const bool split = precision == GNNPN_PREC_SPLIT;
     static unsigned* p_diag = gnnpn_decode_diag_buffer();   // failure record (written on a timed-out sweep only)
-    const int wt = opts.write_through ? 1 : 0;
+    const int wt = (opts.write_through ? 1 : 0) | (opts.paired_start ? 2 : 0);
     const int lds_kb = opts.lds_kb;
 #define GNNPN_LEAN(SPLIT_, OCC_, EVH_, ...)                                                                                  \
     hipLaunchKernelGGL((pointer_decode_lean_kernel<SPLIT_, OCC_, EVH_, ##__VA_ARGS__>), dim3(COOP_OVERSUB * groups * G), dim3(256), \

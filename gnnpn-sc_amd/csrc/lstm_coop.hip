@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                                                                   int32_t B, int32_t L, int n_nets, int groups_per_net,
                                                                   int gpx, int ablate_arg, unsigned* __restrict__ seats,
                                                                   unsigned* __restrict__ diag) {
-    const int ablate = DIAG ? ablate_arg : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
+    const int ablate = DIAG ? (ablate_arg & ~0x1000) : (ablate_arg & 128);   // bit 7 = gnnpn_launch_opts_t.write_through (a tested mode)
     constexpr bool F16 = PREC != 0, SPLIT = PREC == 2;
     constexpr int HS_FLOATS = PREC == 2 ? 3 * SPLIT_TILE / 2 : ROWS * LDH16;
     __shared__ __attribute__((aligned(16))) float hs[HS_FLOATS];      // fp32 tile (k-quarter-major, stride LDT) | fp16 tile | three fp16 piece tiles (stride LDH16 halfs)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     // placement by claim (coop_common.h): one member per CU, a group's members on one XCD
     __shared__ int place[2];
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch
+    if (!coop_place<G>(err, gpx, place, group, member, seats, (ablate_arg & 0x1000) != 0)) return;   // surplus workgroup of the over-subscribed launch (bit 12: opts.paired_start)
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
@@ -607,14 +607,15 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
-    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder
+    const int abl_arg = abl | (opts.paired_start ? 0x1000 : 0);   // bit 12 rides the kernel argument only (placement, coop_place)
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;
     static unsigned* p_diag = gnnpn_decode_diag_buffer();   // failure record (diagnostic build, timed-out sweep only)
 #define GNNPN_ENC(PREC_, PRE_, DIAG_)                                                                            \
     hipLaunchKernelGGL((lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>), dim3(COOP_OVERSUB * groups * G), dim3(256),              \
                        coop_lds_padding((const void*)lstm_encode_coop_kernel<PREC_, PRE_, DIAG_>, lds_kb), s, nets, p_x, \
-                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl, p_seats, p_diag)
+                       p_e, p_s, B, L, n_nets, groups_per_net, gpx, abl_arg, p_seats, p_diag)
     if ((abl & ~128) != 0) {   // diagnostic build (folded form; fp32 with every switch, exact split with the phase stamps)
         if (prec == 1 || pre || (prec == 2 && (abl & ~(128 | 32)) != 0))
             GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: diagnostics are built for the folded form (fp32: all switches; split: stamps only)");

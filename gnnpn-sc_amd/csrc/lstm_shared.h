@@ -20,7 +20,7 @@ struct LstmNets {
 // per-call launch options, resolved from gnnpn_launch_opts_t (NULL = defaults)
 struct CoopOpts {
     int impl = 0, lds_kb = 0;
-    bool write_through = false;
+    bool write_through = false, paired_start = false;
     unsigned* sticky = nullptr;
 };
 inline CoopOpts coop_opts(const gnnpn_launch_opts_t* o) {
@@ -29,6 +29,7 @@ inline CoopOpts coop_opts(const gnnpn_launch_opts_t* o) {
         c.impl = o->impl;
         c.lds_kb = o->lds_kb;
         c.write_through = o->write_through != 0;
+        c.paired_start = o->paired_start != 0;
         c.sticky = o->sticky_status;
     }
     return c;
@@ -36,6 +37,6 @@ inline CoopOpts coop_opts(const gnnpn_launch_opts_t* o) {
 
 int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_t L, int precision, const CoopOpts& opts,
                              void* workspace, int64_t workspace_bytes, hipStream_t s);
-constexpr int COOP_SEAT_TABLE_WORDS = 8 * 256 + 8;
+constexpr int COOP_SEAT_TABLE_WORDS = 8 * 256 + 8 + 8;   // CU seats, per-XCD hand-out counters, [8*256+8] = launches staffing right now
 unsigned* gnnpn_cu_seat_table();   // api.hip: the device's canonical CU -> seat table (nullptr: allocation failed)
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

@@ -257,6 +257,7 @@ class Workspaces:
         word = int(self.status[0].item())
         if word != 0:
             self.status.zero_()
+            _lib.load().gnnpn_coop_reset_staffing()      # a launch that timed out may never have left the count of staffing launches
             last = [int(b[:4].view(torch.int32).item()) if b is not None else None for b in (self._encode, self._decode)]
             detail = ""
             if word & 2:
@@ -327,7 +328,8 @@ def check_status(device=None):
 
 def _launch_opts(ws, impl, lds_kb, write_through):
     o = _lib.LaunchOpts()
-    o.impl, o.lds_kb, o.write_through = int(impl), int(lds_kb), int(bool(write_through))
+    o.impl, o.lds_kb, o.write_through = int(impl), abs(int(lds_kb)), int(bool(write_through))
+    o.paired_start = 1 if int(lds_kb) < 0 else 0      # lds_kb < 0: footprint |lds_kb| KB AND gnnpn_launch_opts_t.paired_start
     o.sticky_status = ws.status.data_ptr() if ws is not None else None
     return o
 
@@ -349,7 +351,8 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
     w_in [4H,8] + b_in [4H] (input projection evaluated inside the cooperative kernel; for shapes
     without a cooperative kernel the projection is materialised first with gnnpn_linear_f32 —
     the same k-ordered fma chain + bias, so the same bits).
-    impl: 0 auto, 1 per-workgroup streaming, 2 cooperative; lds_kb / write_through / ws: gnnpn_launch_opts_t and the
+    impl: 0 auto, 1 per-workgroup streaming, 2 cooperative; lds_kb (NEGATIVE: footprint |lds_kb| KB and gnnpn_launch_opts_t.paired_start —
+    this launch starts together with a partner launch of the same footprint) / write_through / ws: gnnpn_launch_opts_t and the
     ``Workspaces`` to use (default: the device's shared one).
     -> (enc_out list [B,L,H], h_n list [B,H], c_n list [B,H])."""
     n = len(nets)

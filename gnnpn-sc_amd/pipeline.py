@@ -244,11 +244,6 @@ class PipelinedRunner:
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
         equal = 78 if (getattr(pipe, "precision", "f32") == "split" and paired) else 0
         self.lds_kb = [int(v) for v in env.split(",")] if env else [equal] * self.n_slots
-        self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
-        self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
-        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s])
-                       for s in range(self.n_slots)]
         self.count = 0
         # Two slots, long recurrent kernels: start the two replays of a pair TOGETHER (a submission joins the leader that is
         # still waiting for a partner, else it leads).  Free-running slots drift apart by the difference of their step
@@ -262,6 +257,12 @@ class PipelinedRunner:
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
         self.lockstep = self.n_slots == 2 and (env == "1" or (env is None and long_steps))
         self._open_leader, self._last_done = None, [None, None]
+        # gnnpn_launch_opts_t.paired_start (ops: a negative lds_kb): half-batches and slots started in pairs begin together
+        self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
+        self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
+        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=-self.lds_kb[s] if (self.halves or self.lockstep) else self.lds_kb[s],
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s])
+                       for s in range(self.n_slots)]
 
     @staticmethod
     def _clone(b):

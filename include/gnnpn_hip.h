@@ -228,6 +228,13 @@ typedef struct {
  *                   takes one workgroup of each, never two of one)
  *   write_through   non-zero: always publish hand-off granules with agent-scope (sc1) stores instead of keeping them in
  *                   the XCD's L2 when a group has verified at run time that it sits on one XCD (same results)
+ *   paired_start    non-zero: the caller starts this launch TOGETHER with another cooperative launch of the same LDS footprint
+ *                   (two half-batches side by side, two slots started as a pair).  LDS is handed out in contiguous ranges; a
+ *                   workgroup that lands above a short-lived neighbour keeps its range in the middle of the CU and the partner
+ *                   launch's workgroup for that CU can then not be placed until this kernel has finished — two launches that
+ *                   do that to each other both stay short of members and end in hand-off time-outs.  With the flag, a
+ *                   workgroup in such a position does not take its seat (a later arrival of the over-subscribed launch does);
+ *                   without it that happens only while another launch of the process is staffing at the same moment.
  *   sticky_status   device uint32 or NULL: every failure code a cooperative kernel raises (bounded inter-workgroup
  *                   wait timed out: outputs invalid) is OR-ed into it as well as into word 0 of the workspace.  The
  *                   library never clears it — word 0 of the workspace is zeroed by every launch — so one host read
@@ -236,7 +243,7 @@ typedef struct {
     int32_t impl;
     int32_t lds_kb;
     int32_t write_through;
-    int32_t reserved;
+    int32_t paired_start;
     uint32_t* sticky_status;
 } gnnpn_launch_opts_t;
 
@@ -264,6 +271,9 @@ int gnnpn_set_option(const char* name, int value);
  * lanes, the launch's eight per-XCD claim counters (one byte each, two words), device realtime (lo, hi), groups per
  * XCD, workgroup id, the launch's status word. */
 int gnnpn_decode_diag(uint32_t* out, int32_t n_words, int32_t clear);
+/* Housekeeping after a cooperative launch reported a hand-off time-out (sticky status != 0): clears the per-device count of
+ * launches that are still staffing (such a launch may never have left it); synchronises the device. */
+int gnnpn_coop_reset_staffing(void);
 
 /* Greedy pointer decode of up to two pointer networks in one call: T steps of {decoder LSTM cell;
  * dot-attention logits over the step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent
