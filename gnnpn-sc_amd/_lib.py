@@ -39,6 +39,7 @@ _SIGNATURES = {
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
     "gnnpn_coop_reset_staffing": (c_int, []),
+    "gnnpn_coop_staffing_count": (c_int, []),
     "gnnpn_bn_train_forward_f32": (c_int, [_P, c_int64, c_int32, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "gnnpn_bn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int, _P, _P, _P, _P]),
     "gnnpn_bce_sigmoid_f32": (c_int, [_P, _P, c_int64, _P, _P, _P]),

@@ -47,6 +47,14 @@ extern "C" int gnnpn_coop_reset_staffing(void) {
     return GNNPN_OK;
 }
 
+// diagnostics: the count itself (0 whenever no cooperative launch is between its first arrival and its last seat); -1: error
+extern "C" int gnnpn_coop_staffing_count(void) {
+    unsigned* p = gnnpn_cu_seat_table();
+    unsigned v = 0;
+    if (!p || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, p + COOP_STAFFING_WORD, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
+
 extern "C" int gnnpn_set_option(const char* name, int value) {
     if (!name) GNNPN_FAIL(GNNPN_E_ARG, "set_option: null name");
     if (!strcmp(name, "lstm_ablate")) {   // bit0 no MFMA, bit1 no transcendentals, bit2 no tag wait, bit3 no sweep, bit4 no publish, bit5 stamps

@@ -234,11 +234,12 @@ inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t
 //   ~50 us (the front end at 5000 candidates x 512 problems) outlasted 64 surplus workgroups of 16 us each, the launch
 //   stayed one or two members short on some XCDs and its groups timed out (tools/repro_synth4.sh, record in DESIGN.md).
 // one lane, right after it has taken a seat: was that the launch's last one?  Then the launch leaves the per-device
-// count of launches that are staffing (status word 4: 0 not started, 1 counted, 2 staffed).
+// count of launches that are staffing (status word 4: 0 not started, 1 counted, 2 staffed).  The seats are counted in ONE
+// word (status word 5) so that exactly one workgroup sees the total: two last seat-takers on two XCDs comparing the
+// per-XCD counters could each miss the other's increment, and the launch would stay in the count for good.
 __device__ __forceinline__ void coop_note_staffed(unsigned* status, const unsigned* count, unsigned target, unsigned* seats) {
-    bool all = true;
-    for (int x = 0; x < 8; ++x) all &= __hip_atomic_load(count + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
-    if (all && atomicCAS(status + 4, 1u, 2u) == 1u) atomicSub(seats + COOP_STAFFING_WORD, 1u);
+    (void)count;
+    if (atomicAdd(status + 5, 1u) + 1u == 8u * target && atomicCAS(status + 4, 1u, 2u) == 1u) atomicSub(seats + COOP_STAFFING_WORD, 1u);
 }
 template <int G>
 __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats,

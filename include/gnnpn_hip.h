@@ -274,6 +274,8 @@ int gnnpn_decode_diag(uint32_t* out, int32_t n_words, int32_t clear);
 /* Housekeeping after a cooperative launch reported a hand-off time-out (sticky status != 0): clears the per-device count of
  * launches that are still staffing (such a launch may never have left it); synchronises the device. */
 int gnnpn_coop_reset_staffing(void);
+/* Diagnostics: that count (device synchronised first); 0 whenever no cooperative launch is staffing; -1 on error. */
+int gnnpn_coop_staffing_count(void);
 
 /* Greedy pointer decode of up to two pointer networks in one call: T steps of {decoder LSTM cell;
  * dot-attention logits over the step's candidate window [k*n_per,(k+1)*n_per); C*tanh; + latent

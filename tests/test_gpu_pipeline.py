@@ -484,9 +484,10 @@ def test_two_slots_started_together_with_long_recurrences(dev):
             if not all(torch.equal(oj[k], refs[j % 3][k]) for k in ("idx_low", "idx_high", "R")):
                 bad.append(j)
     runner.synchronize(check=True)
-    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd import _lib, ops
     ops.check_status(dev)
     assert not bad, bad
+    assert _lib.load().gnnpn_coop_staffing_count() == 0     # every launch left the count of launches that are staffing
 
 
 @pytest.mark.parametrize("precision", ["f32", "split"])
@@ -524,6 +525,8 @@ def test_soak_two_slots(dev, precision):
         bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
     runner.synchronize(check=True)
     assert bad == 0, f"{bad} of 2000 pipelined steps differ from the single-stream run"
+    from gnnpn_sc_amd import _lib
+    assert _lib.load().gnnpn_coop_staffing_count() == 0     # 8,000 cooperative launches later nobody is left in the count of staffing launches
 
 
 def test_bench_line_contract(dev):
