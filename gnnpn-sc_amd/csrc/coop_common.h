@@ -293,8 +293,8 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 if (fragments && !reserve_arrival) {
                     atomicAdd(status + 3, 1u);                                // statistics: arrivals that left because of their LDS position
                     g = -2;                                                   // leave without holding the slot; the seat stays open
-                } else if (!(fragments && paired_start)) {       // (strict: a badly placed RESERVE arrival does not rush for the seat either: it
-                    //                                              waits with the reserve below and takes an open seat only if nobody better placed has)
+                } else if (!fragments) {                         // (a badly placed RESERVE arrival does not rush for the seat either: it waits
+                    //                                              with the reserve below and takes an open seat only if nobody better placed has)
                     // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch); whoever of
                     // this launch gets there first takes it (one compare-and-swap), every later arrival on the CU is surplus
                     unsigned s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
