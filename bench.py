@@ -418,6 +418,8 @@ def main():
                     help="1 (default): replay each step as one captured HIP graph, per-kernel HIP events in a "
                          "separate eager pass; 0: eager launches with the HIP events inside the timed region "
                          "(the events themselves cost ~25 %% throughput)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: steps of a slot whose selected indices travel in ONE all-gather (0 = 8 at the QWS shape, else 1)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent steps (batches) in flight on separate HIP streams (needs --graph 1)")
     args = ap.parse_args()
@@ -508,6 +510,12 @@ def main():
     runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
     last = {}                                                   # slot -> index of the batch its outputs belong to
     gathers = {}                                                # (runner, slot) -> (gathered tensor, pending work)
+    # Bucketed collective: the selected indices of `bucket` consecutive steps of a slot cross xGMI as ONE all-gather
+    # (48 KB per rank and step at QWS: a collective per 0.55 ms step is all launch overhead — host and device —, 8 steps
+    # per collective carry the same bytes in an eighth of the launches).  Two staging buffers per slot: one fills while
+    # the other's gather is in flight.  Every gather, the partial last bucket included, lands inside the timed region.
+    bucket = args.gather_every if args.gather_every > 0 else (8 if B * T * K <= 256 * 235 * 2 else 1)
+    stages = {}                                                 # (runner, slot) -> {"buf": [2 x [bucket,B,T]], "cur", "fill", "out": [2], "work": [2]}
 
     def step(i, runner=runner):
         """One step.  At N > 1 the single collective of the path — the all-gather of the selected indices — is issued
@@ -527,16 +535,51 @@ def main():
         else:
             out, stream, key = pipe.run(svc, batches[j]), torch.cuda.current_stream(), (0, 0)
         step.last = out
+        if use_dist and bucket > 1:
+            st = stages.get(key)
+            if st is None:
+                idx = out["idx_high"]
+                st = stages[key] = {"buf": [torch.empty((bucket,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device) for _ in range(2)],
+                                    "cur": 0, "fill": 0, "out": [None, None], "work": [None, None], "stream": stream}
+            with torch.cuda.stream(stream):
+                st["buf"][st["cur"]][st["fill"]].copy_(out["idx_high"], non_blocking=True)
+                st["fill"] += 1
+                if st["fill"] == bucket:
+                    flush_bucket(st)
+            return out["idx_high"], out["R"]
         if use_dist:
             with torch.cuda.stream(stream):
                 gathers[key] = gdist.all_gather_indices_async(out["idx_high"], gathers.get(key, (None, None))[0])
             return gathers[key][0], out["R"]
         return out["idx_high"], out["R"]
 
+    def flush_bucket(st):
+        """Gather the filled part of the current staging buffer (called on the slot's stream) and switch to the other one,
+        whose previous gather must have finished before it is written again."""
+        c, n = st["cur"], st["fill"]
+        if n:
+            src = st["buf"][c][:n].reshape(n * st["buf"][c].shape[1], -1)
+            if n == bucket:
+                st["out"][c], st["work"][c] = gdist.all_gather_indices_async(src, st["out"][c])
+            else:                                               # the partial last bucket of a round: its own (smaller) destination
+                st["last"], st["work"][c] = gdist.all_gather_indices_async(src, None)
+            st["gathered_rows"] = (st["out"][c] if n == bucket else st["last"]).shape[0]
+        st["cur"], st["fill"] = 1 - c, 0
+        if st["work"][1 - c] is not None:
+            st["work"][1 - c].wait()                            # stream-side: the other buffer's gather is done before this slot refills it
+            st["work"][1 - c] = None
+
     def finish_gathers():
         for g, work in gathers.values():
             if work is not None:
                 work.wait()
+        for st in stages.values():
+            with torch.cuda.stream(st["stream"]):
+                flush_bucket(st)
+                for i in (0, 1):
+                    if st["work"][i] is not None:
+                        st["work"][i].wait()
+                        st["work"][i] = None
 
     def timed_rounds(run_step):
         """The contract's timed region — barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks —
@@ -675,8 +718,12 @@ def main():
     if rank != 0:
         gdist.destroy(world)
         return
-    if use_dist and tuple(idx.shape) != (world * B, T):
+    if use_dist and bucket == 1 and tuple(idx.shape) != (world * B, T):
         raise SystemExit(f"all-gather returned {tuple(idx.shape)}, expected {(world * B, T)}")
+    if use_dist and bucket > 1:
+        for st in stages.values():
+            if st.get("gathered_rows", 0) % (world * B) != 0 or st.get("gathered_rows", 0) == 0:
+                raise SystemExit(f"bucketed all-gather returned {st.get('gathered_rows')} rows, expected a multiple of {world * B}")
     value = world * B * args.steps / elapsed
     kernels = kernel_table(summary, n_timed, args.precision)
     # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
@@ -732,6 +779,8 @@ def main():
                    "service_embedding": "problem-independent GCN branch evaluated once per (weights, service table), "
                                         "outside the step (SURVEY.md section 7)",
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}",
+                   "collective": (None if not use_dist else "one asynchronous all-gather of the selected indices per step" if bucket == 1 else
+                                  f"one asynchronous all-gather per {bucket} steps of a slot (the selected indices of those steps, staged on the device)"),
                    **({"rank0_cpu_affinity": affinity} if affinity is not None else {}),
                    **({"NOT_A_MEASUREMENT": "GNNPN_BENCH_SHARE_GPU=1: all ranks share one GPU over gloo (launch-path check)"}
                       if share else {})},
