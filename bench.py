@@ -31,6 +31,7 @@ Extra objects on the line:
 Defaults: --gpus 1 --steps 100 --warmup 10 --workload qws (a few seconds of GPU time + ~10 s of CPU baseline).
 """
 import argparse
+import contextlib
 import gc
 import json
 import os
@@ -340,6 +341,30 @@ def bind_to_gpu_numa_node(local_rank):
         return {"bound": False, "why": repr(e)}
 
 
+_share_lock_file = None
+
+
+@contextlib.contextmanager
+def gpu_turn(share):
+    """Ranks that share ONE GPU (GNNPN_BENCH_SHARE_GPU=1: a rehearsal of the launch path, never a measurement) take turns on it:
+    the cooperative kernels place their workgroups per process (seat table, staffing count), and launches of four processes
+    on one card are a mix nobody designed for — one such run ended in a hand-off time-out.  A file lock around every stretch
+    of GPU work (never around a collective: the peers could not reach it) keeps one rank's launches on the card at a time."""
+    global _share_lock_file
+    if not share:
+        yield
+        return
+    import fcntl
+    if _share_lock_file is None:
+        _share_lock_file = open(f"/tmp/gnnpn_bench_share_{os.environ.get('MASTER_PORT', '0')}.lock", "w")
+    fcntl.flock(_share_lock_file, fcntl.LOCK_EX)
+    try:
+        yield
+    finally:
+        torch.cuda.synchronize()
+        fcntl.flock(_share_lock_file, fcntl.LOCK_UN)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) and relay their status.
     Runs BEFORE this process touches a GPU (torch.cuda.device_count() does not initialise one on this image) and never
@@ -507,7 +532,8 @@ def main():
     n_slots = max(1, args.inflight) if args.graph else 1
     if share:       # ranks sharing ONE GPU (launch-path rehearsal): a CU holds two cooperative workgroups in all, so every rank
         n_slots = 1  # runs one launch at a time — four launches of two processes would wait on each other past the spin bound
-    runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
+    with gpu_turn(share):
+        runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
     last = {}                                                   # slot -> index of the batch its outputs belong to
     gathers = {}                                                # (runner, slot) -> (gathered tensor, pending work)
     # Bucketed collective: the selected indices of `bucket` consecutive steps of a slot cross xGMI as ONE all-gather
@@ -529,11 +555,14 @@ def main():
             if use_dist and gathers.get(key, (None, None))[1] is not None:
                 with torch.cuda.stream(runner.stream(s)):
                     gathers[key][1].wait()                      # the previous gather out of this slot's index buffer is done
-            out, s = runner.submit(batches[j])
+            with gpu_turn(share):
+                out, s = runner.submit(batches[j])
             stream = runner.stream(s)
             last[key] = j
         else:
-            out, stream, key = pipe.run(svc, batches[j]), torch.cuda.current_stream(), (0, 0)
+            with gpu_turn(share):
+                out = pipe.run(svc, batches[j])
+            stream, key = torch.cuda.current_stream(), (0, 0)
         step.last = out
         if use_dist and bucket > 1:
             st = stages.get(key)
@@ -626,12 +655,14 @@ def main():
     ops.check_status(dev)
     # self-check: every slot's (overlapped) result equals a single-stream run of the same kernels on the same batch
     decode_impl = runner.decode_impl if runner is not None else 0
-    ref = pipe.run(svc, batch, decode_impl=decode_impl)
-    torch.cuda.synchronize()
+    with gpu_turn(share):
+        ref = pipe.run(svc, batch, decode_impl=decode_impl)
+        torch.cuda.synchronize()
     agreement = None
     if args.precision != "f32":       # agreement of the reduced-precision mode with the f32 path: same batch,
-        r32 = ML2PNPipeline(net, low, high, K).run(svc, batch)   # compared on the SELECTED rows (dummy /
-        torch.cuda.synchronize()                                  # duplicate candidates are one selection)
+        with gpu_turn(share):
+            r32 = ML2PNPipeline(net, low, high, K).run(svc, batch)   # compared on the SELECTED rows (dummy /
+            torch.cuda.synchronize()                                  # duplicate candidates are one selection)
         same = (ref["actions"] == r32["actions"]).all(-1)
         agreement = {"problems_with_identical_selection": round(float(same.all(1).float().mean()), 4),
                      "identical_decisions": round(float(same.float().mean()), 5),
@@ -639,7 +670,8 @@ def main():
     if runner is not None:
         for s in range(runner.n_slots):
             o = runner.graphs[s].outputs
-            rj = pipe.run(svc, batches[last[(id(runner), s)]], decode_impl=decode_impl)
+            with gpu_turn(share):
+                rj = pipe.run(svc, batches[last[(id(runner), s)]], decode_impl=decode_impl)
             if not (torch.equal(o["idx_high"], rj["idx_high"]) and torch.equal(o["R"], rj["R"])):
                 raise SystemExit(f"slot {s}: overlapped result differs from the single-stream run")
     def kernel_pass(rn):
@@ -679,7 +711,8 @@ def main():
 
     n_timed, summary = args.steps, timers.summary()
     if args.graph and not args.no_kernel_timers:
-        summary, n_timed = kernel_pass(runner)
+        with gpu_turn(share):
+            summary, n_timed = kernel_pass(runner)
     gc.enable()
 
     # Second measurement, reported beside the headline and never as `value`: the same workload in the OTHER arithmetic of the
@@ -691,7 +724,8 @@ def main():
                           "products per term (every cross term >= 2^-24 kept), fp32 accumulate; rest f32"}
     if other and args.graph and not args.no_split_line:
         pipe_s = ML2PNPipeline(net, low, high, K, precision=other)
-        runner_s = PipelinedRunner(pipe_s, svc, batch, slots=n_slots, halves=False if share else None)
+        with gpu_turn(share):
+            runner_s = PipelinedRunner(pipe_s, svc, batch, slots=n_slots, halves=False if share else None)
         gc.collect()
         gc.disable()
         for i in range(args.warmup):
@@ -700,7 +734,8 @@ def main():
         el_s, timing_s = summarise(rounds_s)
         runner_s.synchronize(check=True)
         out_s = runner_s.graphs[0].outputs
-        ref_s = pipe.run(svc, batches[last[(id(runner_s), 0)]], decode_impl=decode_impl)
+        with gpu_turn(share):
+            ref_s = pipe.run(svc, batches[last[(id(runner_s), 0)]], decode_impl=decode_impl)
         same = (out_s["actions"] == ref_s["actions"]).all(-1)
         other_line = {"precision": other, "arithmetic": PREC_TEXT[other],
                       "value": round(world * B * args.steps / el_s, 2), "unit": "problems/s",
@@ -710,7 +745,8 @@ def main():
                           "identical_decisions": round(float(same.float().mean()), 5),
                           "max_abs_R_diff": round(float((out_s["R"] - ref_s["R"]).abs().max()), 6)}}
         if not args.no_kernel_timers:
-            sm, nt = kernel_pass(runner_s)
+            with gpu_turn(share):
+                sm, nt = kernel_pass(runner_s)
             other_line["kernels"] = kernel_table(sm, nt, other)
         gc.enable()
         del runner_s
