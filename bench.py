@@ -534,6 +534,9 @@ def main():
         n_slots = 1  # runs one launch at a time — four launches of two processes would wait on each other past the spin bound
     with gpu_turn(share):
         runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
+    if runner is not None:
+        batches = [runner.pack(b) for b in batches]             # the slots' layout: one device-to-device copy per step instead of seven
+        batch = batches[0]
     last = {}                                                   # slot -> index of the batch its outputs belong to
     gathers = {}                                                # (runner, slot) -> (gathered tensor, pending work)
     # Bucketed collective: the selected indices of `bucket` consecutive steps of a slot cross xGMI as ONE all-gather

@@ -265,10 +265,33 @@ class PipelinedRunner:
                        for s in range(self.n_slots)]
 
     @staticmethod
-    def _clone(b):
-        c = graph.CSR(b.wf_csr.rowptr.clone(), b.wf_csr.col.clone(), None, b.wf_csr.n)
-        return DeviceBatch(b.x.clone(), c, b.seg_ptr.clone(), b.local_bounds.clone(), b.present.clone(),
-                           b.global_bounds.clone(), b.max_nodes)
+    def _fields(b):
+        return (b.x, b.wf_csr.rowptr, b.wf_csr.col, b.seg_ptr, b.local_bounds, b.present, b.global_bounds)
+
+    @classmethod
+    def _clone(cls, b):
+        """A copy of the batch whose seven tensors are views into ONE allocation (``_arena``, 256-byte aligned pieces): a
+        batch that was packed the same way (``pack``) moves into a slot's static inputs with one copy instead of seven —
+        at a 0.55 ms step seven 5 us copy kernels in front of every replay are 3 % of the slot's cycle."""
+        fields = cls._fields(b)
+        offs, total = [], 0
+        for t in fields:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=b.x.device)
+        views = []
+        for t, o in zip(fields, offs):
+            v = arena[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+            v.copy_(t)
+            views.append(v)
+        x, rowptr, col, seg, lb, pr, gb = views
+        out = DeviceBatch(x, graph.CSR(rowptr, col, None, b.wf_csr.n), seg, lb, pr, gb, b.max_nodes)
+        out._arena, out._layout = arena, tuple((tuple(t.shape), t.dtype) for t in fields)
+        return out
+
+    def pack(self, batch):
+        """The batch in the slots' own memory layout: ``submit`` moves such a batch with a single device-to-device copy."""
+        return self._clone(batch)
 
     def submit(self, batch=None):
         """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
@@ -282,12 +305,13 @@ class PipelinedRunner:
                 if 0 < dst.max_nodes <= lim and not 0 < batch.max_nodes <= lim:   # workflow graphs) or the layered kernels
                     raise ops.GnnpnError(f"PipelinedRunner: the captured graph holds the one-launch GIN branch (graphs of <= "
                                          f"{lim} nodes); this batch has max_nodes = {batch.max_nodes}")
-                for a, b in ((dst.x, batch.x), (dst.wf_csr.rowptr, batch.wf_csr.rowptr), (dst.wf_csr.col, batch.wf_csr.col),
-                             (dst.seg_ptr, batch.seg_ptr), (dst.local_bounds, batch.local_bounds),
-                             (dst.present, batch.present), (dst.global_bounds, batch.global_bounds)):
-                    if a.shape != b.shape:
-                        raise ops.GnnpnError(f"PipelinedRunner: batch shape {tuple(b.shape)} != captured {tuple(a.shape)}")
-                    a.copy_(b, non_blocking=True)
+                if getattr(batch, "_layout", None) is not None and batch._layout == dst._layout and batch._arena.device == dst._arena.device:
+                    dst._arena.copy_(batch._arena, non_blocking=True)          # packed alike: one copy
+                else:
+                    for a, b in zip(self._fields(dst), self._fields(batch)):
+                        if a.shape != b.shape:
+                            raise ops.GnnpnError(f"PipelinedRunner: batch shape {tuple(b.shape)} != captured {tuple(a.shape)}")
+                        a.copy_(b, non_blocking=True)
             leader = False
             if self.lockstep:
                 # A submission joins the leader that is waiting for a partner (and starts with it) if that leader has not
