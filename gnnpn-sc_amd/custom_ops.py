@@ -68,19 +68,19 @@ _op("qos_reward(Tensor actions, int level) -> Tensor",
     lambda actions, level: ops.qos_reward(actions, "Low" if level == 0 else "High"))
 
 
-def _lstm_encode(net_tensors, n_nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1):   # defaults = the schema's: the dispatcher omits arguments that equal them
+def _lstm_encode(net_tensors, n_nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, paired_start=False):   # defaults = the schema's: the dispatcher omits arguments that equal them
     n = len(ENCODE_KEYS)
     nets = [{k: net_tensors[i * n + j] for j, k in enumerate(ENCODE_KEYS)} for i in range(n_nets)]
-    enc, h_n, c_n = ops.lstm_encode(nets, precision, impl, lds_kb, write_through, _ws(ws_id))
+    enc, h_n, c_n = ops.lstm_encode(nets, precision, impl, lds_kb, write_through, _ws(ws_id), paired_start)
     return list(enc) + list(h_n) + list(c_n)
 
 
 _op("lstm_encode(Tensor?[] net_tensors, int n_nets, str precision='f32', int impl=0, int lds_kb=0, "
-    "bool write_through=False, int ws=-1) -> Tensor[]", _lstm_encode)
+    "bool write_through=False, int ws=-1, bool paired_start=False) -> Tensor[]", _lstm_encode)
 
 
 def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False,
-                    precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, sample_seeds=()):
+                    precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, sample_seeds=(), paired_start=False):
     n = len(DECODE_KEYS)
     nets = []
     for i, lf in enumerate(latent_from):
@@ -90,7 +90,7 @@ def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0,
             d["sample"], d["sample_seed"] = True, sample_seeds[i]
         nets.append(d)
     outs = ops.pointer_decode(nets, inputs, n_cat, n_per, tanh_c, use_tanh, want_queries, precision, impl, lds_kb,
-                              write_through, _ws(ws_id))
+                              write_through, _ws(ws_id), paired_start)
     flat = []
     for o in outs:
         for k in DECODE_OUTS:
@@ -100,26 +100,27 @@ def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0,
 
 _op("pointer_decode(Tensor?[] net_tensors, int[] latent_from, Tensor inputs, int n_cat, int n_per, float tanh_c=10.0, "
     "bool use_tanh=True, bool want_queries=False, str precision='f32', int impl=0, int lds_kb=0, "
-    "bool write_through=False, int ws=-1, int[] sample_seeds=[]) -> Tensor[]", _pointer_decode)
+    "bool write_through=False, int ws=-1, int[] sample_seeds=[], bool paired_start=False) -> Tensor[]", _pointer_decode)
 
 
 # ---- thin callers used by the mirrors: dict-of-tensors in, torch.ops.gnnpn.* underneath ------------------------------
 
-def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None):
+def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None, paired_start=False):
     flat = [d.get(k) for d in nets for k in ENCODE_KEYS]
     out = torch.ops.gnnpn.lstm_encode(flat, len(nets), precision, impl, lds_kb, bool(write_through),
-                                      -1 if ws is None else ws.id)
+                                      -1 if ws is None else ws.id, bool(paired_start))
     n = len(nets)
     return out[:n], out[n:2 * n], out[2 * n:]
 
 
 def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32", impl=0,
-                   lds_kb=0, write_through=False, ws=None):
+                   lds_kb=0, write_through=False, ws=None, paired_start=False):
     flat = [d.get(k) for d in nets for k in DECODE_KEYS]
     lf = [int(d.get("latent_from", -1)) for d in nets]
     seeds = [int(d["sample_seed"]) & 0x7FFFFFFFFFFFFFFF if d.get("sample") else -1 for d in nets]
     out = torch.ops.gnnpn.pointer_decode(flat, lf, inputs, n_cat, n_per, float(tanh_c), bool(use_tanh), bool(want_queries),
-                                         precision, impl, lds_kb, bool(write_through), -1 if ws is None else ws.id, seeds)
+                                         precision, impl, lds_kb, bool(write_through), -1 if ws is None else ws.id, seeds,
+                                         bool(paired_start))
     m = len(DECODE_OUTS)
     res = []
     for i in range(len(nets)):

@@ -362,7 +362,7 @@ class CombinatorialRL(nn.Module):
 
 @torch.no_grad()
 def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=0, lds_kb=0, write_through=False, ws=None,
-                     sample_high_seed=None):
+                     sample_high_seed=None, paired_start=False):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
@@ -373,7 +373,7 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     chain's) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
     sample_high_seed: the High level DRAWS its picks from that stream instead of taking the argmax — the forward of the
     PNHigh training step (trainPNHigh.py:83-84: Low greedy -> latent, High sample='sample'); the Low level stays greedy.
-    decode_impl / lds_kb / write_through / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,
+    decode_impl / lds_kb / write_through / paired_start / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,
     ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
@@ -396,14 +396,15 @@ def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=
     ha.check_precision(precision)
     enc_l, emb_l = la.encode_args(inputs, fold)
     enc_h, emb_h = ha.encode_args(inputs, fold)
-    enc, h_n, c_n = custom_ops.lstm_encode([enc_l, enc_h], precision=precision, lds_kb=lds_kb, write_through=write_through, ws=ws)
+    enc, h_n, c_n = custom_ops.lstm_encode([enc_l, enc_h], precision=precision, lds_kb=lds_kb, write_through=write_through, ws=ws,
+                                           paired_start=paired_start)
     del enc_l, enc_h
     dl, dh = custom_ops.pointer_decode([la.decode_args(emb_l, enc[0], h_n[0], c_n[0], fold=fold),
                                  ha.decode_args(emb_h, enc[1], h_n[1], c_n[1], latent_from=0, fold=fold,
                                                 sample_seed=sample_high_seed)],
                                 inputs, la.serCategory, la.serNumber, la.C, la.use_tanh,
                                 precision="split" if precision == "split" else "f32", impl=decode_impl, lds_kb=lds_kb,
-                                write_through=write_through, ws=ws)
+                                write_through=write_through, ws=ws, paired_start=paired_start)
     R = torch.ops.gnnpn.qos_reward(dh["actions"], 0 if high.level == "Low" else 1)
     return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
             "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -326,10 +326,10 @@ def check_status(device=None):
             w.check()
 
 
-def _launch_opts(ws, impl, lds_kb, write_through):
+def _launch_opts(ws, impl, lds_kb, write_through, paired_start=False):
     o = _lib.LaunchOpts()
-    o.impl, o.lds_kb, o.write_through = int(impl), abs(int(lds_kb)), int(bool(write_through))
-    o.paired_start = 1 if int(lds_kb) < 0 else 0      # lds_kb < 0: footprint |lds_kb| KB AND gnnpn_launch_opts_t.paired_start
+    o.impl, o.lds_kb, o.write_through = int(impl), int(lds_kb), int(bool(write_through))
+    o.paired_start = int(bool(paired_start))
     o.sticky_status = ws.status.data_ptr() if ws is not None else None
     return o
 
@@ -340,7 +340,7 @@ def coop_supported(H, n_per=1, impl=0):
     return H == 256 and n_per <= 16 and impl != 1
 
 
-def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None):
+def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None, paired_start=False):
     """Run the encoder recurrence of len(nets) nets in ONE launch (gnnpn_lstm_encode_f32).
 
     precision="f16" (opt-in, cooperative form only): W_hh and h_{t-1} enter the recurrent product as
@@ -351,8 +351,8 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
     w_in [4H,8] + b_in [4H] (input projection evaluated inside the cooperative kernel; for shapes
     without a cooperative kernel the projection is materialised first with gnnpn_linear_f32 —
     the same k-ordered fma chain + bias, so the same bits).
-    impl: 0 auto, 1 per-workgroup streaming, 2 cooperative; lds_kb (NEGATIVE: footprint |lds_kb| KB and gnnpn_launch_opts_t.paired_start —
-    this launch starts together with a partner launch of the same footprint) / write_through / ws: gnnpn_launch_opts_t and the
+    impl: 0 auto, 1 per-workgroup streaming, 2 cooperative; lds_kb / write_through / paired_start (this launch starts together
+    with a partner launch of the same LDS footprint: strict placement, include/gnnpn_hip.h) / ws: gnnpn_launch_opts_t and the
     ``Workspaces`` to use (default: the device's shared one).
     -> (enc_out list [B,L,H], h_n list [B,H], c_n list [B,H])."""
     n = len(nets)
@@ -388,7 +388,7 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
         raise GnnpnError(f"lstm_encode: unknown precision {precision!r}")
     if precision != "f32" and not coop:
         raise GnnpnError(f"lstm_encode: precision={precision!r} needs the cooperative form (H = 256)")
-    opts = _launch_opts(wsp, impl, lds_kb, write_through)
+    opts = _launch_opts(wsp, impl, lds_kb, write_through, paired_start)
     check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, _PRECISIONS[precision], _lib.ctypes.byref(opts),
                                             dev_ptr(buf, torch.uint8, "workspace", True),
                                             0 if buf is None else buf.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
@@ -396,7 +396,7 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
 
 
 def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32",
-                   impl=0, lds_kb=0, write_through=False, ws=None):
+                   impl=0, lds_kb=0, write_through=False, ws=None, paired_start=False):
     """Greedy decode of 1 or 2 pointer networks in ONE call (gnnpn_pointer_decode_f32).
 
     nets: list of dicts with keys enc_out, h0, c0, start, wih, whh, bih, bhh, EITHER embedded [B,L,H]
@@ -454,7 +454,7 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
     coop = coop_supported(H, n_per, impl)
     wsp = workspaces(dev, ws) if coop else None
     buf = wsp.decode(B, n_cat, n_per) if coop else None
-    opts = _launch_opts(wsp, impl, lds_kb, write_through)
+    opts = _launch_opts(wsp, impl, lds_kb, write_through, paired_start)
     check(_lib.load().gnnpn_pointer_decode_f32(
         len(nets), arr, dev_ptr(inputs, F32, "inputs"), float(tanh_c), int(bool(use_tanh)), B, n_cat, n_per, H,
         _PRECISIONS["split"] if precision == "split" else 0, _lib.ctypes.byref(opts),

@@ -125,8 +125,9 @@ class ML2PNPipeline:
                                                      batch.present, batch.global_bounds, self.n_per)
 
     @torch.no_grad()
-    def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None):
-        """One pass.  decode_impl / lds_kb / ws: launch options of the recurrent kernels (modelPN.two_level_greedy).
+    def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None, paired_start=False):
+        """One pass.  decode_impl / lds_kb / paired_start / ws: launch options of the recurrent kernels (modelPN.two_level_greedy;
+        paired_start: the caller starts these launches together with a partner's — half-batches do by construction).
         ``ws`` = a PAIR of workspaces: the recurrent part runs as two half-batches side by side, the second on a side
         stream (fork / join, capturable) — the problems are independent, and two cooperative launches of one workgroup
         per CU each share every CU for their whole length (encoder beside encoder, decoder beside decoder), which two
@@ -145,20 +146,20 @@ class ML2PNPipeline:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 out_b = two_level_greedy(self.low, self.high, rows[half:], precision=self.precision, decode_impl=decode_impl,
-                                         lds_kb=lds_kb, ws=ws[1])
+                                         lds_kb=lds_kb, ws=ws[1], paired_start=True)
             out_a = two_level_greedy(self.low, self.high, rows[:half], precision=self.precision, decode_impl=decode_impl,
-                                     lds_kb=lds_kb, ws=ws[0])
+                                     lds_kb=lds_kb, ws=ws[0], paired_start=True)
             cur.wait_stream(side)
             for v in out_b.values():
                 v.record_stream(cur)
             out = {k: torch.cat([out_a[k], out_b[k]]) for k in out_a}
         else:
             out = two_level_greedy(self.low, self.high, rows, precision=self.precision, decode_impl=decode_impl,
-                                   lds_kb=lds_kb, ws=ws)
+                                   lds_kb=lds_kb, ws=ws, paired_start=paired_start)
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
-    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None):
+    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None, paired_start=False):
         """Record one whole pass over (services, batch) into a HIP graph and return a callable that
         replays it on the CURRENT stream (one launch per step instead of ~25).  The returned dict's
         tensors are the graph's static outputs: they are overwritten by every replay.  ``ws`` is the
@@ -171,12 +172,12 @@ class ML2PNPipeline:
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for _ in range(warmup):          # allocate workspaces / pack weights outside the capture
-                self.run(services, batch, decode_impl, lds_kb, ws)
+                self.run(services, batch, decode_impl, lds_kb, ws, paired_start)
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = self.run(services, batch, decode_impl, lds_kb, ws)
+            out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start)
         for w in all_ws:
             w.frozen = True
 
@@ -257,11 +258,11 @@ class PipelinedRunner:
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
         self.lockstep = self.n_slots == 2 and (env == "1" or (env is None and long_steps))
         self._open_leader, self._last_done = None, [None, None]
-        # gnnpn_launch_opts_t.paired_start (ops: a negative lds_kb): half-batches and slots started in pairs begin together
+        # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
-        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=-self.lds_kb[s] if (self.halves or self.lockstep) else self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s])
+        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep)
                        for s in range(self.n_slots)]
 
     @staticmethod
