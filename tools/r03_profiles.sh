@@ -51,6 +51,8 @@ for wl in ${WLS:-qws normal synth4 synth5}; do
 done
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_qws_f16 -- python3 $R/bench.py --precision f16 --steps 2 --warmup 1 $SOLO > $O/fetch_qws_f16.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_qws_f16 -- python3 $R/bench.py --precision f16 --steps 2 --warmup 1 $SOLO > $O/write_qws_f16.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_synth5_f16 -- python3 $R/bench.py --workload synth5 --precision f16 --steps 2 --warmup 1 $SOLO > $O/fetch_synth5_f16.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_synth5_f16 -- python3 $R/bench.py --workload synth5 --precision f16 --steps 2 --warmup 1 $SOLO > $O/write_synth5_f16.log 2>&1
 fi
 find $O -name '*kernel_trace.csv' -size +4M -delete
 find $O -name '*.db' -delete
