@@ -672,6 +672,8 @@ def main():
                      "mean_abs_R_diff": round(float((ref["R"] - r32["R"]).abs().mean()), 6)}
     if runner is not None:
         for s in range(runner.n_slots):
+            if (id(runner), s) not in last:        # fewer steps than slots
+                continue
             o = runner.graphs[s].outputs
             with gpu_turn(share):
                 rj = pipe.run(svc, batches[last[(id(runner), s)]], decode_impl=decode_impl)
@@ -803,15 +805,18 @@ def main():
         "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 encoder operands / f32 rest",
-                                       "split": "f32 (recurrent W_hh.h products: fp32 operands split exactly into 3 x f16, six f16-matrix-core "
-                                                "products per term, f32 accumulate; everything else f32)"}[args.precision],
+                                       # its own token, not "f32": a consumer keyed on dtype must not compare this line with an
+                                       # fp32-MFMA line of another round as like with like; `agreement_vs_f32` is always in the line
+                                       "split": "f32-split3xf16 (f32 operands and results; recurrent W_hh.h products: fp32 operands split exactly into 3 x f16, "
+                                                "six f16-matrix-core products per term, f32 accumulate; everything else f32 arithmetic)"}[args.precision],
+        "precision": args.precision,
         "data": "synthetic", "timing": timing,
         "config": {"workload": w["desc"], "batch_per_gpu": B, "global_batch": B * world,
                    "resident_batches": len(batches),
                    "launch": ("eager, one stream" if runner is None else
                               "hipGraph replay, one step in flight, its recurrent part as two half-batches side by side on two HIP "
                               "streams (cooperative launches paired on every CU)" if runner.halves else
-                              f"hipGraph replay, {runner.n_slots} independent step(s) in flight on separate HIP streams"),
+                              f"hipGraph replay, {runner.n_streams} independent step(s) in flight on separate HIP streams"),
                    "kernel_timing": ("HIP events in a separate single-stream pass" if args.graph else
                                      "HIP events inside the timed region (durations include overlap with the "
                                      "other in-flight step)"),

@@ -130,9 +130,17 @@ __device__ __forceinline__ void granule_load2_x8_x4_lat(u32x4 (&v)[8], u32x4 (&w
 
 // A failed bounded wait: the launch's own status word (zeroed by every launch) and the caller's sticky word
 // (never cleared by the library), see gnnpn_launch_opts_t.sticky_status.
-__device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsigned code) {
+constexpr int COOP_STAFFING_WORD = 8 * 256 + 8;   // in the per-device seat table (api.hip): cooperative launches that are staffing right now
+// `seats` (the per-device seat table): a launch that ends in a time-out may never take its last seat, so it leaves the
+// count of staffing launches HERE (status word 4: 1 counted -> 2 left; coop_note_staffed's own 1 -> 2 then fails, so the
+// count is decremented once whichever comes first).  Without this a failed launch stayed in the count until the host
+// polled the status, every later launch saw "another launch is staffing" and its early arrivals kept declining their
+// seats (measured with unconditional declines: 430 k -> 255-300 k problems/s) — and C-ABI / graph-replay callers never
+// got the reset at all.
+__device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsigned code, unsigned* seats = nullptr) {
     atomicOr(err, code);
     if (sticky) atomicOr(sticky, code);
+    if (seats && atomicCAS(err + 4, 1u, 2u) == 1u) atomicSub(seats + COOP_STAFFING_WORD, 1u);
 }
 
 // ---- placement by CLAIM: one workgroup per CU, groups inside one XCD, whatever the dispatcher does ------------------
@@ -152,7 +160,6 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
 // workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
 constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD seat counters, [1152,1184) arrivals, [2048,10240) CU claims
 constexpr unsigned COOP_LDS_UNITS = 640;    // a CU's 160 KB of LDS in the 256-byte units of HW_REG_LDS_ALLOC
-constexpr int COOP_STAFFING_WORD = 8 * 256 + 8;   // in the per-device seat table (api.hip): cooperative launches that are staffing right now
 constexpr int COOP_XCDCNT_OFFSET = 1024;
 constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
 constexpr int COOP_CLAIM_OFFSET = 2048;

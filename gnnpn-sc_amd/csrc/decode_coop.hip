@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
             break;
         }
     }
-    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
+    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u, seats);
 }
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {

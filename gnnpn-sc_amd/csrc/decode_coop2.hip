@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
         }
         if (abort_flag) break;
     }
-    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
+    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u, seats);
 }
 
 int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {

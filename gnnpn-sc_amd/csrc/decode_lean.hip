@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
         }
         if (abort_flag) break;
     }
-    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u);
+    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u, seats);
 }
 
 // pick_prob[b][t] = softmax of the step's window logits (+ the latent logits) at the pick = 1 / sum_j exp(v_j - v_pick):

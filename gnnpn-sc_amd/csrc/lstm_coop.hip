@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
         }
         first_tile = false;
     }
-    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u);
+    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u, seats);
 }
 
 // ---- 16-member form (opts.impl = 3): groups of 16 workgroups of 16 hidden units ------------------------------------
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets net
         }
         first_tile = false;
     }
-    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u);
+    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u, seats);
 }
 
 

@@ -257,7 +257,12 @@ class Workspaces:
         word = int(self.status[0].item())
         if word != 0:
             self.status.zero_()
-            _lib.load().gnnpn_coop_reset_staffing()      # a launch that timed out may never have left the count of staffing launches
+            # a launch that timed out leaves the count of staffing launches by itself (coop_raise); this reset is the belt to
+            # those braces — on THIS object's device, and a failure of the reset is reported with the status it hides behind
+            with torch.cuda.device(self.device):
+                rc = _lib.load().gnnpn_coop_reset_staffing()
+            if rc != 0:
+                what = f"{what} (and gnnpn_coop_reset_staffing failed: {_lib.load().gnnpn_last_error().decode('utf-8', 'replace')})"
             last = [int(b[:4].view(torch.int32).item()) if b is not None else None for b in (self._encode, self._decode)]
             detail = ""
             if word & 2:

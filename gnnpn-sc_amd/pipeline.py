@@ -143,6 +143,17 @@ class ML2PNPipeline:
             side = self._side_streams.get(rows.device)
             if side is None:
                 side = self._side_streams[rows.device] = torch.cuda.Stream(rows.device)
+            # everything both halves share is produced on the CURRENT stream before the fork: the packed / folded weights
+            # (pack kernels and host-to-device copies of a first call) and the lazily allocated workspaces would otherwise be
+            # issued on the side stream by the half that runs first in Python, with nothing ordering the other half's
+            # reads behind them
+            for net in (self.low, self.high):
+                net.actor.packed()
+                net.actor.check_precision(self.precision)
+            n_cat = rows.shape[1] // self.n_per
+            for w in ws:
+                w.encode()
+                w.decode(max(half, B - half), n_cat, self.n_per)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 out_b = two_level_greedy(self.low, self.high, rows[half:], precision=self.precision, decode_impl=decode_impl,
@@ -159,13 +170,15 @@ class ML2PNPipeline:
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
-    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None, paired_start=False):
+    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None, paired_start=False, pool=None):
         """Record one whole pass over (services, batch) into a HIP graph and return a callable that
         replays it on the CURRENT stream (one launch per step instead of ~25).  The returned dict's
         tensors are the graph's static outputs: they are overwritten by every replay.  ``ws`` is the
         private ``ops.Workspaces`` of this graph (default: a new one), so that graphs may be in flight
         at the same time on different streams (independent batches pipelined); it is frozen — the graph
-        holds its addresses — and lives as long as the returned callable."""
+        holds its addresses — and lives as long as the returned callable.  ``pool``: a graph memory pool shared with
+        other captures that are only ever replayed one after the other on ONE stream (their intermediates then share
+        memory; every capture's outputs stay private)."""
         ws = ops.new_workspaces(batch.x.device) if ws is None else ws
         all_ws = list(ws) if isinstance(ws, (tuple, list)) else [ws]
         stream = torch.cuda.Stream()
@@ -176,7 +189,7 @@ class ML2PNPipeline:
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, pool=pool):
             out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start)
         for w in all_ws:
             w.frozen = True
@@ -203,8 +216,10 @@ class ML2PNPipeline:
 
 class PipelinedRunner:
     """Throughput mode: ``slots`` independent batches in flight on ``slots`` HIP streams — or, for batches of 512 problems
-    and more, ONE batch in flight whose recurrent part runs as two half-batches side by side (``halves``); two slots with
-    recurrences of 2000 steps and more start their replays in pairs (``lockstep``).  See __init__.
+    and more, ONE batch in flight whose recurrent part runs as two half-batches side by side (``halves``: the ``slots``
+    static input / output sets then take turns on one stream); two slots with recurrences of 2000 steps and more start
+    their replays in pairs (``lockstep``).  In every mode ``n_slots`` is the reuse distance of ``submit``'s outputs.
+    See __init__.
 
     The recurrent kernels are step-latency-bound and leave most of the machine idle, so consecutive
     (independent) batches are overlapped: every slot owns one captured HIP graph of the whole pass, its
@@ -225,12 +240,18 @@ class PipelinedRunner:
         n = example_batch.n_problems
         self.halves = bool(halves) if halves is not None else (n >= 512 and int(slots) > 1 and
                                                                os.environ.get("GNNPN_PIPE_HALVES", "1") != "0")
-        self.pipe, self.services, self.n_slots = pipe, services, (1 if self.halves else max(1, int(slots)))
-        self.streams = [torch.cuda.Stream() for _ in range(self.n_slots)]
+        # ``n_slots`` = the number of static input / output sets = the reuse distance of submit()'s outputs, in EVERY mode
+        # (the half-batch mode used to collapse to one slot, and a caller following the documented rule read
+        # outputs the next replay was already overwriting).  ``n_streams`` = steps in flight: the half-batch mode keeps ONE
+        # step in flight, so its slots' graphs replay one after the other on one stream (and share one graph memory pool:
+        # their intermediates are never live together; every slot's outputs stay private).
+        self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
+        self.n_streams = 1 if self.halves else self.n_slots
+        self.streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
         # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
         # 228 k vs 221 k problems/s in fp32, 353 k vs 316 k with the split precision.
         shared = 4
-        paired = self.n_slots > 1 or self.halves      # two cooperative launches share every CU
+        paired = self.n_streams > 1 or self.halves    # two cooperative launches share every CU
         self.decode_impl = int(os.environ.get("GNNPN_PIPE_DECODE_IMPL", shared if paired else 0))
         # Placement: the cooperative kernels claim one CU per workgroup at run time (csrc/coop_common.h, coop_place), so
         # the two slots' launches share every CU one workgroup each whatever the dispatcher does; the LDS-footprint
@@ -256,13 +277,15 @@ class PipelinedRunner:
         # tail by which the two replays differ (2 % at that shape); short steps (QWS, Normal) keep running free.
         env = os.environ.get("GNNPN_PIPE_LOCKSTEP")
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
-        self.lockstep = self.n_slots == 2 and (env == "1" or (env is None and long_steps))
+        self.lockstep = self.n_streams == 2 and (env == "1" or (env is None and long_steps))
         self._open_leader, self._last_done = None, [None, None]
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
+        pool = torch.cuda.graph_pool_handle() if self.halves and self.n_slots > 1 else None
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep)
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
+                                    pool=pool)
                        for s in range(self.n_slots)]
 
     @staticmethod
@@ -296,10 +319,11 @@ class PipelinedRunner:
 
     def submit(self, batch=None):
         """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
-        consume them (or record an event) before the slot comes round again, ``slots`` submits later."""
+        consume them (or record an event on ``stream(slot)``) before the slot comes round again, ``n_slots`` submits
+        later — in every mode (half-batch mode included: there the slots alternate on one stream)."""
         s = self.count % self.n_slots
         self.count += 1
-        with torch.cuda.stream(self.streams[s]):
+        with torch.cuda.stream(self.stream(s)):
             if batch is not None:
                 dst = self.batches[s]
                 lim = ops.REQUEST_BRANCH_MAX_NODES        # the captured graph holds the one-launch GIN branch (small
@@ -318,7 +342,7 @@ class PipelinedRunner:
                 # A submission joins the leader that is waiting for a partner (and starts with it) if that leader has not
                 # finished yet — the host runs ahead of the device, so back-to-back submissions always pair —; otherwise it
                 # leads a new pair, behind whatever the other slot ran last.
-                st, lead = self.streams[s], self._open_leader
+                st, lead = self.stream(s), self._open_leader
                 if lead is not None and lead[0] != s and not lead[2].query():
                     st.wait_event(lead[1])
                     self._open_leader = None
@@ -331,14 +355,15 @@ class PipelinedRunner:
             out = self.graphs[s]()
             if self.lockstep:
                 done = torch.cuda.Event()
-                done.record(self.streams[s])
+                done.record(self.stream(s))
                 self._last_done[s] = done
                 if leader:
                     self._open_leader = (s, started, done)
         return out, s
 
     def stream(self, slot):
-        return self.streams[slot]
+        """The HIP stream slot ``slot``'s replays run on (half-batch mode: every slot's, there is one step in flight)."""
+        return self.streams[slot % self.n_streams]
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""

@@ -48,7 +48,7 @@ def _models(cfg, ds, n_services, n_cat, epoch=-1, random_init=False):
         raise FileNotFoundError(f"ML+2PN --infer for epoch {epoch}: no weights at {', '.join(missing)} "
                                 "(train them with `main.py <ds> ML|PNLow|PNHigh`, or pass --random-init for seeded random weights)")
     torch.manual_seed(0)
-    sd_ml = torch.load(p_ml, map_location="cpu") if os.path.exists(p_ml) else None
+    sd_ml = _load_ml_checkpoint(p_ml) if os.path.exists(p_ml) else None
     # the vocabulary the checkpoint was trained with (trainML builds the reference's Embedding(100, c); the synthetic
     # 1000-task configurations need larger tables)
     vocab = sd_ml["nodeEncoder.embeddings.0.weight"].shape[0] if sd_ml is not None else max(100, n_cat + 1)
@@ -63,6 +63,26 @@ def _models(cfg, ds, n_services, n_cat, epoch=-1, random_init=False):
         if os.path.exists(path):            # checkpoint format of trainPNLow.py:112-117 / trainPNHigh.py:118-129
             m.load_state_dict(torch.load(path, map_location="cpu")["model"])
     return net, low, high, K
+
+
+def _load_ml_checkpoint(path):
+    """The GNN ranker's weights as a ``state_dict``.  This build's `main.py <ds> ML` saves the state_dict; the reference
+    pickles the WHOLE module (``torch.save(self.model, ...)``, trainML.py:147), which unpickles only where its classes
+    (src.models.modelML.Net, torch_geometric 1.7.0's GINConv / GCNConv) are importable — then its state_dict is taken;
+    anything else is refused with a message that names the expected format."""
+    import torch
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    except Exception as e:        # noqa: BLE001  (unpickling a whole-module checkpoint without its classes raises many kinds)
+        raise RuntimeError(f"{path}: not loadable here ({type(e).__name__}: {e}).  Expected a state_dict of Net "
+                           "(keys 'nodeEncoder.embeddings.0.weight', ...) as `main.py <ds> ML` of this build writes it; a "
+                           "whole-module pickle of the reference (trainML.py:147) needs src.models.modelML and "
+                           "torch_geometric==1.7.0 importable — re-save it there with torch.save(model.state_dict(), path)") from e
+    if isinstance(obj, torch.nn.Module):
+        obj = obj.state_dict()
+    if not (isinstance(obj, dict) and "nodeEncoder.embeddings.0.weight" in obj):
+        raise RuntimeError(f"{path}: expected a state_dict of Net (key 'nodeEncoder.embeddings.0.weight' ...), got {type(obj).__name__}")
+    return obj
 
 
 def main(argv):

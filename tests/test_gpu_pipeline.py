@@ -270,7 +270,7 @@ def test_half_batches_side_by_side_match_the_whole_batch(dev, B, precision):
     batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=20 + i, tasks_per_problem=10), dev)
                for i in range(3)]
     runner = PipelinedRunner(pipe, svc, batches[0], slots=2, halves=True)
-    assert runner.halves and runner.n_slots == 1 and len(runner.workspaces) == 2
+    assert runner.halves and runner.n_slots == 2 and runner.n_streams == 1 and len(runner.workspaces) == 2
     keys = ("idx_low", "idx_high", "R", "actions", "action_probs", "win_low", "win_high_raw", "candidate_ids")
     got = []
     for b in batches:
@@ -283,6 +283,16 @@ def test_half_batches_side_by_side_match_the_whole_batch(dev, B, precision):
         ref = pipe.run(svc, b, decode_impl=runner.decode_impl)
         for k in keys:
             assert g[k].shape == ref[k].shape and torch.equal(g[k], ref[k]), k
+    # the documented output contract holds in this mode too: a slot's static outputs stay intact until the slot
+    # comes round again, n_slots submits later — read here, unconsumed, after the NEXT submission has run
+    out0, s0 = runner.submit(batches[1])
+    out1, s1 = runner.submit(batches[2])
+    assert s0 != s1 and out0["idx_high"].data_ptr() != out1["idx_high"].data_ptr()
+    runner.synchronize(check=True)
+    for out, b in ((out0, batches[1]), (out1, batches[2])):
+        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), k
     with pytest.raises(ops.GnnpnError):                     # nothing to put on the second stream
         pipe.run(svc, DeviceBatch.from_problems(synth.make_problem_batch(table, 16, seed=3, tasks_per_problem=10), dev),
                  ws=(ops.new_workspaces(dev), ops.new_workspaces(dev)))
@@ -553,7 +563,9 @@ def test_bench_line_contract(dev):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert base["metric"].startswith(d["metric"].split(" (")[0]) and d["unit"] == "problems/s"
-    assert d["dtype"].startswith("f32") and d["vs_baseline"] is None and d["value"] > 0       # BASELINE.md publishes no number
+    assert d["dtype"].split()[0] == "f32-split3xf16" and d["precision"] == "split"     # the default arithmetic has its own dtype token ...
+    assert d["agreement_vs_f32"]["identical_decisions"] >= 0.999                     # ... and always reports its agreement with plain f32
+    assert d["vs_baseline"] is None and d["value"] > 0                               # BASELINE.md publishes no number
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1

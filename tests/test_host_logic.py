@@ -110,6 +110,17 @@ def test_infer_weights_follow_the_epoch(tmp_path, monkeypatch):
     assert all(torch.equal(v, sd_high[k_]) for k_, v in high.state_dict().items())
     with pytest.raises(FileNotFoundError):                                          # another epoch: not these files
         cli._models(cfg, "QWS", S, T, 2)
+    # the reference writes model-{n}.pkl as a pickle of the WHOLE module (trainML.py:147): a module object is taken by its
+    # state_dict, anything that is neither is refused by name
+    torch.save(net, "solutions/ML/QWS/model-3.pkl")                                 # a whole-module pickle of an importable class
+    got = cli._load_ml_checkpoint("solutions/ML/QWS/model-3.pkl")
+    assert set(got) == set(sd_ml) and all(torch.equal(got[k_], sd_ml[k_]) for k_ in sd_ml)
+    torch.save([1, 2, 3], "solutions/ML/QWS/model-3.pkl")
+    with pytest.raises(RuntimeError, match="expected a state_dict of Net"):
+        cli._models(cfg, "QWS", S, T, 3)
+    (tmp_path / "solutions" / "ML" / "QWS" / "model-3.pkl").write_bytes(b"not a checkpoint")
+    with pytest.raises(RuntimeError, match="not loadable here"):
+        cli._models(cfg, "QWS", S, T, 3)
 
 
 def test_calc_penalties():
