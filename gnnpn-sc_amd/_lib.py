@@ -11,8 +11,9 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 3
+# GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
+LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -27,6 +28,11 @@ _SIGNATURES = {
     "gnnpn_csr_aggregate_blocks_f32": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32,
                                                c_int32, c_int32, _P, _P]),
     "gnnpn_csr_block_row_order": (c_int, [_P, c_int32, c_int32, _P, _P]),
+    "gnnpn_csr_tile_plan_geometry": (c_int, [c_int32, c_int32, _P]),
+    "gnnpn_csr_tile_plan_rows": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gnnpn_csr_tile_plan_fill": (c_int, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, c_int64, _P]),
+    "gnnpn_csr_aggregate_tiled_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_int32, c_int32,
+                                              c_int32, _P]),
     "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,
@@ -90,6 +96,13 @@ class LaunchOpts(ctypes.Structure):
     """gnnpn_launch_opts_t of include/gnnpn_hip.h (per-call implementation choice / placement / sticky status)."""
     _fields_ = [("impl", c_int32), ("lds_kb", c_int32), ("write_through", c_int32), ("paired_start", c_int32),
                 ("sticky_status", _P)]
+
+
+class TilePlanGeom(ctypes.Structure):
+    """gnnpn_tile_plan_geom_t of include/gnnpn_hip.h."""
+    _fields_ = [(n, c_int32) for n in ("n_blocks", "src_tiles", "src_tile_rows", "dst_tiles", "dst_tile_rows", "units", "wavefronts",
+                                       "passes")] + \
+               [(n, c_int64) for n in ("header_bytes", "order_bytes", "tstart_bytes", "selfw_bytes", "meta_bytes")]
 
 
 class GinLayer(ctypes.Structure):

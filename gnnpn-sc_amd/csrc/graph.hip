@@ -5,6 +5,7 @@
 // coalesced rows, 4 neighbour rows in flight per wave, accumulation strictly in CSR order with
 // separate multiply and add (the rounding of a materialised message followed by scatter_add).
 #include "common.h"
+#include "graph_lds.h"
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void csr_aggregate_kernel(
@@ -135,18 +136,6 @@ extern "C" int gnnpn_csr_aggregate_f32(const int32_t* rowptr, const int32_t* col
 // csr_aggregate_kernel.  24.7 % of the HBM roofline at 2507 x 256 copies (gather form 15.4 %); what bounds it: DESIGN.md 8.
 // Placement (speed only): the SLICE-WGs of one block get equal blockIdx % 8 (one XCD), so the two halves of every 128-B
 // line of x — read by two different slices — meet in that XCD's L2 and the (col, w) lists are fetched from HBM once.
-// value of lane L of the own group of LPR (4, 2 or 1) consecutive lanes, as a DPP quad permute (no LDS round trip)
-template <int LPR, int L>
-__device__ __forceinline__ int quad_from(int v) {
-    if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xF, 0xF, true);                 // [L,L,L,L]
-    else if constexpr (LPR == 2) return __builtin_amdgcn_update_dpp(0, v, L | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6), 0xF, 0xF, true);
-    else return v;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(4))) i32x4_u { int32_t v[4]; };     // 16 bytes at 4-byte alignment: one global_load_dwordx4
-struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
-
 // the 4 consecutive (col, w) entries at idx of one lane of a row's lane group.  SAFE = no row of the wave ends within 4
 // entries of the arrays' end: one unconditional 16-byte load per array (SGPR base + 32-bit lane offset; a lane beyond its
 // row's end re-reads the line behind it and the values are ignored).
@@ -171,50 +160,6 @@ __device__ __forceinline__ void lds_agg_fetch(const int32_t* __restrict__ col, c
                 if (HAS_W) wb[k] = w[idx + k];
             }
     }
-}
-
-// the 4 edges held by lane P of every row's lane group: each lane of the group takes (offset, weight) from there by a DPP
-// quad permute (folded into the address add) and requests its 16 bytes of the source row from LDS ...
-template <int LPR, bool HAS_W, int P>
-__device__ __forceinline__ void lds_agg_read4(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4],
-                                              int lane_off, float4 (&xv)[4], float (&wq)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        xv[k] = *reinterpret_cast<const float4*>(tile + (quad_from<LPR, P>(cc[k]) + lane_off));
-        if (HAS_W) wq[k] = __int_as_float(quad_from<LPR, P>(__float_as_int(ww[k])));
-    }
-}
-
-// ... and adds them in edge order
-template <bool HAS_W>
-__device__ __forceinline__ void lds_agg_add4(const float4 (&xv)[4], const float (&wq)[4], f32x2& a01, f32x2& a23) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        f32x2 lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
-        if (HAS_W) {
-            const f32x2 w2 = {wq[k], wq[k]};
-            lo = lo * w2;                             // -ffp-contract=off: the product is rounded before the add
-            hi = hi * w2;
-        }
-        a01 = a01 + lo;
-        a23 = a23 + hi;
-    }
-}
-
-// the first NP groups of 4 edges of a batch, as straight-line code: the reads of group p+1 are in flight under the adds of p
-template <int LPR, bool HAS_W, int NP>
-__device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, const int (&cc)[4], const float (&ww)[4],
-                                                int lane_off, f32x2& a01, f32x2& a23) {
-    float4 xa[4], xb[4];
-    float wa[4], wb[4];
-    lds_agg_read4<LPR, HAS_W, 0>(tile, cc, ww, lane_off, xa, wa);
-    if (NP > 1) lds_agg_read4<LPR, HAS_W, 1 % LPR>(tile, cc, ww, lane_off, xb, wb);
-    lds_agg_add4<HAS_W>(xa, wa, a01, a23);
-    if (NP > 2) lds_agg_read4<LPR, HAS_W, 2 % LPR>(tile, cc, ww, lane_off, xa, wa);
-    if (NP > 1) lds_agg_add4<HAS_W>(xb, wb, a01, a23);
-    if (NP > 3) lds_agg_read4<LPR, HAS_W, 3 % LPR>(tile, cc, ww, lane_off, xb, wb);
-    if (NP > 2) lds_agg_add4<HAS_W>(xa, wa, a01, a23);
-    if (NP > 3) lds_agg_add4<HAS_W>(xb, wb, a01, a23);
 }
 
 // the rows of one pass of a wave (one row per lane group of LPR lanes), all their edges, 4*LPR per batch: entry k of lane p

@@ -71,6 +71,83 @@ def csr_block_row_order(rowptr, block_rows):
     return order
 
 
+PREFER_TILED_AGGREGATE = None   # None: the tiled form (destination tile x source tile, features staged in LDS per source tile)
+#                                 for block-local graphs whose plan is valid and whose blocks exceed the whole-block form
+#                                 (> LDS_SLICE16_ROWS_MAX rows); True: wherever the plan is valid; False: never
+TILED_MIN_WORKGROUPS = 128
+_tile_plans = {}                # (id(rowptr), id(col), id(w), block_rows) -> (weak references, TilePlan)
+
+
+class TilePlan:
+    """The plan of gnnpn_csr_aggregate_tiled_f32 for one (graph, weights): tile geometry, the per-unit headers, the row
+    order, the trailing self loops and the sliced-ELL stream of (LDS offset, weight) batches — built once (three launches
+    and one host read of the batch count) and reused by every layer and call.  ``valid`` is False when some row's
+    neighbour list does not visit the source tiles in order (the sums would be taken in another order): callers then
+    keep the gather form.  ``stats``: edges, (row, edge) slots in the stream, its efficiency and the histogram of the
+    per-(row, source tile) run lengths."""
+
+    def __init__(self, rowptr, col, w, block_rows):
+        import ctypes
+        lib = _lib.load()
+        n = rowptr.numel() - 1
+        g = _lib.TilePlanGeom()
+        self.valid, self.block_rows, self.n_rows = False, int(block_rows), n
+        self.stats = {}
+        if n <= 0 or lib.gnnpn_csr_tile_plan_geometry(n, int(block_rows), ctypes.byref(g)) != 0:
+            return
+        dev = rowptr.device
+        self.geom = {k: int(getattr(g, k)) for k in ("n_blocks", "src_tiles", "src_tile_rows", "dst_tiles", "dst_tile_rows", "units",
+                                                     "wavefronts", "passes")}
+        self.header = torch.empty(g.header_bytes // 4, dtype=I32, device=dev)
+        self.order = torch.empty(g.order_bytes // 4, dtype=I32, device=dev)
+        tstart = torch.empty(g.tstart_bytes // 4, dtype=I32, device=dev)
+        self.selfw = torch.empty(g.selfw_bytes // 4, dtype=F32, device=dev)
+        meta = torch.empty(g.meta_bytes // 4, dtype=I32, device=dev)
+        check(lib.gnnpn_csr_tile_plan_rows(dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), n,
+                                           int(block_rows), dev_ptr(self.header, I32, "header"), dev_ptr(self.order, I32, "order"),
+                                           dev_ptr(tstart, I32, "tstart"), dev_ptr(self.selfw, F32, "selfw"),
+                                           dev_ptr(meta, I32, "meta"), stream_ptr()), "gnnpn_csr_tile_plan_rows")
+        m = [int(v) & 0xFFFFFFFF for v in meta.cpu().tolist()]          # the one host read: validity and the stream's size
+        hist = m[8:72]
+        self.stats = {"invalid_rows": m[0], "quads": m[1], "edges": m[2], "slots": m[3], "rows": m[4],
+                      "efficiency": (m[2] / m[3]) if m[3] else 1.0, "stream_bytes": m[1] * 512, "run_histogram": hist,
+                      "mean_run": (sum(i * h for i, h in enumerate(hist)) / max(1, sum(hist)))}
+        if m[0] != 0:
+            return
+        self.batches = torch.zeros((m[1] + 3) * 512, dtype=U8, device=dev)      # + three quads of slack for the fixed-shape loads
+        check(lib.gnnpn_csr_tile_plan_fill(dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), n, int(block_rows),
+                                           dev_ptr(self.header, I32, "header"), dev_ptr(self.order, I32, "order"),
+                                           dev_ptr(tstart, I32, "tstart"), dev_ptr(self.batches, U8, "batches"), m[1], stream_ptr()),
+              "gnnpn_csr_tile_plan_fill")
+        self.valid = True
+
+    def aggregate(self, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE):
+        x = _rows2d(x, "csr_aggregate_tiled.x")
+        C = x.shape[1]
+        y = torch.empty((self.n_rows, C), dtype=F32, device=x.device)
+        check(_lib.load().gnnpn_csr_aggregate_tiled_f32(
+            dev_ptr(self.header, I32, "header"), dev_ptr(self.order, I32, "order"), dev_ptr(self.selfw, F32, "selfw"),
+            dev_ptr(self.batches, U8, "batches"), dev_ptr(x, F32, "x"), C, dev_ptr(self_coef, F32, "self_coef", True),
+            dev_ptr(bias, F32, "bias", True), dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act,
+            dev_ptr(y, F32, "y"), C, self.n_rows, C, self.block_rows, stream_ptr()), "gnnpn_csr_aggregate_tiled_f32")
+        return y
+
+
+def csr_tile_plan(rowptr, col, w, block_rows):
+    """The cached TilePlan of (rowptr, w) — a property of the graph and its weights, like csr_block_row_order — or None
+    while a stream capture is in progress and none has been built yet (building reads the batch count back)."""
+    key = (id(rowptr), id(col), id(w) if w is not None else 0, int(block_rows))
+    hit = _tile_plans.get(key)
+    if hit is not None and hit[0]() is rowptr and hit[3]() is col and (w is None or hit[1]() is w):
+        return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    plan = TilePlan(rowptr, col, w, block_rows)
+    drop = lambda _, k=key: _tile_plans.pop(k, None)   # noqa: E731
+    _tile_plans[key] = (weakref.ref(rowptr, drop), weakref.ref(w, drop) if w is not None else None, plan, weakref.ref(col, drop))
+    return plan
+
+
 def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
     """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
     ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
@@ -81,6 +158,12 @@ def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shif
     n = rowptr.numel() - 1
     C = x.shape[1]
     y = torch.empty((n, C), dtype=F32, device=x.device)
+    if PREFER_TILED_AGGREGATE is not False and block_rows > 0 and C % 16 == 0 and n > 0 and x.data_ptr() % 16 == 0 and \
+            (PREFER_TILED_AGGREGATE or (block_rows > LDS_SLICE16_ROWS_MAX and
+                                        -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= TILED_MIN_WORKGROUPS)):
+        plan = csr_tile_plan(rowptr, col, w, block_rows)
+        if plan is not None and plan.valid:
+            return plan.aggregate(x, self_coef, bias, scale, shift, act)
     rows_max = LDS_BLOCK_ROWS_MAX if PREFER_LDS_AGGREGATE else LDS_SLICE16_ROWS_MAX
     if PREFER_LDS_AGGREGATE is not False and 0 < block_rows <= rows_max and C % 4 == 0 and n > 0:
         lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and (block_rows + 1) * 16 * c <= 160 * 1024)

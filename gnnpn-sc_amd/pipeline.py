@@ -176,9 +176,8 @@ class ML2PNPipeline:
         tensors are the graph's static outputs: they are overwritten by every replay.  ``ws`` is the
         private ``ops.Workspaces`` of this graph (default: a new one), so that graphs may be in flight
         at the same time on different streams (independent batches pipelined); it is frozen — the graph
-        holds its addresses — and lives as long as the returned callable.  ``pool``: a graph memory pool shared with
-        other captures that are only ever replayed one after the other on ONE stream (their intermediates then share
-        memory; every capture's outputs stay private)."""
+        holds its addresses — and lives as long as the returned callable.  ``pool``: a graph memory pool to capture
+        into (torch.cuda.graph's argument; NOT for graphs whose outputs must survive each other's replays)."""
         ws = ops.new_workspaces(batch.x.device) if ws is None else ws
         all_ws = list(ws) if isinstance(ws, (tuple, list)) else [ws]
         stream = torch.cuda.Stream()
@@ -243,8 +242,7 @@ class PipelinedRunner:
         # ``n_slots`` = the number of static input / output sets = the reuse distance of submit()'s outputs, in EVERY mode
         # (the half-batch mode used to collapse to one slot, and a caller following the documented rule read
         # outputs the next replay was already overwriting).  ``n_streams`` = steps in flight: the half-batch mode keeps ONE
-        # step in flight, so its slots' graphs replay one after the other on one stream (and share one graph memory pool:
-        # their intermediates are never live together; every slot's outputs stay private).
+        # step in flight, so its slots' graphs replay one after the other on one stream.
         self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
         self.n_streams = 1 if self.halves else self.n_slots
         self.streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
@@ -282,10 +280,11 @@ class PipelinedRunner:
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
-        pool = torch.cuda.graph_pool_handle() if self.halves and self.n_slots > 1 else None
+        # (every graph keeps its OWN memory pool, also the half-batch mode's two that never run together: in a shared pool
+        # the second capture places its outputs where the first keeps intermediates, and the first graph's next replay
+        # writes over them — measured: garbage in a slot's outputs one submission later)
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
-                                    pool=pool)
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep)
                        for s in range(self.n_slots)]
 
     @staticmethod

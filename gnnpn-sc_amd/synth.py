@@ -70,7 +70,8 @@ class ProblemBatch:
 
 def make_service_table(n_cat, n_services, seed=0, degree=32, graph="random"):
     """q0,q1 ~ U(0,1); q2,q3 ~ U(0.9,1); E_s = S*degree directed edges as symmetric
-    pairs with uniform endpoints and U(0,1] weights."""
+    pairs with uniform endpoints and U(0,1] weights.  graph: "random" (pairs in the order drawn), "scan" (the same kind of
+    pairs in the reference's emission order), anything else: no edges."""
     rng = np.random.default_rng(seed)
     sizes = category_sizes(n_services, n_cat)
     cat_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
@@ -85,6 +86,20 @@ def make_service_table(n_cat, n_services, seed=0, degree=32, graph="random"):
         a, b = a[keep], b[keep]
         src = np.stack([a, b], 1).reshape(-1)
         dst = np.stack([b, a], 1).reshape(-1)
+        w = (1.0 - rng.random(src.shape[0], dtype=np.float32)).astype(np.float32)
+        edge_index = np.stack([src, dst]).astype(np.int64)
+    elif graph == "scan":
+        # the same random pairs in the order the reference's co-occurrence scan emits them (src/loadData.py:56-65:
+        # for i < j in lexicographic order, edge i -> j then j -> i; a pair occurs once): every row's in-edges then come
+        # sorted by source, which is what the tiled aggregate (gnnpn_csr_aggregate_tiled_f32) needs
+        n_pairs = n_services * degree // 2
+        a = rng.integers(0, n_services, n_pairs)
+        b = rng.integers(0, n_services, n_pairs)
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        key = np.unique(lo[lo != hi] * np.int64(n_services) + hi[lo != hi])
+        lo, hi = key // n_services, key % n_services
+        src = np.stack([lo, hi], 1).reshape(-1)
+        dst = np.stack([hi, lo], 1).reshape(-1)
         w = (1.0 - rng.random(src.shape[0], dtype=np.float32)).astype(np.float32)
         edge_index = np.stack([src, dst]).astype(np.int64)
     else:

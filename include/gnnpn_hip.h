@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 3   /* 3: gnnpn_csr_aggregate_blocks_f32 takes a row order; gnnpn_csr_block_row_order */
+#define GNNPN_ABI_VERSION 4   /* 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -96,6 +96,52 @@ int gnnpn_csr_aggregate_blocks_f32(const int32_t* rowptr, const int32_t* col, co
  * A property of the graph (one launch per graph, reused by every layer and call); block_rows <= 16384, else GNNPN_E_UNSUP.
  * No counterpart in the reference: scheduling input of gnnpn_csr_aggregate_blocks_f32. */
 int gnnpn_csr_block_row_order(const int32_t* rowptr, int32_t n_rows, int32_t block_rows, int32_t* row_order, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The aggregate for block-local graphs of ANY block size up to 20472 rows, node features staged in LDS one SOURCE TILE at a
+ * time (destination tile x source tile; csrc/graph_tiled.hip).  A workgroup owns (block, destination tile of <= 2560 rows,
+ * 16-channel slice), keeps its destination rows' running sums in registers and walks the block's source tiles (<= 2559 rows)
+ * in order.  Valid — and bit-identical to gnnpn_csr_aggregate_f32 — for graphs in which every row's neighbour list visits
+ * the source tiles in non-decreasing order, an optional trailing self loop excepted (the reference's service graph:
+ * src/loadData.py:56-65 emits the pairs in lexicographic order, add_remaining_self_loops appends the loops; the check is
+ * part of the plan).  The edge lists are consumed from a PLAN built once per (graph, weights): a sliced-ELL stream in the
+ * order the wavefronts read it (quads of 512 B: [16 rows][4] LDS offsets + [16 rows][4] weights).
+ *
+ *   1. gnnpn_csr_tile_plan_geometry: tile counts and the byte sizes of the plan's arrays (host only).
+ *   2. gnnpn_csr_tile_plan_rows: fills header / order / tstart / selfw / meta (device).  Read meta back (stream-ordered):
+ *        meta[0] = rows that break the rule above (0: the graph qualifies; otherwise use gnnpn_csr_aggregate_f32),
+ *        meta[1] = quads in the stream (allocate (meta[1] + 3) * 512 bytes: the kernel's fixed-shape loads read up to three
+ *        quads past the last one), meta[2] = edges in the stream, meta[3] = (row, edge) slots the stream holds = 64 * meta[1]
+ *        (efficiency = meta[2] / meta[3]), meta[4] = rows, meta[8..72) = histogram of the per-(row, source tile) run lengths
+ *        (last bin: >= 63).
+ *   3. gnnpn_csr_tile_plan_fill: writes the stream (w == NULL: weight 1).
+ *   4. gnnpn_csr_aggregate_tiled_f32 per layer: same epilogue arguments as gnnpn_csr_aggregate_f32; C a multiple of 16.
+ * GNNPN_E_UNSUP (nothing enqueued) where the form does not apply.  Replaces: GCNConv.propagate over the batched service
+ * graph, src/models/modelML.py:152-155 (torch_geometric 1.7.0). */
+typedef struct gnnpn_tile_plan_geom {
+    int32_t n_blocks;       /* ceil(n_rows / block_rows) */
+    int32_t src_tiles;      /* source tiles per block, <= 8 */
+    int32_t src_tile_rows;  /* rows per source tile, <= 2559: a 16-channel slice of a tile and one all-zero row fill a CU's 160 KB of LDS */
+    int32_t dst_tiles;      /* destination tiles per block */
+    int32_t dst_tile_rows;  /* rows per destination tile, a multiple of 16, <= 2560 */
+    int32_t units;          /* dst_tile_rows / 16: groups of 16 rows that walk their edge lists in step (one wavefront) */
+    int32_t wavefronts;     /* per workgroup: 16 */
+    int32_t passes;         /* units per wavefront and source tile, <= 10 */
+    int64_t header_bytes;   /* int32[2] per (block, destination tile, source tile, unit): first quad, quads of 4 edges per row */
+    int64_t order_bytes;    /* int32 per (block, destination tile, position): block-local destination row, -1 = none */
+    int64_t tstart_bytes;   /* int32 per (row, source tile + 1): the row's first edge in every source tile */
+    int64_t selfw_bytes;    /* float per (block, destination tile, position), like order: weight of the row's trailing self loop where the epilogue adds it, NaN = nothing to add */
+    int64_t meta_bytes;     /* 512 */
+} gnnpn_tile_plan_geom_t;
+int gnnpn_csr_tile_plan_geometry(int32_t n_rows, int32_t block_rows, gnnpn_tile_plan_geom_t* out);
+int gnnpn_csr_tile_plan_rows(const int32_t* rowptr, const int32_t* col, const float* w, int32_t n_rows, int32_t block_rows,
+                             int32_t* header, int32_t* order, int32_t* tstart, float* selfw, int32_t* meta, void* stream);
+int gnnpn_csr_tile_plan_fill(const int32_t* col, const float* w, int32_t n_rows, int32_t block_rows, const int32_t* header,
+                             const int32_t* order, const int32_t* tstart, void* batches, int64_t n_quads, void* stream);
+int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_t* order, const float* selfw, const void* batches,
+                                  const float* x, int64_t ldx, const float* self_coef, const float* bias,
+                                  const float* scale, const float* shift, int act, float* y, int64_t ldy,
+                                  int32_t n_rows, int32_t C, int32_t block_rows, void* stream);
 
 /* GCN symmetric normalisation on a destination-major CSR that already contains one self-loop
  * entry per node (add_remaining_self_loops, fill 1): deg[i] = sum of w_raw over row i (CSR order),

@@ -500,6 +500,109 @@ def test_csr_aggregate_picks_the_lds_form_for_block_local_graphs(dev):
         ops.PREFER_LDS_AGGREGATE = saved
 
 
+def _scan_graph_copies(S, copies, degree, seed, dev, ragged=False, self_loops=True):
+    """Block-diagonal copies of a graph in the reference's emission order (rows sorted by source; self loops appended by
+    gcn_csr, or none), optionally with a shorter last block."""
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd import graph
+    table = synth.make_service_table(5, S, seed, degree=degree, graph="scan")
+    ei, ea = torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr)
+    csr = graph.gcn_csr(ei, ea, S) if self_loops else graph.csr_by_destination(ei, S, ea)
+    nnz = csr.col.numel()
+    n = copies * S - (S // 3 if ragged else 0)
+    rp_full = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])])
+    col_full = torch.cat([csr.col.long() + c * S for c in range(copies)])
+    w_full = csr.w.repeat(copies)
+    keep = (col_full < n)[: int(rp_full[n])]
+    seg = torch.repeat_interleave(torch.arange(n), (rp_full[1:n + 1] - rp_full[:n]))
+    rp = torch.zeros(n + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(torch.bincount(seg[keep], minlength=n), 0)
+    return rp.to(dev), col_full[: int(rp_full[n])][keep].int().to(dev), w_full[: int(rp_full[n])][keep].to(dev), n
+
+
+@pytest.mark.parametrize("S,copies,C,degree,weighted,self_coef,ragged,self_loops", [
+    (300, 3, 256, 8, True, False, False, True),        # one source tile, one destination tile, 2 passes
+    (2507, 2, 64, 32, True, False, False, True),       # the QWS table: one tile of 2507 rows, 10 passes
+    (2600, 3, 32, 12, True, False, True, True),        # two source tiles, two destination tiles, ragged last block
+    (5000, 2, 48, 32, True, False, False, True),       # the 1000-task shape: 2 x 2 tiles
+    (5000, 1, 16, 6, False, True, False, False),       # no weights, GIN self term, rows without a trailing self loop
+    (7000, 1, 32, 20, True, False, False, True),       # 3 x 3 tiles
+    (20000, 1, 16, 32, True, False, False, True),      # the 2000-task shape: 8 x 8 tiles
+])
+def test_csr_aggregate_tiled_equals_gather(dev, S, copies, C, degree, weighted, self_coef, ragged, self_loops):
+    """gnnpn_csr_aggregate_tiled_f32 (destination tile x source tile, the source tile's 16-channel slice staged in LDS, the
+    edge lists consumed from the plan's sliced-ELL stream) against gnnpn_csr_aggregate_f32 on block-diagonal copies of a
+    graph in the reference's edge order: the same bits, with the plan's own accounting checked against the CSR."""
+    ops = _ops()
+    rp, col, w, n = _scan_graph_copies(S, copies, degree, 3, dev, ragged, self_loops)
+    w = w if weighted else None
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(n, C, generator=g).to(dev)
+    bias, scale, shift = (torch.randn(C, generator=g).to(dev) for _ in range(3))
+    eps = torch.tensor([0.125], device=dev) if self_coef else None
+    want = ops.csr_aggregate(rp, col, w, x, self_coef=eps, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)   # gather form
+    x2 = torch.randn(n, C, generator=g).to(dev)
+    want2 = ops.csr_aggregate(rp, col, w, x2)
+    last = (rp[1:] - 1).clamp(min=0).long()
+    loop_row = (col[last] == torch.arange(n, device=dev)).logical_and(rp[1:] > rp[:-1])      # rows that end with their self loop
+    plan = ops.csr_tile_plan(rp, col, w, S)
+    assert plan.valid, plan.stats
+    st, gm = plan.stats, plan.geom
+    assert gm["src_tiles"] == -(-S // 2559) and gm["dst_tiles"] == -(-S // 2560)
+    # the stream holds every edge but the trailing self loops of rows OUTSIDE the last source tile (the epilogue adds those)
+    own_tile = (torch.arange(n, device=dev) % S) // gm["src_tile_rows"]
+    n_epilogue = int((loop_row & (own_tile != gm["src_tiles"] - 1)).sum())
+    assert st["edges"] == col.numel() - n_epilogue and st["rows"] == n
+    assert st["slots"] >= st["edges"] and st["quads"] * 64 == st["slots"] and sum(st["run_histogram"]) == n * gm["src_tiles"]
+    got = plan.aggregate(x, eps, bias, scale, shift, ops.ACT_RELU)
+    assert torch.equal(got, want)
+    assert ops.csr_tile_plan(rp, col, w, S) is plan                               # cached per (graph, weights)
+    assert torch.equal(plan.aggregate(x2), want2)                                 # a second layer on the same plan, no epilogue
+
+
+def test_csr_aggregate_tiled_skewed_degrees_and_invalid_graphs(dev):
+    """Heavy-tailed degrees on the tiled form — empty rows, hub rows with more than a thousand edges inside one source tile
+    (more quads than the sort key holds: only the order of the units depends on it) — and the validity check: a graph whose
+    rows are not in source order is refused by the plan (ops.csr_aggregate then keeps the gather form)."""
+    ops = _ops()
+    S, C = 5200, 32
+    g = torch.Generator().manual_seed(11)
+    deg = torch.randint(0, 9, (S,), generator=g)
+    heavy = torch.randperm(S, generator=g)[:40]
+    deg[heavy] = torch.randint(200, 700, (40,), generator=g)
+    deg[heavy[:3]] = torch.tensor([2300, 1500, 1100])
+    deg[torch.randperm(S, generator=g)[: S // 10]] = 0
+    rows = []
+    for i in range(S):
+        c = torch.randperm(S, generator=g)[: int(deg[i])].sort().values       # sorted sources, no duplicates
+        c = c[c != i]
+        rows.append(torch.cat([c, torch.tensor([i])]) if i % 7 else c)         # most rows end with their self loop
+    rp = torch.zeros(S + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(torch.tensor([r.numel() for r in rows]), 0)
+    col = torch.cat(rows).int().to(dev)
+    rp = rp.to(dev)
+    w = (torch.rand(col.numel(), generator=g) + 0.25).to(dev)
+    x = torch.randn(S, C, generator=g).to(dev)
+    want = ops.csr_aggregate(rp, col, w, x)
+    plan = ops.csr_tile_plan(rp, col, w, S)
+    assert plan.valid and plan.stats["run_histogram"][63] >= 40
+    assert torch.equal(plan.aggregate(x), want)
+    # the same lists with one row's sources out of order: invalid, and the dispatcher keeps the gather form
+    col_bad = col.clone()
+    r = int(heavy[5])
+    lo, hi = int(rp[r]), int(rp[r + 1])
+    col_bad[lo:hi - 1] = col_bad[lo:hi - 1].flip(0)
+    bad = ops.csr_tile_plan(rp, col_bad, w, S)
+    assert not bad.valid and bad.stats["invalid_rows"] == 1
+    saved = ops.PREFER_TILED_AGGREGATE
+    try:
+        ops.PREFER_TILED_AGGREGATE = True
+        assert torch.equal(ops.csr_aggregate(rp, col_bad, w, x, block_rows=S), ops.csr_aggregate(rp, col_bad, w, x))
+        assert torch.equal(ops.csr_aggregate(rp, col, w, x, block_rows=S), want)       # valid plan: the tiled form, same bits
+    finally:
+        ops.PREFER_TILED_AGGREGATE = saved
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation

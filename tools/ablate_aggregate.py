@@ -1,0 +1,56 @@
+"""Where the tiled aggregate's time goes: timing-only builds of the library (results wrong by design) with one part of the
+kernel removed each — compiled here (no GPU needed), timed on the GPU box.
+
+    python tools/ablate_aggregate.py build                 # compiles gnnpn-sc_amd/build/ablate/libgnnpn_hip_abl<bits>.so
+    python tools/ablate_aggregate.py run [S:copies ...]    # on the GPU: times every build on the tiled form
+
+bits (csrc/graph_lds.h): 1 no LDS reads, 2 one add instead of 2 multiplies + 2 adds per (edge, lane), 4 no tile fill,
+8 no result stores, 16 no stream loads.
+"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gnnpn-sc_amd")
+OUT = os.path.join(PKG, "build", "ablate")
+VARIANTS = [0, 1, 2, 3, 4, 8, 12, 16, 19, 31]
+
+
+def build():
+    sys.path.insert(0, PKG)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gnnpn_build", os.path.join(PKG, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    os.makedirs(OUT, exist_ok=True)
+    objs = [os.path.join(PKG, "build", s.replace(".hip", ".o")) for s in b.SOURCES]
+    for v in VARIANTS:
+        mine = []
+        for src in ("graph.hip", "graph_tiled.hip"):
+            o = os.path.join(OUT, f"{src[:-4]}_abl{v}.o")
+            subprocess.run(["hipcc"] + b.FLAGS + [f"-DGNNPN_AGG_ABLATE={v}", "-c", os.path.join(b.CSRC, src), "-o", o], check=True)
+            mine.append(o)
+        rest = [o for o in objs if os.path.basename(o) not in ("graph.o", "graph_tiled.o")]
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(OUT, f"libgnnpn_hip_abl{v}.so")] + rest + mine, check=True)
+        print("built", v, flush=True)
+
+
+def run(configs):
+    for v in VARIANTS:
+        env = dict(os.environ, GNNPN_LIB=os.path.join(OUT, f"libgnnpn_hip_abl{v}.so"), PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_aggregate.py"), "--configs", ",".join(configs),
+                            "--forms", "tiled", "--no-check"], env=env, capture_output=True, text=True)
+        for ln in r.stdout.splitlines():
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            print(json.dumps({"ablate": v, "S": d["S"], "copies": d["copies"], "tiled_ms": d.get("tiled", {}).get("ms")}), flush=True)
+        if r.returncode != 0:
+            print(json.dumps({"ablate": v, "error": r.stderr[-400:]}), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    else:
+        run(sys.argv[2:] or ["2507:256", "5000:128", "20000:8"])

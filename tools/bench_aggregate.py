@@ -3,8 +3,10 @@ holds B copies of the service table (trainML.py:109-114, modelML.py:145-156), i.
 layer.  Times both forms on the same operands and checks that they agree bit for bit:
   gather : gnnpn_csr_aggregate_f32        (one wave per destination row, source rows gathered from L2)
   lds    : gnnpn_csr_aggregate_blocks_f32 (north star "node features staged in LDS": one workgroup per (copy, channel slice))
+  tiled  : gnnpn_csr_aggregate_tiled_f32  (destination tile x source tile, one source tile's slice in LDS at a time, the edge
+           lists from the plan's sliced-ELL stream; needs rows in source order: --graph scan, the reference's emission order)
 
-    python tools/bench_aggregate.py [--configs S:copies,...] [--degree 32]
+    python tools/bench_aggregate.py [--configs S:copies,...] [--degree 32] [--graph scan|random]
 
 Algorithmic bytes per launch: 2*N*C*4 + E*(4+4) + (N+1)*4, N = copies*S, C = 256.
 """
@@ -18,6 +20,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="2507:256,2507:64,5000:128,5000:32,10000:32,20000:8")
 ap.add_argument("--degree", type=int, default=32)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--graph", default="scan", help="scan: pairs in the reference's emission order (rows sorted by source); random: as drawn")
+ap.add_argument("--forms", default="gather,lds,tiled", help="gather, lds, tiled")
+ap.add_argument("--no-check", action="store_true", help="timing-only (ablation) builds: do not compare the forms")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 F32, I32 = torch.float32, torch.int32
@@ -52,7 +57,7 @@ def timed(fn, reps):
 out = []
 for cfg in a.configs.split(","):
     S, copies = (int(v) for v in cfg.split(":"))
-    table = synth.make_service_table(47, S, 0, degree=a.degree)
+    table = synth.make_service_table(47, S, 0, degree=a.degree, graph=a.graph)
     csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
     nnz = csr.col.numel()
     rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
@@ -65,16 +70,33 @@ for cfg in a.configs.split(","):
     bias = torch.randn(C, device=dev, generator=g)
     scale, shift = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
     ops.PREFER_LDS_AGGREGATE = False
+    ops.PREFER_TILED_AGGREGATE = False
     gather = lambda: ops.csr_aggregate(rp, col, norm, x, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)   # noqa: E731
     alg = 2 * N * C * 4 + nnz * copies * 8 + (N + 1) * 4
-    rec = {"S": S, "copies": copies, "rows": N, "channels": C, "nnz": nnz * copies, "algorithmic_bytes": alg}
-    ms_g = timed(gather, a.reps)
-    rec["gather"] = {"ms": round(ms_g, 4), "GBps": round(alg / ms_g / 1e6, 1), "frac_of_8TBps": round(alg / ms_g / 8e9, 4)}
-    if S <= ops.LDS_BLOCK_ROWS_MAX:
+    rec = {"S": S, "copies": copies, "rows": N, "channels": C, "nnz": nnz * copies, "algorithmic_bytes": alg, "graph": a.graph}
+    forms = a.forms.split(",")
+    want = gather()
+    if "gather" in forms:
+        ms_g = timed(gather, a.reps)
+        rec["gather"] = {"ms": round(ms_g, 4), "GBps": round(alg / ms_g / 1e6, 1), "frac_of_8TBps": round(alg / ms_g / 8e9, 4)}
+    if "tiled" in forms:
+        plan = ops.csr_tile_plan(rp, col, norm, S)
+        st = plan.stats
+        rec["tiled"] = {"plan_valid": plan.valid, **({"geometry": plan.geom} if plan.stats else {}),
+                        "stream": {k: st.get(k) for k in ("edges", "slots", "efficiency", "stream_bytes", "mean_run")},
+                        "run_histogram": st.get("run_histogram")}
+        if plan.valid:
+            tiled = lambda: plan.aggregate(x, None, bias, scale, shift, ops.ACT_RELU)   # noqa: E731
+            assert a.no_check or torch.equal(tiled(), want), f"tiled form differs from the gather form at S={S}"
+            ms_t = timed(tiled, a.reps)
+            alg_t = 2 * N * C * 4 + st["stream_bytes"] + N * 8          # what this form reads instead of the CSR: stream, row order, self-loop weights
+            rec["tiled"].update(ms=round(ms_t, 4), GBps=round(alg / ms_t / 1e6, 1), frac_of_8TBps=round(alg / ms_t / 8e9, 4),
+                                bytes_this_form_moves=alg_t, bit_identical_to_gather=not a.no_check)
+        del plan
+    if S <= ops.LDS_BLOCK_ROWS_MAX and "lds" in forms:
         order = ops.csr_block_row_order(rp, S)                              # once per graph
         lds = lambda: blocks_form(rp, col, norm, x, bias, scale, shift, S, order)   # noqa: E731
         lds_unordered = lambda: blocks_form(rp, col, norm, x, bias, scale, shift, S)   # noqa: E731
-        want = gather()
         assert torch.equal(lds(), want), f"LDS-staged form differs from the gather form at S={S}"
         assert torch.equal(lds_unordered(), want), f"LDS-staged form (rows as they come) differs from the gather form at S={S}"
         ms_l, ms_u = timed(lds, a.reps), timed(lds_unordered, a.reps)
