@@ -264,14 +264,18 @@ REAL_STDOUT = 1
 
 def batched_aggregate_roofline(table, B, dev, reps=10):
     """The GCN aggregate on the reference's own batching of the service graph (B block-diagonal copies of the table,
-    trainML.py:109-114, modelML.py:145-156): one layer, 256 channels, through ops.csr_aggregate (the LDS-staged kernel where
-    a copy's 16-channel slice fits the LDS, else the L2 gather kernel).  NOT part of the step (the step uses the cached
+    trainML.py:109-114, modelML.py:145-156): one layer, 256 channels, through ops.csr_aggregate (the tiled kernel — one source
+    tile's 16-channel slice in LDS at a time — where the graph's plan is valid, as it is for the reference's edge order).  NOT part of the step (the step uses the cached
     service embedding): reported in ``kernels`` with "in_step": false so that the north star's aggregate roofline has a
     number in this line.  HIP events on the stream the launches go to (torch's current stream), best of 3 rounds."""
     from gnnpn_sc_amd import graph, ops
+    import gnnpn_sc_amd.synth as synth
     S = table.n_services
     copies = max(1, min(B, 256, 700_000 // S))
-    csr = graph.gcn_csr(torch.from_numpy(table.edge_index), torch.from_numpy(table.edge_attr), S)
+    # the table's graph with its edge list in the order the reference's scan emits it (src/loadData.py:56-65: rows sorted by
+    # source) — the order the reference's own service graphs have and the tiled aggregate needs
+    ei, ea = synth.scan_order(table.edge_index, table.edge_attr)
+    csr = graph.gcn_csr(torch.from_numpy(ei), torch.from_numpy(ea), S)
     nnz = csr.col.numel()
     rp = torch.cat([csr.rowptr[:-1].long() + c * nnz for c in range(copies)] + [torch.tensor([copies * nnz])]).int().to(dev)
     col = torch.cat([csr.col.long() + c * S for c in range(copies)]).int().to(dev)
@@ -291,8 +295,11 @@ def batched_aggregate_roofline(table, B, dev, reps=10):
         if rnd:
             best = min(best, e0.elapsed_time(e1) / reps)
     work = 2 * N * C * 4 + copies * nnz * 8 + (N + 1) * 4             # SURVEY section 8d per graph, times the copies
-    form = "lds-staged" if S <= ops.LDS_SLICE16_ROWS_MAX and copies * (C // 16) >= ops.LDS_MIN_WORKGROUPS else "l2-gather"
-    return {"kernel": "csr_aggregate_batched", "in_step": False, "form": form, "copies": copies, "rows": N, "edges": copies * nnz,
+    plan = ops._tile_plans.get((id(rp), id(col), id(norm), S))
+    form = ("tiled" if plan is not None and plan[2].valid else
+            "lds-staged" if S <= ops.LDS_SLICE16_ROWS_MAX and copies * (C // 16) >= ops.LDS_MIN_WORKGROUPS else "l2-gather")
+    return {"kernel": "csr_aggregate_batched", "in_step": False, "form": form, "edge_order": "reference scan order (src/loadData.py:56-65)",
+            "copies": copies, "rows": N, "edges": copies * nnz,
             "launches_per_step": 0, "avg_ms": round(best, 4), "bound": "hbm", "achieved": round(work / best / 1e6, 3),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(work / best / 1e6 / PEAK_HBM_GBS, 5)}
 

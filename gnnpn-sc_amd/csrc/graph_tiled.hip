@@ -306,7 +306,11 @@ __device__ __forceinline__ void fill_tile(float* __restrict__ tile, const float*
 // wave-instruction is slower than staging the same pieces through registers; two workgroups of 8 wavefronts per CU on
 // half-size source tiles — 0.82 / 1.07 ms: twice the source tiles cost more slots in the stream than the overlap of one
 // workgroup's fills and stores with the other's gather buys; touching a unit's stream lines ahead of time with one
-// 4-byte load per 128-byte line — slower: the touches are as many L2 -> L1 line transfers again.)
+// 4-byte load per 128-byte line — slower: the touches are as many L2 -> L1 line transfers again; ONE loop over a
+// wavefront's batches, unrolled over three register sets (two pairs of stream loads in flight instead of one), the
+// passes not unrolled and the unit's sums swapped into fixed registers by a switch — 0.71 / 0.87 / 0.56 ms: the scalar
+// control per unit (switches, header look-ups, tile-switch events) costs more than the deeper look-ahead saves, and at
+// 2.5 quads per unit (20000 rows) it dominates.)
 template <int PASSES, int HREGS>      // HREGS: registers that hold the headers, 64 (source tile, pass) entries each
 __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int2* __restrict__ header, const int32_t* __restrict__ order, const float* __restrict__ selfw,

@@ -198,7 +198,14 @@ class Net(nn.Module):
             for lp in p["nolin"]:
                 xs = torch.ops.gnnpn.linear(xs, lp["w"], lp["bias"], lp["a"], lp["s"], ACT_RELU)
             return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                             # :164
-        norm = torch.ops.gnnpn.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
+        # the normalised edge weights are a function of the graph alone: computed once per CSR object (GCNConv recomputes the
+        # same values in every forward) — which also keeps the tensor, and with it the aggregate's per-(graph, weights) plan
+        # (ops.csr_tile_plan), the same from call to call
+        norm = getattr(svc_csr, "_gcn_norm", None)
+        if norm is None:
+            norm = torch.ops.gnnpn.gcn_norm(svc_csr.rowptr, svc_csr.col, svc_csr.w)
+            if not torch.cuda.is_current_stream_capturing():      # (memory of a capture's private pool must not outlive the graph)
+                svc_csr._gcn_norm = norm
         for lp in p["gcn"]:                                                                     # :152-155
             xw = torch.ops.gnnpn.linear(xs, lp["wt"])                                                       # transform first
             xs = torch.ops.gnnpn.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],

@@ -71,9 +71,12 @@ def csr_block_row_order(rowptr, block_rows):
     return order
 
 
-PREFER_TILED_AGGREGATE = None   # None: the tiled form (destination tile x source tile, features staged in LDS per source tile)
-#                                 for block-local graphs whose plan is valid and whose blocks exceed the whole-block form
-#                                 (> LDS_SLICE16_ROWS_MAX rows); True: wherever the plan is valid; False: never
+PREFER_TILED_AGGREGATE = None   # None: the tiled form (destination tile x source tile, one source tile's slice staged in LDS at a
+#                                 time, edge lists from the plan's stream) for block-local graphs whose plan is valid — rows in
+#                                 source-tile order, the reference's own edge order — and that have enough (block, destination
+#                                 tile, slice) workgroups to fill the chip: measured faster than both other forms from 2507 to
+#                                 20000 rows per block (profiles/r04_csr_aggregate_roofline.json); True: wherever the plan is
+#                                 valid; False: never
 TILED_MIN_WORKGROUPS = 128
 _tile_plans = {}                # (id(rowptr), id(col), id(w), block_rows) -> (weak references, TilePlan)
 
@@ -151,16 +154,16 @@ def csr_tile_plan(rowptr, col, w, block_rows):
 def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
     """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
     ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
-    records it): the LDS-staged form gnnpn_csr_aggregate_blocks_f32 is then used when a block fits the LDS with
-    16-channel slices and there are enough (block, slice) workgroups to fill the chip (``ops.PREFER_LDS_AGGREGATE``
-    forces it on wherever it fits, or off); bit-identical either way."""
+    records it).  With enough workgroups to fill the chip: the tiled form gnnpn_csr_aggregate_tiled_f32 where the graph's
+    plan is valid (rows in source-tile order; ``PREFER_TILED_AGGREGATE``), else the whole-block LDS form
+    gnnpn_csr_aggregate_blocks_f32 when a block fits the LDS with 16-channel slices (``PREFER_LDS_AGGREGATE``), else the
+    gather form; bit-identical every way."""
     x = _rows2d(x, "csr_aggregate.x")
     n = rowptr.numel() - 1
     C = x.shape[1]
     y = torch.empty((n, C), dtype=F32, device=x.device)
     if PREFER_TILED_AGGREGATE is not False and block_rows > 0 and C % 16 == 0 and n > 0 and x.data_ptr() % 16 == 0 and \
-            (PREFER_TILED_AGGREGATE or (block_rows > LDS_SLICE16_ROWS_MAX and
-                                        -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= TILED_MIN_WORKGROUPS)):
+            (PREFER_TILED_AGGREGATE or -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= TILED_MIN_WORKGROUPS):
         plan = csr_tile_plan(rowptr, col, w, block_rows)
         if plan is not None and plan.valid:
             return plan.aggregate(x, self_coef, bias, scale, shift, act)

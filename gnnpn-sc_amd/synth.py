@@ -108,6 +108,24 @@ def make_service_table(n_cat, n_services, seed=0, degree=32, graph="random"):
     return ServiceTable(n_cat, cat_ptr, qos.astype(np.float64), edge_index, w)
 
 
+def scan_order(edge_index, edge_attr):
+    """The same undirected weighted graph with its edge list in the order the reference's co-occurrence scan emits it
+    (src/loadData.py:56-65: for i < j in lexicographic order, i -> j then j -> i; a pair occurs once — the first weight of a
+    repeated directed edge is kept): every row's in-edges come sorted by source."""
+    src, dst = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    n = int(max(src.max(), dst.max())) + 1 if src.size else 0
+    key = src.astype(np.int64) * n + dst
+    _, first = np.unique(key, return_index=True)                 # one weight per directed edge
+    w_of = dict(zip(key[first].tolist(), np.asarray(edge_attr)[first].tolist()))
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    pk = np.unique(lo[lo != hi].astype(np.int64) * n + hi[lo != hi])
+    lo, hi = pk // n, pk % n
+    s2 = np.stack([lo, hi], 1).reshape(-1)
+    d2 = np.stack([hi, lo], 1).reshape(-1)
+    w2 = np.array([w_of.get(int(a) * n + int(b), w_of.get(int(b) * n + int(a))) for a, b in zip(s2, d2)], np.float32)
+    return np.stack([s2, d2]).astype(np.int64), w2
+
+
 def make_problem_batch(table, n_problems, seed=1, tasks_per_problem=10, lo_range=(0.0, 0.9)):
     """SURVEY.md §8d "Problem": 1 request node + n_t task nodes, chain edges in both directions;
     request floats [1,.3,1,1,.3,1]; task floats [1,lo,hi,1,lo,hi], lo ~ U(lo_range), hi = 1."""

@@ -603,6 +603,30 @@ def test_csr_aggregate_tiled_skewed_degrees_and_invalid_graphs(dev):
         ops.PREFER_TILED_AGGREGATE = saved
 
 
+def test_csr_aggregate_dispatch_prefers_the_tiled_form_on_the_reference_edge_order(dev):
+    """ops.csr_aggregate with the block_rows promise on copies of a graph in the reference's emission order: the tiled form runs
+    (its plan is built once and cached), results equal the gather form's; through Net.service_embedding the normalised weights
+    — and so the plan — are computed once per CSR object."""
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    S, copies, C = 2507, 9, 256
+    rp, col, w_raw, n = _scan_graph_copies(S, copies, 32, 5, dev)
+    w = ops.gcn_norm(rp, col, w_raw)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(1)).to(dev)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(2)).to(dev)
+    want = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU)                        # no promise: gather form
+    before = len(ops._tile_plans)
+    got = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)           # 9 x 1 x 16 = 144 workgroups: tiled
+    assert len(ops._tile_plans) == before + 1 and ops.csr_tile_plan(rp, col, w, S).valid
+    assert torch.equal(got, want)
+    saved = ops.PREFER_TILED_AGGREGATE
+    try:
+        ops.PREFER_TILED_AGGREGATE = False
+        assert torch.equal(ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S), want)   # whole-block LDS form
+    finally:
+        ops.PREFER_TILED_AGGREGATE = saved
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation
