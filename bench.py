@@ -793,12 +793,12 @@ def main():
             k["traffic"] = t2.get(k["kernel"])
     if world == 1 and args.graph and not args.no_kernel_timers:
         agg = batched_aggregate_roofline(table, B, dev)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_csr_aggregate_pmc_traffic.json")) as f:
+        try:     # the committed PMC passes of tools/r04_aggregate_profiles.sh, keyed by shape (rows per copy x copies) and kernel
+            with open(os.path.join(ROOT, "profiles", "r04_csr_aggregate_pmc_traffic.json")) as f:
                 pm = json.load(f)
-            agg["traffic"] = (pm["kernels"]["lds" if agg["form"] == "lds-staged" else "gather"]["traffic"]
-                              if (agg["rows"], agg["edges"]) == (641792, 21173504) else None)
-        except (OSError, ValueError, KeyError):
+            kname = {"tiled": "csr_aggregate_tiled_kernel", "l2-gather": "csr_aggregate_kernel"}.get(agg["form"])
+            agg["traffic"] = pm["shapes"][f"{agg['rows'] // agg['copies']}x{agg['copies']}"][kname]["traffic"]
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
             agg["traffic"] = None
     roof = None
     if kernels:

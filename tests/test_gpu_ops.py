@@ -471,8 +471,9 @@ def test_csr_aggregate_lds_staged_equals_gather(dev, S, copies, C, weighted, sel
 
 
 def test_csr_aggregate_picks_the_lds_form_for_block_local_graphs(dev):
-    """ops.csr_aggregate with the caller's block_rows promise: the LDS-staged kernel where a block takes 16-channel slices
-    and there are enough (block, slice) workgroups, the gather kernel otherwise or when forced — the same bits every way."""
+    """ops.csr_aggregate with the caller's block_rows promise: the tiled kernel where the plan is valid, the whole-block
+    LDS-staged kernel where a block takes 16-channel slices and there are enough (block, slice) workgroups, the gather
+    kernel otherwise or when forced — the same bits every way."""
     import gnnpn_sc_amd.synth as synth
     from gnnpn_sc_amd import graph
     ops = _ops()
@@ -485,19 +486,25 @@ def test_csr_aggregate_picks_the_lds_form_for_block_local_graphs(dev):
     w = ops.gcn_norm(rp, col, csr.w.repeat(copies).to(dev))
     x = torch.randn(copies * S, C, generator=torch.Generator().manual_seed(1)).to(dev)
     b = torch.randn(C, generator=torch.Generator().manual_seed(2)).to(dev)
-    saved = ops.PREFER_LDS_AGGREGATE
+    saved, saved_t = ops.PREFER_LDS_AGGREGATE, ops.PREFER_TILED_AGGREGATE
     try:
-        ops.PREFER_LDS_AGGREGATE = False
-        want = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)
-        ops.PREFER_LDS_AGGREGATE = None                               # default: 9 blocks x 16 slices = 144 workgroups -> LDS form
+        ops.PREFER_LDS_AGGREGATE = ops.PREFER_TILED_AGGREGATE = False
+        want = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)          # both LDS forms off: gather
+        assert (id(rp), id(col), id(w), S) not in ops._tile_plans and id(rp) not in ops._row_orders
+        ops.PREFER_LDS_AGGREGATE = ops.PREFER_TILED_AGGREGATE = None  # defaults: 9 blocks x 16 slices = 144 workgroups
         got = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)
-        assert id(rp) in ops._row_orders                              # the LDS form ran (it computed and cached the row order)
+        # blocks of ONE source tile (<= 2559 rows) qualify for the tiled form in any edge order: it runs first
+        assert ops.csr_tile_plan(rp, col, w, S).valid and id(rp) not in ops._row_orders
+        assert torch.equal(got, want)
+        ops.PREFER_TILED_AGGREGATE = False                            # without it: the whole-block LDS form
+        got = ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S)
+        assert id(rp) in ops._row_orders                              # (it computed and cached the row order)
         assert torch.equal(got, want)
         ops.PREFER_LDS_AGGREGATE = True
         assert torch.equal(ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU, block_rows=S), want)
         assert torch.equal(ops.csr_aggregate(rp, col, w, x, bias=b, act=ops.ACT_RELU), want)      # no promise: gather form
     finally:
-        ops.PREFER_LDS_AGGREGATE = saved
+        ops.PREFER_LDS_AGGREGATE, ops.PREFER_TILED_AGGREGATE = saved, saved_t
 
 
 def _scan_graph_copies(S, copies, degree, seed, dev, ragged=False, self_loops=True):
