@@ -361,22 +361,37 @@ class CombinatorialRL(nn.Module):
 
 
 @torch.no_grad()
-def two_level_greedy(low, high, inputs, fold=None, precision="f32", decode_impl=0, lds_kb=0, write_through=False, ws=None,
+def default_precision(low, high, fold=None, sampling=False, decode_impl=0):
+    """The arithmetic of the two recurrent W_hh.h products when the caller does not choose: the exact three-piece split
+    ("split": fp32 in, fp32 out, no operand bit dropped, error bound and measured error below the fp32 matrix chain's,
+    identical selections on every pinned problem, 1.4-1.5 x the throughput — DESIGN.md section 12, and what bench.py
+    measures) wherever its kernels apply — the cooperative, folded, greedy form: hidden size 256, windows of at most 16
+    candidates, no category embedding, no general attention — and the fp32 matrix cores ("f32") everywhere else."""
+    la, ha = low.actor, high.actor
+    fits = all(a.hidden_size == 256 and a.serNumber <= 16 and a.embedding_size == 0 and not a.general for a in (la, ha))
+    folded = FOLD_INPUT_PROJECTION if fold is None else bool(fold)
+    return "split" if fits and folded and not sampling and decode_impl != 1 else "f32"      # (decode_impl 1: the streaming form)
+
+
+def two_level_greedy(low, high, inputs, fold=None, precision=None, decode_impl=0, lds_kb=0, write_through=False, ws=None,
                      sample_high_seed=None, paired_start=False):
     """The inference harness of trainPNHigh.py:138-139 as one device-resident call: both encoders in
     ONE launch (they are independent), both decoders in ONE launch (High biased by Low's window
     logits, one step behind), QoS reward.  Returns dict(idx_low, idx_high [B,T] int32, R [B], actions [B,T,8],
     action_probs [B,T], win_low, win_high_raw [B,T,K]) — the High decision is taken on
     win_high_raw + win_low (modelPN.py:216).
-    precision: "f32" (default here) | "split" (both W_hh.h products from fp32 operands split EXACTLY into three fp16 pieces,
-    six products per term on the fp16 matrix cores, fp32 accumulate: no operand bit dropped, error bound below the fp32
-    chain's) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
+    precision: None (default: ``default_precision`` — "split" wherever its kernels apply, else "f32") | "f32" (fp32 matrix
+    cores) | "split" (both W_hh.h products from fp32 operands split EXACTLY into three fp16 pieces, six products per term
+    on the fp16 matrix cores, fp32 accumulate: no operand bit dropped, error bound below the fp32 chain's, DESIGN.md
+    section 12) | "f16" (encoder operands in plain fp16: opt-in reduced precision).
     sample_high_seed: the High level DRAWS its picks from that stream instead of taking the argmax — the forward of the
     PNHigh training step (trainPNHigh.py:83-84: Low greedy -> latent, High sample='sample'); the Low level stays greedy.
     decode_impl / lds_kb / write_through / paired_start / ws: per-call launch options of the two recurrent kernels (ops.lstm_encode,
     ops.pointer_decode): which decoder build, LDS-footprint placement control, hand-off form, whose workspaces."""
     inputs = inputs.contiguous()
     la, ha = low.actor, high.actor
+    if precision is None:
+        precision = default_precision(low, high, fold, sample_high_seed is not None, decode_impl)
     if la.general or ha.general or la.embedding_size != 0 or ha.embedding_size != 0:
         # 'Bahdanau' attention / glimpses / the category embedding (embeddingTag=1): one net per call
         if sample_high_seed is not None or precision != "f32":

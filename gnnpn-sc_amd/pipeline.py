@@ -93,9 +93,12 @@ def half_batch_split(n_problems):
 class ML2PNPipeline:
     """net: modelML.Net; low/high: modelPN.CombinatorialRL (levels "Low"/"High")."""
 
-    def __init__(self, net, low, high, n_per, precision="f32"):
+    def __init__(self, net, low, high, n_per, precision=None):
+        from .modelPN import default_precision
         self.net, self.low, self.high, self.n_per = net, low, high, n_per
-        self.precision = precision       # "f16": opt-in fp16-operand encoder (not parity-exact)
+        # None: modelPN.default_precision — the exact split wherever its kernels apply (what bench.py measures), else fp32;
+        # "f16": opt-in fp16-operand encoder (not parity-exact)
+        self.precision = default_precision(low, high) if precision is None else precision
         self.cache_service_embedding = True   # False: re-evaluate the GCN branch in every pass (round-1 behaviour)
         self._side_streams = {}
 
