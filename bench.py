@@ -553,12 +553,16 @@ def main():
     bucket = args.gather_every if args.gather_every > 0 else (8 if B * T * K <= 256 * 235 * 2 else 1)
     stages = {}                                                 # (runner, slot) -> {"buf": [2 x [bucket,B,T]], "cur", "fill", "out": [2], "work": [2]}
 
-    def step(i, runner=runner):
+    cur = {"runner": runner, "degraded": None}                  # the headline runner may be replaced by its degraded form (below)
+
+    def step(i, runner=None):
         """One step.  At N > 1 the single collective of the path — the all-gather of the selected indices — is issued
         asynchronously behind the slot's decode: the process group's own stream carries it over xGMI while the slot's
         stream goes straight on to its next step; the slot only waits for it (stream-side) right before the replay that
         would overwrite the gathered buffer, two steps later."""
         j = i % len(batches)
+        serial = cur["degraded"] is not None and (runner is None or runner is cur["runner"])
+        runner = cur["runner"] if runner is None else runner
         if runner is not None:
             s = runner.count % runner.n_slots
             key = (id(runner), s)
@@ -585,10 +589,18 @@ def main():
                 st["fill"] += 1
                 if st["fill"] == bucket:
                     flush_bucket(st)
+                    if serial:                                   # degraded rank: the slot's next launches wait for the collective
+                        for k in (0, 1):
+                            if st["work"][k] is not None:
+                                st["work"][k].wait()
+                                st["work"][k] = None
             return out["idx_high"], out["R"]
         if use_dist:
             with torch.cuda.stream(stream):
                 gathers[key] = gdist.all_gather_indices_async(out["idx_high"], gathers.get(key, (None, None))[0])
+                if serial and gathers[key][1] is not None:
+                    gathers[key][1].wait()
+                    gathers[key] = (gathers[key][0], None)
             return gathers[key][0], out["R"]
         return out["idx_high"], out["R"]
 
@@ -624,6 +636,7 @@ def main():
         """The contract's timed region — barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks —
         repeated until --min-time seconds have been measured (every rank sees the same maxima, so they stop together)."""
         rounds, total, i0, res = [], 0.0, args.warmup, None
+        timed_rounds.local = []
 
         def one_round():
             nonlocal i0, res
@@ -637,7 +650,9 @@ def main():
             torch.cuda.synchronize()
             gdist.barrier(world)
             i0 += args.steps
-            return gdist.max_over_ranks(time.perf_counter() - t0, dev, world)
+            local = time.perf_counter() - t0
+            timed_rounds.local.append(local)
+            return gdist.max_over_ranks(local, dev, world)
 
         # UNTIMED settling rounds behind the W warm-up steps (more warm-up, same shape as the timed rounds): with the driver's
         # `--warmup 5` the first timed round ran 10-13 % slower than the rest (2.9 ms of work do not bring the clocks up and the
@@ -650,6 +665,7 @@ def main():
             if len(settle) >= 3 and all(abs(settle[-k] - settle[-k - 1]) <= 0.02 * settle[-k] for k in (1, 2)):
                 break
         timed_rounds.settle = len(settle)
+        timed_rounds.local = []
         while True:
             dt = one_round()
             rounds.append(dt)
@@ -670,19 +686,72 @@ def main():
 
     gc.collect()
     gc.disable()                     # no collector pauses inside the timed region or the timing pass
-    for i in range(args.warmup):
-        step(i)
-    if os.environ.get("GNNPN_BENCH_DEBUG") and runner is not None:
-        torch.cuda.synchronize()
-        print("[debug] after warm-up:", [(int(x.status[0]), int(x.encode()[:4].view(torch.int32).item())) for x in runner.workspaces],
-              file=sys.stderr, flush=True)
-    timers.enabled = not args.graph
-    rounds, (idx, R) = timed_rounds(step)
-    timers.enabled = False
+
+    # A cooperative launch that reports a failed inter-workgroup hand-off (bounded spin: its outputs are invalid) voids the
+    # measurement it happened in.  At N = 1 that used to end the process; at N = 8 one such launch on one rank would lose the
+    # whole scaling line.  Now the RANK it happened on switches, in this process (no exec, no restart), to a degraded form —
+    # one step in flight, the placement-independent write-through hand-off in every cooperative launch, the all-gather waited
+    # for on the slot's stream before the next launch (no collective kernel beside a staffing window) — and every rank
+    # repeats the phase (the collectives of a phase are counted the same on all ranks); the line then carries
+    # "degraded": {...} and the per-rank record says which rank.  rc != 0 only if a rank fails in the degraded form too.
+    def any_rank(flag):
+        return gdist.max_over_ranks(1.0 if flag else 0.0, dev, world) > 0 if world > 1 else bool(flag)
+
+    def degrade(word, phase):
+        if cur["degraded"] is not None:
+            raise SystemExit(f"rank {rank}: hand-off status {word:#x} in the degraded form too ({phase}): no valid measurement")
+        print(f"[bench] rank {rank}: hand-off status {word:#x} during {phase}: switching to the degraded form "
+              "(one step in flight, write-through hand-off, serialised collective)", file=sys.stderr, flush=True)
+        cur["degraded"] = {"rank": rank, "status": word, "phase": phase, "form": "slots=1, write_through=1, collective serialised"}
+        for d in (stages, gathers, last):
+            d.clear()
+        with gpu_turn(share):
+            cur["runner"] = PipelinedRunner(pipe, svc, batch, slots=1, halves=False, write_through=True)
+
+    force_fail = os.environ.get("GNNPN_BENCH_FORCE_DEGRADE")           # test hook: pretend the first status poll of that phase failed
+    if force_fail and int(os.environ.get("GNNPN_BENCH_FORCE_DEGRADE_RANK", rank)) != rank:   # ... on that rank only
+        force_fail = None
+    rounds = idx = R = None
+    for attempt in range(3):
+        for i in range(args.warmup):
+            step(i)
+        finish_gathers()
+        bad = cur["runner"].poll() if cur["runner"] is not None else 0
+        if force_fail == "warmup" and attempt == 0 and cur["runner"] is not None:
+            bad |= 0x40
+        if os.environ.get("GNNPN_BENCH_DEBUG") and cur["runner"] is not None:
+            print("[debug] after warm-up:", bad, [w.placement() for w in cur["runner"].workspaces], file=sys.stderr, flush=True)
+        if any_rank(bad):
+            if bad:
+                degrade(bad, "warm-up")
+            continue
+        timers.enabled = not args.graph
+        rounds, (idx, R) = timed_rounds(step)
+        timers.enabled = False
+        bad = cur["runner"].poll() if cur["runner"] is not None else 0
+        if force_fail == "timed" and attempt == 0 and cur["runner"] is not None:
+            bad |= 0x40
+        if any_rank(bad):
+            if bad:
+                degrade(bad, "timed rounds")
+            rounds = None
+            continue
+        break
+    if rounds is None:
+        raise SystemExit(f"rank {rank}: no clean measurement in three attempts")
+    runner = cur["runner"]
     elapsed, timing = summarise(rounds)
-    if runner is not None:
-        runner.synchronize(check=True)   # sticky status of every launch of the timed region: a timed-out hand-off voids the run
     ops.check_status(dev)
+    # per-rank record (every rank contributes; rank 0 prints): this rank's own step time, whether it degraded, and the placement
+    # counters of its slots' last encoder launches (members placed, seats off their canonical CU, declined seats)
+    lr = sorted(timed_rounds.local)
+    mine = {"rank": rank, "ms_per_step_local": round(lr[len(lr) // 2] / args.steps * 1e3, 4) if lr else None,
+            "degraded": cur["degraded"], "placement_last_launch": [w.placement() for w in runner.workspaces] if runner is not None else None}
+    per_rank = [mine]
+    if world > 1:
+        import torch.distributed as td
+        per_rank = [None] * world
+        td.all_gather_object(per_rank, mine)
     # self-check: every slot's (overlapped) result equals a single-stream run of the same kernels on the same batch
     decode_impl = runner.decode_impl if runner is not None else 0
     with gpu_turn(share):
@@ -764,12 +833,13 @@ def main():
             step(i, runner_s)
         rounds_s, _ = timed_rounds(lambda i: step(i, runner_s))
         el_s, timing_s = summarise(rounds_s)
-        runner_s.synchronize(check=True)
+        bad_s = runner_s.poll()                    # the second line is not worth the first: a failed hand-off here is recorded, not fatal
         out_s = runner_s.graphs[0].outputs
         with gpu_turn(share):
             ref_s = pipe.run(svc, batches[last[(id(runner_s), 0)]], decode_impl=decode_impl)
         same = (out_s["actions"] == ref_s["actions"]).all(-1)
         other_line = {"precision": other, "arithmetic": PREC_TEXT[other],
+                      **({"INVALID_hand_off_status": bad_s} if bad_s else {}),
                       "value": round(world * B * args.steps / el_s, 2), "unit": "problems/s",
                       "ms_per_step": round(el_s / args.steps * 1e3, 4), "timing": timing_s,
                       f"agreement_vs_{args.precision}": {
@@ -857,6 +927,9 @@ def main():
                       if share else {})},
         "roofline": roof, "kernels": kernels + ([agg] if world == 1 and args.graph and not args.no_kernel_timers else []),
     }
+    line["per_rank"] = per_rank
+    if any(r.get("degraded") for r in per_rank if r):
+        line["degraded"] = [r["degraded"] for r in per_rank if r and r.get("degraded")]
     if agreement is not None:
         line["agreement_vs_f32"] = agreement
     if other_line is not None:

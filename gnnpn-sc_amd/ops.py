@@ -337,6 +337,27 @@ class Workspaces:
             ws = self._decode = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return ws
 
+    def poll(self):
+        """Synchronise the device, return the sticky status word and clear it (0: every launch since the last poll / check was
+        fine) — the non-raising form of ``check`` for callers that have a degraded mode to fall back to (bench.py at N > 1)."""
+        torch.cuda.synchronize(self.device)
+        word = int(self.status[0].item())
+        if word != 0:
+            self.status.zero_()
+            with torch.cuda.device(self.device):
+                _lib.load().gnnpn_coop_reset_staffing()
+        return word
+
+    def placement(self):
+        """Placement counters of this object's LAST encoder launch (the launch's own status area, zeroed before every launch):
+        members placed, seats taken off their canonical CU by the reserve, early arrivals that declined a seat because of their
+        LDS position (csrc/coop_common.h) — diagnosis only; synchronises."""
+        torch.cuda.synchronize(self.device)
+        if self._encode is None:
+            return None
+        w = self._encode[:16].view(torch.int32).tolist()
+        return {"members_placed": w[1], "off_canonical_seats": w[2], "declined_seats": w[3]}
+
     def check(self, what="cooperative kernel"):
         """Synchronise the device and raise if any launch since the last check reported a failed hand-off."""
         torch.cuda.synchronize(self.device)

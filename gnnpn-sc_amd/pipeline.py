@@ -128,7 +128,7 @@ class ML2PNPipeline:
                                                      batch.present, batch.global_bounds, self.n_per)
 
     @torch.no_grad()
-    def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None, paired_start=False):
+    def run(self, services, batch, decode_impl=0, lds_kb=0, ws=None, paired_start=False, write_through=False):
         """One pass.  decode_impl / lds_kb / paired_start / ws: launch options of the recurrent kernels (modelPN.two_level_greedy;
         paired_start: the caller starts these launches together with a partner's — half-batches do by construction).
         ``ws`` = a PAIR of workspaces: the recurrent part runs as two half-batches side by side, the second on a side
@@ -160,20 +160,20 @@ class ML2PNPipeline:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 out_b = two_level_greedy(self.low, self.high, rows[half:], precision=self.precision, decode_impl=decode_impl,
-                                         lds_kb=lds_kb, ws=ws[1], paired_start=True)
+                                         lds_kb=lds_kb, ws=ws[1], paired_start=True, write_through=write_through)
             out_a = two_level_greedy(self.low, self.high, rows[:half], precision=self.precision, decode_impl=decode_impl,
-                                     lds_kb=lds_kb, ws=ws[0], paired_start=True)
+                                     lds_kb=lds_kb, ws=ws[0], paired_start=True, write_through=write_through)
             cur.wait_stream(side)
             for v in out_b.values():
                 v.record_stream(cur)
             out = {k: torch.cat([out_a[k], out_b[k]]) for k in out_a}
         else:
             out = two_level_greedy(self.low, self.high, rows, precision=self.precision, decode_impl=decode_impl,
-                                   lds_kb=lds_kb, ws=ws, paired_start=paired_start)
+                                   lds_kb=lds_kb, ws=ws, paired_start=paired_start, write_through=write_through)
         out.update(scores=scores, pn_inputs=rows, candidate_ids=ids)
         return out
 
-    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None, paired_start=False, pool=None):
+    def capture(self, services, batch, warmup=2, decode_impl=0, lds_kb=0, ws=None, paired_start=False, pool=None, write_through=False):
         """Record one whole pass over (services, batch) into a HIP graph and return a callable that
         replays it on the CURRENT stream (one launch per step instead of ~25).  The returned dict's
         tensors are the graph's static outputs: they are overwritten by every replay.  ``ws`` is the
@@ -187,12 +187,12 @@ class ML2PNPipeline:
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for _ in range(warmup):          # allocate workspaces / pack weights outside the capture
-                self.run(services, batch, decode_impl, lds_kb, ws, paired_start)
+                self.run(services, batch, decode_impl, lds_kb, ws, paired_start, write_through)
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=pool):
-            out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start)
+            out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start, write_through)
         for w in all_ws:
             w.frozen = True
 
@@ -232,7 +232,7 @@ class PipelinedRunner:
     tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
     """
 
-    def __init__(self, pipe, services, example_batch, slots=2, halves=None):
+    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=False):
         # Batches of 512 problems and more: ONE batch in flight, its recurrent part as two half-batches side by side
         # (ML2PNPipeline.run with a pair of workspaces).  A cooperative launch has one workgroup per CU and two of them
         # fill a CU's registers, so nothing else runs beside a co-resident pair; with two WHOLE batches in flight on two
@@ -286,8 +286,12 @@ class PipelinedRunner:
         # (every graph keeps its OWN memory pool, also the half-batch mode's two that never run together: in a shared pool
         # the second capture places its outputs where the first keeps intermediates, and the first graph's next replay
         # writes over them — measured: garbage in a slot's outputs one submission later)
+        # write_through: the placement-independent hand-off form (agent-scope write-through granule stores) in every cooperative
+        # launch of this runner — the degraded mode bench.py falls back to when a launch reported a failed hand-off
+        self.write_through = bool(write_through)
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep)
+                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
+                                    write_through=self.write_through)
                        for s in range(self.n_slots)]
 
     @staticmethod
@@ -369,7 +373,17 @@ class PipelinedRunner:
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
-        return self.pipe.run(self.services, self.batches[slot], decode_impl=self.decode_impl)   # one launch per kernel, whole batch
+        return self.pipe.run(self.services, self.batches[slot], decode_impl=self.decode_impl, write_through=self.write_through)   # one launch per kernel, whole batch
+
+    def poll(self):
+        """Wait for every slot's stream; the OR of the slots' sticky status words since the last poll / check, cleared — 0: no
+        launch reported a failed hand-off.  The non-raising form of ``synchronize(check=True)``."""
+        for st in self.streams:
+            st.synchronize()
+        word = 0
+        for w in self.workspaces:
+            word |= w.poll()
+        return word
 
     def synchronize(self, check=True):
         """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a

@@ -573,6 +573,21 @@ def test_bench_line_contract(dev):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["processes"] >= 1 and cb["configurations"] and cb["usable_cpus"] >= cb["cores"] >= 1
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["degraded"] is None and "degraded" not in d
+    assert all(p["members_placed"] == 256 for p in pr[0]["placement_last_launch"])            # 32 groups x 8 members per slot
+    assert d["timing"]["untimed_settling_rounds"] == 0                                        # --min-time 0: the contract's bare region
+    # a hand-off status during the timed rounds (forced) does not end the run: this rank switches, in process, to the degraded
+    # form — one step in flight, write-through hand-off, the collective (RCCL, world 1) waited for before the next launch — the
+    # phase is repeated and the line says so
+    env_d = dict(env, GNNPN_BENCH_FORCE_DEGRADE="timed", GNNPN_FORCE_DIST="1")
+    rd = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--min-time", "0.05",
+                         "--no-split-line", "--no-cpu-baseline", "--no-kernel-timers"], capture_output=True, text=True, timeout=600,
+                        env=env_d, cwd=root)
+    assert rd.returncode == 0, rd.stderr[-2000:]
+    dd = json.loads([ln for ln in rd.stdout.splitlines() if ln.strip()][-1])
+    assert dd["degraded"][0]["phase"] == "timed rounds" and dd["degraded"][0]["status"] == 0x40 and dd["per_rank"][0]["degraded"]
+    assert dd["value"] > 0
     # the self-launching multi-rank entry, FOUR ranks on this one GPU over gloo (launch path only: rank environment, port,
     # rank-0-only stdout, NUMA binding, all-gather shape [N * B, T]; the box allows six GPU processes, pytest is one of them;
     # the N = 8 logic is rehearsed with eight gloo ranks on the CPU in tests/test_host_logic.py) — weak, then strong scaling
@@ -587,3 +602,12 @@ def test_bench_line_contract(dev):
         d2 = json.loads(out2[0])
         assert d2["n_gpus"] == 4 and d2["config"]["global_batch"] == gb == 4 * d2["config"]["batch_per_gpu"]
         assert "rank0_cpu_affinity" in d2["config"] and "NOT_A_MEASUREMENT" in d2["config"]
+        assert [p["rank"] for p in d2["per_rank"]] == [0, 1, 2, 3] and all(p["ms_per_step_local"] > 0 for p in d2["per_rank"])
+    # ... and with ONE of the four ranks reporting a hand-off status after the warm-up: that rank degrades, every rank repeats
+    # the phase (the collectives of a phase are counted the same on all ranks), the line names the rank
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--min-time", "0",
+                         "--no-cpu-baseline", "--no-split-line", "--no-kernel-timers", "--batch", "32"], capture_output=True, text=True,
+                        timeout=900, env=dict(env2, GNNPN_BENCH_FORCE_DEGRADE="warmup", GNNPN_BENCH_FORCE_DEGRADE_RANK="2"), cwd=root)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    d3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.strip()][-1])
+    assert [x["rank"] for x in d3["degraded"]] == [2] and [bool(p["degraded"]) for p in d3["per_rank"]] == [False, False, True, False]
