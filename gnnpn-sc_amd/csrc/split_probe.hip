@@ -83,3 +83,29 @@ extern "C" int gnnpn_recurrent_product_f32(const float* whh_packed, const float*
     GNNPN_CHECK_LAUNCH("recurrent_product_f32");
     return GNNPN_OK;
 }
+
+// ---- test hook: a stand-in for a collective's kernel beside the cooperative launches ------------------------------------
+// An RCCL ring kernel at world size 8 holds a few dozen CUs' LDS and wave slots for tens of microseconds, every step, on a
+// stream of its own — the one thing the placement of the cooperative kernels (coop_common.h: claims, seats, LDS positions)
+// has never met on this one-GPU box, where RCCL at world size 1 is a copy.  `n_workgroups` workgroups of 256 threads each
+// hold `lds_bytes` of LDS for `hold_us` microseconds (a sleeping spin on s_memrealtime: no memory traffic) and leave.
+namespace {
+__global__ __launch_bounds__(256) void lds_interferer_kernel(unsigned ticks, unsigned* __restrict__ sink) {
+    extern __shared__ unsigned held[];
+    held[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (held[threadIdx.x] == 0xFFFFFFFFu && sink) *sink = 1u;      // keeps the allocation alive; never true
+}
+}  // namespace
+
+extern "C" int gnnpn_debug_lds_interferer(int32_t n_workgroups, int32_t lds_bytes, int32_t hold_us, void* stream) {
+    GNNPN_REQUIRE(n_workgroups > 0 && n_workgroups <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && hold_us >= 0 && hold_us <= 100000,
+                  "debug_lds_interferer: bad arguments");
+    if (hipFuncSetAttribute((const void*)lds_interferer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        GNNPN_FAIL(GNNPN_E_LAUNCH, "debug_lds_interferer: cannot reserve %d B of LDS", lds_bytes);
+    hipLaunchKernelGGL(lds_interferer_kernel, dim3((unsigned)n_workgroups), dim3(256), (unsigned)lds_bytes, static_cast<hipStream_t>(stream),
+                       (unsigned)hold_us * 100u, static_cast<unsigned*>(nullptr));
+    GNNPN_CHECK_LAUNCH("debug_lds_interferer");
+    return GNNPN_OK;
+}

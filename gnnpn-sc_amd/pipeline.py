@@ -299,16 +299,18 @@ class PipelinedRunner:
         return (b.x, b.wf_csr.rowptr, b.wf_csr.col, b.seg_ptr, b.local_bounds, b.present, b.global_bounds)
 
     @classmethod
-    def _clone(cls, b):
+    def _clone(cls, b, host=False):
         """A copy of the batch whose seven tensors are views into ONE allocation (``_arena``, 256-byte aligned pieces): a
         batch that was packed the same way (``pack``) moves into a slot's static inputs with one copy instead of seven —
-        at a 0.55 ms step seven 5 us copy kernels in front of every replay are 3 % of the slot's cycle."""
+        at a 0.55 ms step seven 5 us copy kernels in front of every replay are 3 % of the slot's cycle.  ``host``: the
+        arena in PINNED host memory (``pack_host``): the same single copy, now host-to-device."""
         fields = cls._fields(b)
         offs, total = [], 0
         for t in fields:
             offs.append(total)
             total += (t.numel() * t.element_size() + 255) // 256 * 256
-        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=b.x.device)
+        arena = (torch.empty(max(total, 256), dtype=torch.uint8, pin_memory=True) if host else
+                 torch.empty(max(total, 256), dtype=torch.uint8, device=b.x.device))
         views = []
         for t, o in zip(fields, offs):
             v = arena[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
@@ -323,6 +325,13 @@ class PipelinedRunner:
         """The batch in the slots' own memory layout: ``submit`` moves such a batch with a single device-to-device copy."""
         return self._clone(batch)
 
+    def pack_host(self, batch):
+        """The batch (host or device tensors) in the slots' layout in ONE pinned host allocation: ``submit`` moves it into a
+        slot's static inputs with a single asynchronous host-to-device copy on the slot's stream — the reference's per-batch
+        ``inputs.cuda()`` (src/models/trainPNHigh.py:134-136) as one copy instead of seven.  The caller must not rewrite the
+        arena before that copy has run (record an event on ``stream(slot)``)."""
+        return self._clone(batch, host=True)
+
     def submit(self, batch=None):
         """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
         consume them (or record an event on ``stream(slot)``) before the slot comes round again, ``n_slots`` submits
@@ -336,8 +345,9 @@ class PipelinedRunner:
                 if 0 < dst.max_nodes <= lim and not 0 < batch.max_nodes <= lim:   # workflow graphs) or the layered kernels
                     raise ops.GnnpnError(f"PipelinedRunner: the captured graph holds the one-launch GIN branch (graphs of <= "
                                          f"{lim} nodes); this batch has max_nodes = {batch.max_nodes}")
-                if getattr(batch, "_layout", None) is not None and batch._layout == dst._layout and batch._arena.device == dst._arena.device:
-                    dst._arena.copy_(batch._arena, non_blocking=True)          # packed alike: one copy
+                if getattr(batch, "_layout", None) is not None and batch._layout == dst._layout and \
+                        (batch._arena.device == dst._arena.device or (batch._arena.device.type == "cpu" and batch._arena.is_pinned())):
+                    dst._arena.copy_(batch._arena, non_blocking=True)          # packed alike: one copy (device-to-device, or pinned host to device)
                 else:
                     for a, b in zip(self._fields(dst), self._fields(batch)):
                         if a.shape != b.shape:

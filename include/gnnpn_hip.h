@@ -511,6 +511,12 @@ int gnnpn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
  * evaluated on an array so that tests can measure them against the CPU's libm-grade functions. */
 int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t n, void* stream);
 
+/* Test hook: a stand-in for a collective's kernel beside the cooperative launches — n_workgroups workgroups of 256 threads hold
+ * lds_bytes of LDS each for hold_us microseconds (sleeping spin, no memory traffic) on `stream`.  What an 8-rank RCCL ring kernel
+ * does to the placement of the cooperative kernels cannot be seen on a one-GPU box (RCCL at world size 1 is a copy); the soak
+ * tests run the two-slot pipeline beside this. */
+int gnnpn_debug_lds_interferer(int32_t n_workgroups, int32_t lds_bytes, int32_t hold_us, void* stream);
+
 /* ES-WOA fine-tuning of P compositions in one launch (one wavefront per problem).  Replaces `ESWOA.__init__` +
  * `ESWOA.start` of src/baselines/WOA.py:8-162 (the step after the ML+2PN path); the caller
  * (gnnpn-sc_amd/WOA.py) does the reference's host-side preparation: 5-decimal rounding of the QoS tuples (:13-26) and

@@ -540,6 +540,82 @@ def test_soak_two_slots(dev, precision):
     assert _lib.load().gnnpn_coop_staffing_count() == 0     # 8,000 cooperative launches later nobody is left in the count of staffing launches
 
 
+@pytest.mark.parametrize("shape", ["qws_two_slots", "synth4_half_batches"])
+def test_soak_beside_a_collective_shaped_interferer(dev, shape):
+    """What an 8-rank RCCL ring kernel does to the placement of the cooperative launches cannot be seen on a one-GPU box (RCCL
+    at world size 1 is a copy), so a stand-in runs beside the pipeline: every step, on a third stream, 8-32 workgroups that
+    hold 64-96 KB of LDS each for 20-50 us (gnnpn_debug_lds_interferer), at random phases — beside two free-running slots at
+    the QWS shape and beside the paired half-batches of a 512-problem batch at the 1000-task shape.  No launch reports a
+    failed hand-off and every step's outputs equal the single-stream run's; the throughput lost is measured with a burst beside
+    EVERY step and beside every 8th (the cadence of bench.py's bucketed all-gather) and recorded (profiles/r04_interferer_soak.json)."""
+    import json
+    import os
+    import random
+    import time
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import _lib
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B, n_t, steps = (47, 2507, 5, 256, 10, 600) if shape == "qws_two_slots" else (1000, 5000, 5, 512, 1000, 24)
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=300 + i, tasks_per_problem=n_t), dev) for i in range(2)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    assert runner.halves == (shape != "qws_two_slots")
+    packed = [runner.pack(b) for b in batches]
+    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    keys = ("idx_low", "idx_high", "R")
+    side = torch.cuda.Stream()
+    lib = _lib.load()
+    rng = random.Random(7)
+
+    def run(every):                                                           # every: a burst every that many steps (0: none)
+        pending, bad = [], 0
+        for i in range(8):
+            runner.submit(packed[i % 2])
+        runner.synchronize(check=True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out, s = runner.submit(packed[i % 2])
+            if every and i % every == 0:
+                for _ in range(rng.randint(1, 2)):                            # one or two bursts, on their own stream
+                    _lib.check(lib.gnnpn_debug_lds_interferer(rng.randint(8, 32), rng.choice((64, 80, 96)) * 1024, rng.randint(20, 50),
+                                                              side.cuda_stream), "gnnpn_debug_lds_interferer")
+            ev = torch.cuda.Event()
+            ev.record(runner.stream(s))
+            pending.append((i % 2, ev, out))
+            if len(pending) == runner.n_slots:
+                vj, evj, oj = pending.pop(0)
+                evj.synchronize()
+                bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
+        for vj, evj, oj in pending:
+            evj.synchronize()
+            bad += int(not all(torch.equal(oj[k], refs[vj][k]) for k in keys))
+        runner.synchronize(check=True)                                        # raises on any failed hand-off
+        side.synchronize()
+        return B * steps / (time.perf_counter() - t0), bad
+
+    run(0)                                                                    # clocks, first launches
+    base, bad0 = run(0)
+    with_it, bad1 = run(1)                                                    # a burst beside EVERY step
+    with_8, bad3 = run(8)                                                     # beside every 8th: the cadence of bench.py's bucketed all-gather at this step length
+    base2, bad2 = run(0)
+    ref_rate = 0.5 * (base + base2)
+    rec = {"shape": shape, "steps": steps, "problems_per_s_without": [round(base, 1), round(base2, 1)],
+           "problems_per_s_with_interferer_every_step": round(with_it, 1), "loss_pct_every_step": round((1 - with_it / ref_rate) * 100, 2),
+           "problems_per_s_with_interferer_every_8th_step": round(with_8, 1), "loss_pct_every_8th_step": round((1 - with_8 / ref_rate) * 100, 2),
+           "interferer": "1-2 bursts of 8-32 workgroups x 64-96 KB LDS x 20-50 us on a third stream",
+           "placement_last_launch": [w.placement() for w in runner.workspaces]}
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity", f"interferer_soak_{shape}.json"), "w") as f:
+        json.dump(rec, f)
+    assert bad0 == bad1 == bad2 == bad3 == 0, rec
+    assert lib.gnnpn_coop_staffing_count() == 0
+    assert with_it >= 0.75 * ref_rate and with_8 >= 0.93 * ref_rate, rec           # measured: 13 % / 2 % at the QWS shape (r04_interferer_soak.json)
+
+
 def test_bench_line_contract(dev):
     """bench.py as the driver runs it (a child process, `--gpus 1 --steps K --warmup W`): exit 0, exactly ONE JSON line on
     stdout with the contract's keys, the BASELINE metric / config, a roofline object for the dominant kernel and the CPU
