@@ -304,6 +304,30 @@ def batched_aggregate_roofline(table, B, dev, reps=10):
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(work / best / 1e6 / PEAK_HBM_GBS, 5)}
 
 
+def pcie_inclusive_rate(runner, batches, B, T, steps, dev):
+    """The step rate when every batch STARTS in pinned host memory and the selected indices and scores go back to pinned host
+    memory (what a caller of the reference's Python API holds: src/models/trainPNHigh.py:134-136 `inputs.cuda()`, :140-141
+    `.cpu()`): one host-to-device copy of the batch's arena (PipelinedRunner.pack_host) and one device-to-host copy of the
+    packed results per step, on the slot's stream.  Reported beside `value`, never as `value`."""
+    hosts = [runner.pack_host(b) for b in batches]
+    host_out = [torch.empty(B * T + B, dtype=torch.int32).pin_memory() for _ in range(runner.n_slots)]
+    dev_out = [torch.empty(B * T + B, dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
+
+    def run(n):
+        for i in range(n):
+            out, s = runner.submit(hosts[i % len(hosts)])
+            with torch.cuda.stream(runner.stream(s)):
+                d = dev_out[s]
+                d[: B * T].copy_(out["idx_high"].reshape(-1), non_blocking=True)
+                d[B * T:].copy_(out["R"].view(torch.int32), non_blocking=True)
+                host_out[s].copy_(d, non_blocking=True)
+        runner.synchronize(check=False)
+    run(8)
+    t0 = time.perf_counter()
+    run(steps)
+    return B * steps / (time.perf_counter() - t0)
+
+
 def bind_to_gpu_numa_node(local_rank):
     """Pin this rank's process to the CPUs of the NUMA node its GPU hangs off (eight ranks replaying two HIP graphs every
     0.4-0.8 ms are launch-rate-sensitive: a rank whose host threads sit on the far socket pays for every doorbell).  Reads
@@ -437,6 +461,8 @@ def main():
                     "(default: the workload's G, else its per-GPU batch)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps rotate over")
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step timed region until this many seconds")
+    ap.add_argument("--write-through", type=int, default=-1, help="hand-off form of the cooperative kernels: 1 = agent-scope write-through "
+                    "granule stores (placement independent), 0 = stores that stay in the XCD's L2 (same-XCD groups), -1 = the library's default")
     ap.add_argument("--precision", default="split", choices=["f32", "f16", "split"],
                     help="arithmetic of the recurrent W_hh.h products.  split (default): fp32 operands decomposed EXACTLY into "
                          "three fp16 pieces, every cross term >= 2^-24 kept, fp32 accumulate — fp32 in, fp32 out, no operand "
@@ -540,7 +566,8 @@ def main():
     if share:       # ranks sharing ONE GPU (launch-path rehearsal): a CU holds two cooperative workgroups in all, so every rank
         n_slots = 1  # runs one launch at a time — four launches of two processes would wait on each other past the spin bound
     with gpu_turn(share):
-        runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None) if args.graph else None
+        runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None,
+                                 write_through=None if args.write_through < 0 else bool(args.write_through)) if args.graph else None
     if runner is not None:
         batches = [runner.pack(b) for b in batches]             # the slots' layout: one device-to-device copy per step instead of seven
         batch = batches[0]
@@ -927,6 +954,16 @@ def main():
                       if share else {})},
         "roofline": roof, "kernels": kernels + ([agg] if world == 1 and args.graph and not args.no_kernel_timers else []),
     }
+    if world == 1 and args.graph and not args.no_kernel_timers and not share and not use_dist:
+        with gpu_turn(share):
+            n_pcie = max(100, min(2000, int(0.25 / max(elapsed / args.steps, 1e-6))))      # about a quarter of a second of steps
+            pv = pcie_inclusive_rate(runner, batches, B, T, n_pcie, dev)
+        if runner.poll() == 0:
+            in_b = sum(t.numel() * t.element_size() for t in PipelinedRunner._fields(batches[0]))
+            line["pcie_inclusive"] = {"value": round(pv, 2), "unit": "problems/s", "ratio_to_value": round(pv / value, 4), "steps": n_pcie,
+                                      "per_step": f"one host-to-device copy of {in_b // 1024} KB (pinned arena in the slots' layout), "
+                                                  f"one device-to-host copy of {(B * T + B) * 4 // 1024} KB (idx_high, R)",
+                                      "note": "never `value`: the timed region of `value` starts with the inputs resident in HBM"}
     line["per_rank"] = per_rank
     if any(r.get("degraded") for r in per_rank if r):
         line["degraded"] = [r["degraded"] for r in per_rank if r and r.get("degraded")]

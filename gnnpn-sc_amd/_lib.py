@@ -75,6 +75,7 @@ _SIGNATURES = {
     "gnnpn_eswoa_wide_f64": (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gnnpn_debug_cell_activations": (c_int, [_P, _P, _P, c_int64, _P]),
     "gnnpn_debug_lds_interferer": (c_int, [c_int32, c_int32, c_int32, _P]),
+    "gnnpn_debug_mfma_f16": (c_int, [_P, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -83,6 +83,13 @@ class DeviceBatch:
                            self.global_bounds[lo:hi].contiguous(), self.max_nodes)
 
 
+# Hand-off form of the cooperative kernels in the runner's launches (gnnpn_launch_opts_t.write_through): False = granule stores
+# that stay in the group's XCD L2 (faster; correct by this toolchain's lowering and by the run-time XCD placement of a group),
+# True = agent-scope write-through stores (valid by the HIP memory model, placement independent).  Settled by measurement in
+# round 4: DESIGN.md section 11.
+DEFAULT_WRITE_THROUGH = False
+
+
 def half_batch_split(n_problems):
     """Where a batch is cut for the two half-batches that run side by side: whole tiles of 16 problems to the first half,
     the (possibly ragged) rest to the second; 0 when there is nothing to put on the second stream."""
@@ -232,7 +239,7 @@ class PipelinedRunner:
     tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
     """
 
-    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=False):
+    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=None):
         # Batches of 512 problems and more: ONE batch in flight, its recurrent part as two half-batches side by side
         # (ML2PNPipeline.run with a pair of workspaces).  A cooperative launch has one workgroup per CU and two of them
         # fill a CU's registers, so nothing else runs beside a co-resident pair; with two WHOLE batches in flight on two
@@ -288,7 +295,7 @@ class PipelinedRunner:
         # writes over them — measured: garbage in a slot's outputs one submission later)
         # write_through: the placement-independent hand-off form (agent-scope write-through granule stores) in every cooperative
         # launch of this runner — the degraded mode bench.py falls back to when a launch reported a failed hand-off
-        self.write_through = bool(write_through)
+        self.write_through = DEFAULT_WRITE_THROUGH if write_through is None else bool(write_through)
         self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
                                     ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
                                     write_through=self.write_through)
