@@ -323,9 +323,14 @@ def pcie_inclusive_rate(runner, batches, B, T, steps, dev):
                 host_out[s].copy_(d, non_blocking=True)
         runner.synchronize(check=False)
     run(8)
-    t0 = time.perf_counter()
-    run(steps)
-    return B * steps / (time.perf_counter() - t0)
+    best = 0.0
+    gc.disable()
+    for _ in range(2):                # the first pass still pays the first use of the pinned arenas
+        t0 = time.perf_counter()
+        run(steps)
+        best = max(best, B * steps / (time.perf_counter() - t0))
+    gc.enable()
+    return best
 
 
 def bind_to_gpu_numa_node(local_rank):
