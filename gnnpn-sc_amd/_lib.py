@@ -35,6 +35,8 @@ _SIGNATURES = {
                                               c_int32, _P]),
     "gnnpn_gcn_norm_f32": (c_int, [_P, _P, _P, _P, _P, c_int32, _P]),
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "gnnpn_gin_layer_f32": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, c_int32,
+                                    _P, c_int64, c_int64, _P]),
     "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,
                                          _P, _P, _P, _P]),
     "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),

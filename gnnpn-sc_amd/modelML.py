@@ -105,6 +105,7 @@ class Net(nn.Module):
             nn.Linear(c + self.qosNumber if i == 0 else 2 * h, 2 * h) for i in range(numLayersGCN))
         self._prep = None
         self.fuse_request_branch = os.environ.get("GNNPN_LAYERED_GIN") != "1"   # one-launch GIN branch for small workflow graphs
+        self.fuse_gin_layers = os.environ.get("GNNPN_LAYERED_GIN") != "1"       # one launch per GIN layer for large ones (same bits)
         self.parallel_branches = os.environ.get("GNNPN_SERIAL_BRANCHES") != "1"   # scores(): GCN branch on a side stream
         self._side_streams = {}
 
@@ -149,6 +150,8 @@ class Net(nn.Module):
                              "b3": f(conv.nn[3].bias), "a2": a2.to(device), "s2": b2.to(device)})
             if conv.nn[3].weight.shape[0] % 16 == 0:      # MFMA B-fragment layout for the one-launch GIN branch
                 p["gin"][-1].update(w0p=ops.pack_mfma_b(p["gin"][-1]["w0"]), w3p=ops.pack_mfma_b(p["gin"][-1]["w3"]))
+            if conv.nn[0].weight.shape[0] % 32 == 0 and conv.nn[3].weight.shape[0] % 32 == 0:   # ... and for the one-launch layer
+                p["gin"][-1].update(w0q=ops.pack_mfma_b32(p["gin"][-1]["w0"]), w3q=ops.pack_mfma_b32(p["gin"][-1]["w3"]))
         for conv, bn in zip(self.serviceConvs, self.serviceBatchNorms):
             a, b = _bn_affine(bn)
             p["gcn"].append({"wt": f(conv.weight.detach().t()), "bias": f(conv.bias), "a": a.to(device),
@@ -158,6 +161,8 @@ class Net(nn.Module):
         p["nodeLin"] = (f(self.nodeLin.weight), f(self.nodeLin.bias))
         if self.nodeLin.weight.shape[0] % 16 == 0:
             p["nodeLin_p"] = ops.pack_mfma_b(p["nodeLin"][0])
+        if self.nodeLin.weight.shape[0] % 32 == 0:
+            p["nodeLin_q"] = ops.pack_mfma_b32(p["nodeLin"][0])
         p["serviceLin"] = (f(self.serviceLin.weight), f(self.serviceLin.bias))
         self._prep = p
         return p
@@ -181,11 +186,24 @@ class Net(nn.Module):
             return torch.ops.gnnpn.request_branch(x, p["node_table"], wf_csr.rowptr, wf_csr.col, seg_ptr, int(max_nodes),
                                                   flat, p["nodeLin_p"], p["nodeLin"][1], 128)
         h = torch.ops.gnnpn.embed_concat(x, p["node_table"])                                               # :134-137
-        for lp in p["gin"]:                                                                     # :139-142
+        n_lin = self.nodeLin.weight.shape[0]
+        fused = self.fuse_gin_layers and h.shape[0] >= 4096 and all(
+            "w0q" in lp and ops.gin_layer_supported(lp["w0"].shape[1], lp["w0"].shape[0], lp["w3"].shape[0]) for lp in p["gin"])
+        last = len(p["gin"]) - 1
+        lin_done = False
+        for i, lp in enumerate(p["gin"]):                                                       # :139-142
+            if fused:    # one launch per layer (the [rows x 256] intermediate stays on the CU), nodeLin behind the last: same bits
+                with_lin = i == last and "nodeLin_q" in p and ops.gin_layer_supported(lp["w0"].shape[1], 256, 128, n_lin)
+                h = torch.ops.gnnpn.gin_layer(wf_csr.rowptr, wf_csr.col, h, lp["eps"], lp["w0q"], lp["b0"], lp["a1"], lp["s1"],
+                                              lp["w3q"], lp["b3"], lp["a2"], lp["s2"],
+                                              p["nodeLin_q"] if with_lin else None, p["nodeLin"][1] if with_lin else None)
+                lin_done = with_lin
+                continue
             agg = torch.ops.gnnpn.csr_aggregate(wf_csr.rowptr, wf_csr.col, None, h, self_coef=lp["eps"])
             t = torch.ops.gnnpn.linear(agg, lp["w0"], lp["b0"], lp["a1"], lp["s1"], ACT_RELU)
             h = torch.ops.gnnpn.linear(t, lp["w3"], lp["b3"], lp["a2"], lp["s2"], ACT_RELU)
-        h = torch.ops.gnnpn.linear(h, *p["nodeLin"])                                                        # :165
+        if not lin_done:
+            h = torch.ops.gnnpn.linear(h, *p["nodeLin"])                                                    # :165
         return torch.ops.gnnpn.segment_mean(seg_ptr, h)                                                     # :166
 
     @torch.no_grad()

@@ -221,6 +221,45 @@ def pack_mfma_b(w):
     return v.permute(0, 2, 4, 1, 3).reshape(N // 16, Kp // 16, 64, 4).contiguous()   # [t, k16, (kq, c), j]
 
 
+def gin_layer(rowptr, col, x, eps, w1, b1, a1, s1, w2, b2, a2, s2, w3=None, b3=None):
+    """One GIN layer for large workflow graphs in one launch (gnnpn_gin_layer_f32): aggregate -> Linear + BN + ReLU -> Linear + BN
+    + ReLU [-> Linear + bias].  w1 / w2 / w3: the weights PACKED by ``pack_mfma_b32`` ([N/32, Kp/2, 64]).  Bit-identical to
+    csr_aggregate(self_coef=eps) + linear + linear (+ linear) on the unpacked weights.  Raises GnnpnError for shapes the kernel
+    is not built for (``gin_layer_supported``)."""
+    x = _rows2d(x, "gin_layer.x")
+    n, c_in = x.shape
+    if w1.dim() != 3 or w2.dim() != 3 or (w3 is not None and w3.dim() != 3) or w1.shape[1] * 2 != (c_in + 31) // 32 * 32:
+        raise GnnpnError("gin_layer: weights must be packed with ops.pack_mfma_b32 (and w1 for this many input channels)")
+    h1, h2 = w1.shape[0] * 32, w2.shape[0] * 32
+    h3 = w3.shape[0] * 32 if w3 is not None else 0
+    out = torch.empty((n, h3 if w3 is not None else h2), dtype=F32, device=x.device)
+    check(_lib.load().gnnpn_gin_layer_f32(
+        dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(x, F32, "x"), c_in, c_in, dev_ptr(eps, F32, "eps"),
+        dev_ptr(w1, F32, "w1"), dev_ptr(b1, F32, "b1", True), dev_ptr(a1, F32, "a1", True), dev_ptr(s1, F32, "s1", True), h1,
+        dev_ptr(w2, F32, "w2"), dev_ptr(b2, F32, "b2", True), dev_ptr(a2, F32, "a2", True), dev_ptr(s2, F32, "s2", True), h2,
+        dev_ptr(w3, F32, "w3", True), dev_ptr(b3, F32, "b3", True), h3, dev_ptr(out, F32, "out"), out.shape[1], n, stream_ptr()),
+        "gnnpn_gin_layer_f32")
+    return out
+
+
+def gin_layer_supported(c_in, h1, h2, h3=None):
+    return h1 == 256 and h2 == 128 and (h3 is None or h3 == 128) and 0 < c_in <= 256
+
+
+def pack_mfma_b32(w):
+    """[N, K] weight (rows = output features) -> v_mfma_f32_32x32x2_f32 B-fragments [N/32, Kp/2, 64]:
+    packed[t][kp][lane] = w[32t + lane%32][2*kp + lane//32], K zero-padded to a multiple of 32 (the padding linear_f32_kernel
+    applies in its last k-tile).  A one-time layout change at weight-load time (no arithmetic)."""
+    N, K = w.shape
+    if N % 32:
+        raise GnnpnError(f"pack_mfma_b32: output features {N} must be a multiple of 32")
+    Kp = (K + 31) // 32 * 32
+    wp = torch.zeros((N, Kp), dtype=w.dtype, device=w.device)
+    wp[:, :K] = w
+    v = wp.view(N // 32, 32, Kp // 2, 2)                  # [t, c, kp, h]
+    return v.permute(0, 2, 3, 1).reshape(N // 32, Kp // 2, 64).contiguous()   # [t, kp, (h, c)]
+
+
 REQUEST_BRANCH_MAX_NODES = 16
 
 

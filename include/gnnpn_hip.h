@@ -156,6 +156,19 @@ int gnnpn_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, const float* w
 int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, float* out,
                            int64_t ldo, int32_t n_seg, int32_t C, void* stream);
 
+/* One GIN layer of the workflow branch for LARGE graphs in one launch: neighbour aggregate ((1 + *eps) * x_i + sum_j x_j, CSR
+ * order) -> Linear(c_in -> h1) + BN + ReLU -> Linear(h1 -> h2) + BN + ReLU [-> Linear(h2 -> h3) + bias when w3 != NULL: nodeLin
+ * behind the last layer]; a workgroup owns 64 rows and the [rows x h1] intermediate stays in LDS (csrc/gin_layer.hip).  Built
+ * for h1 = 256, h2 = 128, h3 = 128, c_in <= 256 (GNNPN_E_UNSUP otherwise: callers use the separate kernels).  w1 / w2 / w3: the
+ * weights as v_mfma_f32_32x32x2_f32 B-fragments, packed[t][kp][lane] = W[32 t + lane % 32][2 kp + lane / 32] with K zero-padded
+ * to a multiple of 32 (ops.pack_mfma_b32: layout only); BN folded to scale / shift (or NULL).  Stage for stage the arithmetic of
+ * gnnpn_csr_aggregate_f32 (self_coef = eps) and gnnpn_linear_f32: the result is bit-identical to calling those in sequence.
+ * Replaces: GINConv + BatchNorm1d + ReLU (src/models/modelML.py:75-93,139-143) and nodeLin (:165) per layer. */
+int gnnpn_gin_layer_f32(const int32_t* rowptr, const int32_t* col, const float* x, int64_t ldx, int32_t c_in, const float* eps,
+                        const float* w1, const float* b1, const float* bn1_scale, const float* bn1_shift, int32_t h1,
+                        const float* w2, const float* b2, const float* bn2_scale, const float* bn2_shift, int32_t h2,
+                        const float* w3, const float* b3, int32_t h3, float* out, int64_t ldo, int64_t n_rows, void* stream);
+
 /* The whole workflow (GIN) branch of Net.forward in ONE launch, for batches whose workflow graphs have at most 16 nodes
  * (QWS / Normal requests: <= 11): embedding lookup + concat, n_layers x {GIN aggregate, Linear+BN+ReLU, Linear+BN+ReLU},
  * nodeLin, mean over each graph's nodes; node features stay in LDS between the stages.  Stage for stage the arithmetic of

@@ -634,6 +634,44 @@ def test_csr_aggregate_dispatch_prefers_the_tiled_form_on_the_reference_edge_ord
         ops.PREFER_TILED_AGGREGATE = saved
 
 
+@pytest.mark.parametrize("n,c_in,nodes_per_graph,with_lin", [(5000, 26, 1001, False), (5000, 128, 1001, True), (70, 26, 7, True),
+                                                             (4097, 128, 50, False), (300, 24, 11, True)])
+def test_gin_layer_equals_the_separate_kernels(dev, n, c_in, nodes_per_graph, with_lin):
+    """gnnpn_gin_layer_f32 (aggregate -> Linear + BN + ReLU -> Linear + BN + ReLU [-> nodeLin] in one launch, the [rows x 256]
+    intermediate in LDS) against gnnpn_csr_aggregate_f32 + gnnpn_linear_f32 x 2 (+ 1): the same fma chains, zero padding and
+    epilogue roundings -> the same bits; chain graphs with a ragged last row tile, a last graph cut short, isolated nodes."""
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + c_in)
+    i = torch.arange(n - 1)
+    keep = (i + 1) % nodes_per_graph != 0                                  # chain edges inside each graph, both directions
+    src = torch.stack([i[keep], i[keep] + 1], 1).reshape(-1)
+    dst = torch.stack([i[keep] + 1, i[keep]], 1).reshape(-1)
+    extra = torch.randint(0, n, (2, n // 3), generator=g)                   # and some long-range edges (rows far outside the tile)
+    ei = torch.cat([torch.stack([src, dst]), extra], 1)
+    csr = graph.csr_by_destination(ei, n).to(dev)
+    x = torch.randn(n, c_in, generator=g).to(dev)
+    eps = torch.tensor([0.07], device=dev)
+    mk = lambda *s: (torch.randn(*s, generator=g) / s[-1] ** 0.5).to(dev)   # noqa: E731
+    w1, b1, w2, b2, w3, b3 = mk(256, c_in), mk(256), mk(128, 256), mk(128), mk(128, 128), mk(128)
+    a1, s1, a2, s2 = (torch.rand(256, generator=g) + 0.5).to(dev), mk(256), (torch.rand(128, generator=g) + 0.5).to(dev), mk(128)
+    agg = ops.csr_aggregate(csr.rowptr, csr.col, None, x, self_coef=eps)
+    t = ops.linear(agg, w1, b1, a1, s1, ops.ACT_RELU)
+    want = ops.linear(t, w2, b2, a2, s2, ops.ACT_RELU)
+    if with_lin:
+        want = ops.linear(want, w3, b3)
+    q1, q2, q3 = ops.pack_mfma_b32(w1), ops.pack_mfma_b32(w2), ops.pack_mfma_b32(w3)          # the matrix core's B-fragment layout
+    got = ops.gin_layer(csr.rowptr, csr.col, x, eps, q1, b1, a1, s1, q2, b2, a2, s2, q3 if with_lin else None, b3 if with_lin else None)
+    assert got.shape == want.shape and torch.equal(got, want)
+    got = ops.gin_layer(csr.rowptr, csr.col, x, eps, q1, None, None, None, q2, b2, None, None)      # no bias / no BN operands
+    assert torch.equal(got, ops.linear(ops.linear(agg, w1, None, None, None, ops.ACT_RELU), w2, b2, None, None, ops.ACT_RELU))
+    with pytest.raises(ops.GnnpnError):
+        ops.gin_layer(csr.rowptr, csr.col, x, eps, ops.pack_mfma_b32(w1[:128]), b1[:128], a1[:128], s1[:128],
+                      ops.pack_mfma_b32(mk(128, 128)), b2, a2, s2)                                   # h1 != 256
+    with pytest.raises(ops.GnnpnError):
+        ops.gin_layer(csr.rowptr, csr.col, x, eps, w1, b1, a1, s1, w2, b2, a2, s2)                  # unpacked weights
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation
