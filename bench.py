@@ -897,11 +897,11 @@ def main():
     value = world * B * args.steps / elapsed
     kernels = kernel_table(summary, n_timed, args.precision)
     # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
-    # profiles/r03_pmc_traffic.json (tools/r03_profiles.sh + tools/collect_profiles.py), FETCH_SIZE doubled as the gfx950 guide
+    # profiles/r04_pmc_traffic.json (tools/r04_profiles.sh + tools/collect_profiles.py), FETCH_SIZE doubled as the gfx950 guide
     # prescribes; only quoted when this run is a workload / batch / precision those passes measured.
     def pmc_traffic(precision):
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             return {k: v["traffic"] for k, v in pmc.get(f"{args.workload}_b{B}_{precision}", {}).get("kernels", {}).items()}
         except (OSError, ValueError, KeyError):

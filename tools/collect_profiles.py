@@ -32,10 +32,10 @@ for src, dst in (("bench_qws.json", RN + "_qws_b256_bench.json"), ("bench_qws_dr
     cp_json(src, dst)
 if os.path.exists(os.path.join(O, "aggregate.jsonl")):
     recs = [json.loads(ln) for ln in open(os.path.join(O, "aggregate.jsonl")) if ln.startswith("{")]
-    json.dump({"what": "GCN aggregate layer over B block-diagonal copies of the service graph (the reference's batching), both forms, "
+    json.dump({"what": "GCN aggregate layer over B block-diagonal copies of the service graph (the reference's batching; edge lists in the reference's scan order), all forms, "
                        "tools/bench_aggregate.py, 1 x MI355X", "records": recs}, open(os.path.join(P, RN + "_csr_aggregate_roofline.json"), "w"), indent=1)
-    print("-> r03_csr_aggregate_roofline.json")
-stats = [(f"stats_{wl}_{pr}", fRN + "_{key}_{pr}_solo_eager_kernel_stats.csv") for wl, key in (("qws", "qws_b256"), ("normal", "normal_b1024"),
+    print("->", RN + "_csr_aggregate_roofline.json")
+stats = [(f"stats_{wl}_{pr}", f"{RN}_{key}_{pr}_solo_eager_kernel_stats.csv") for wl, key in (("qws", "qws_b256"), ("normal", "normal_b1024"),
                                                                                     ("synth4", "synth4_b512"), ("synth5", "synth5_b256"))
          for pr in ("split", "f32")]
 stats += [("stats_qws_f16", RN + "_qws_b256_f16_solo_eager_kernel_stats.csv"), ("stats_synth5_f16", RN + "_synth5_b256_f16_solo_eager_kernel_stats.csv"),
@@ -66,7 +66,7 @@ for wl, key0 in (("qws", "qws_b256"), ("normal", "normal_b1024"), ("synth4", "sy
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[-1])):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        with open(os.path.join(P, fRN + "_{key}_pmc_{name}_size_summary.csv"), "w") as o:
+        with open(os.path.join(P, f"{RN}_{key}_pmc_{name}_size_summary.csv"), "w") as o:
             o.write("kernel,dispatches,mean_counter_value_KB\n")
             for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
                 o.write(f"\"{k[:90]}\",{len(v)},{sum(v) / len(v):.1f}\n")
@@ -81,4 +81,4 @@ for wl, key0 in (("qws", "qws_b256"), ("normal", "normal_b1024"), ("synth4", "sy
                 ks[label] = {"fetch_size_raw": round(fe), "fetch_corrected": round(2 * fe), "write_size": round(wr), "traffic": round(2 * fe + wr)}
     out[key] = {"workload": f"bench.py --workload {wl} --precision {pr} (default batch), eager single-stream launches, 1 x MI355X", "kernels": ks}
 json.dump(out, open(os.path.join(P, RN + "_pmc_traffic.json"), "w"), indent=1)
-print("-> r03_pmc_traffic.json", {k: list(v["kernels"]) for k, v in out.items() if isinstance(v, dict)})
+print("->", RN + "_pmc_traffic.json", {k: list(v["kernels"]) for k, v in out.items() if isinstance(v, dict)})
