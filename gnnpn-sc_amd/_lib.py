@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
 LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -37,6 +37,10 @@ _SIGNATURES = {
     "gnnpn_segment_mean_f32": (c_int, [_P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "gnnpn_gin_layer_f32": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, c_int32,
                                     _P, c_int64, c_int64, _P]),
+    "gnnpn_split_weights_bytes": (c_int64, [c_int32, c_int32]),
+    "gnnpn_pack_split_weights_f16": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "gnnpn_gin_layer_split": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32,
+                                      _P, _P, _P, c_int32, _P, c_int64, c_int64, _P]),
     "gnnpn_request_branch_f32": (c_int, [_P, c_int32, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32,
                                          _P, _P, _P, _P]),
     "gnnpn_select_candidates": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),

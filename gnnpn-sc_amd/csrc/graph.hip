@@ -434,6 +434,15 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const int32_t* __rest
     const float* col = x + c;
     float acc = 0.0f;
     int n = b;
+    // 32 rows in flight per lane (long segments — 1001 nodes per workflow at the 1000-task shapes — are one wave per 64 channels:
+    // the loop is a latency chain, 8 in flight took 82 us for 512 x 1001 rows), summed in row order all the same
+    for (; n + 32 <= e; n += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = col[(int64_t)(n + u) * ldx];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = __fadd_rn(acc, v[u]);
+    }
     for (; n + 8 <= e; n += 8) {
         float v[8];
 #pragma unroll

@@ -7,6 +7,7 @@ calling an operator with host tensors fails in the dispatcher ("Could not run 'g
     torch.ops.gnnpn.linear / embed_concat / csr_aggregate / gcn_norm / segment_mean
     torch.ops.gnnpn.request_branch             (the whole GIN branch of small workflow graphs in one launch)
     torch.ops.gnnpn.gin_layer                  (one GIN layer of large workflow graphs in one launch)
+    torch.ops.gnnpn.gin_layer_split            (the same on the fp16 matrix cores through the exact split)
     torch.ops.gnnpn.segment_topk_feasible      (candidate reduction: sort + loadDataPN + SCDataset)
     torch.ops.gnnpn.rank_rows / precision_at_k
     torch.ops.gnnpn.lstm_encode                (n nets in one launch)
@@ -58,6 +59,9 @@ _op("request_branch(Tensor x, Tensor table, Tensor rowptr, Tensor col, Tensor se
     "Tensor[] layer_tensors, Tensor lin_w_packed, Tensor lin_b, int hidden) -> Tensor", _request_branch)
 _op("gin_layer(Tensor rowptr, Tensor col, Tensor x, Tensor eps, Tensor w1, Tensor? b1, Tensor? a1, Tensor? s1, Tensor w2, Tensor? b2, "
     "Tensor? a2, Tensor? s2, Tensor? w3=None, Tensor? b3=None) -> Tensor", ops.gin_layer)
+_op("gin_layer_split(Tensor rowptr, Tensor col, Tensor x, Tensor eps, Tensor w1, Tensor i1, Tensor? b1, Tensor? a1, Tensor? s1, "
+    "Tensor w2, Tensor i2, Tensor? b2, Tensor? a2, Tensor? s2, Tensor? w3=None, Tensor? i3=None, Tensor? b3=None) -> Tensor",
+    ops.gin_layer_split)
 _op("gcn_norm(Tensor rowptr, Tensor col, Tensor w_raw) -> Tensor", ops.gcn_norm)
 _op("segment_mean(Tensor segptr, Tensor x) -> Tensor", ops.segment_mean)
 _op("segment_topk_feasible(Tensor scores, Tensor cat_ptr, Tensor qos, Tensor local_bounds, Tensor present, "

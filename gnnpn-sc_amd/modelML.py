@@ -106,6 +106,10 @@ class Net(nn.Module):
         self._prep = None
         self.fuse_request_branch = os.environ.get("GNNPN_LAYERED_GIN") != "1"   # one-launch GIN branch for small workflow graphs
         self.fuse_gin_layers = os.environ.get("GNNPN_LAYERED_GIN") != "1"       # one launch per GIN layer for large ones (same bits)
+        # arithmetic of the dense products of those large layers: "f32" (the matrix core's fp32 chain, bit-identical to the layered
+        # kernels) or "split" (fp16 matrix cores through the exact 3-piece split, gin_layer_split.hip).  ML2PNPipeline passes its
+        # own precision per call; this is the default of direct calls (Net.forward, TrainML.test).
+        self.dense_precision = os.environ.get("GNNPN_DENSE_PRECISION", "f32")
         self.parallel_branches = os.environ.get("GNNPN_SERIAL_BRANCHES") != "1"   # scores(): GCN branch on a side stream
         self._side_streams = {}
 
@@ -152,6 +156,8 @@ class Net(nn.Module):
                 p["gin"][-1].update(w0p=ops.pack_mfma_b(p["gin"][-1]["w0"]), w3p=ops.pack_mfma_b(p["gin"][-1]["w3"]))
             if conv.nn[0].weight.shape[0] % 32 == 0 and conv.nn[3].weight.shape[0] % 32 == 0:   # ... and for the one-launch layer
                 p["gin"][-1].update(w0q=ops.pack_mfma_b32(p["gin"][-1]["w0"]), w3q=ops.pack_mfma_b32(p["gin"][-1]["w3"]))
+                if device.type == "cuda":    # ... and split exactly into fp16 pieces for its fp16-matrix-core form
+                    p["gin"][-1].update(w0s=ops.pack_split_weights(p["gin"][-1]["w0"]), w3s=ops.pack_split_weights(p["gin"][-1]["w3"]))
         for conv, bn in zip(self.serviceConvs, self.serviceBatchNorms):
             a, b = _bn_affine(bn)
             p["gcn"].append({"wt": f(conv.weight.detach().t()), "bias": f(conv.bias), "a": a.to(device),
@@ -163,6 +169,8 @@ class Net(nn.Module):
             p["nodeLin_p"] = ops.pack_mfma_b(p["nodeLin"][0])
         if self.nodeLin.weight.shape[0] % 32 == 0:
             p["nodeLin_q"] = ops.pack_mfma_b32(p["nodeLin"][0])
+            if device.type == "cuda":
+                p["nodeLin_s"] = ops.pack_split_weights(p["nodeLin"][0])
         p["serviceLin"] = (f(self.serviceLin.weight), f(self.serviceLin.bias))
         self._prep = p
         return p
@@ -176,7 +184,7 @@ class Net(nn.Module):
                 self.numLayersGIN <= 4 and self.reqAndServiceChannels + x.shape[1] - 1 <= 32)
 
     @torch.no_grad()
-    def request_embedding(self, x, wf_csr, seg_ptr, max_nodes=0):
+    def request_embedding(self, x, wf_csr, seg_ptr, max_nodes=0, dense_precision=None):
         """Workflow branch (modelML.py:133-143,165-166): x [N,7], CSR of the batched workflow graphs,
         graph segment pointer -> [B, hidden].  ``max_nodes`` > 0 promises that every graph has at most that many nodes
         and that every edge stays inside its graph: up to 16 the whole branch then runs as ONE launch."""
@@ -191,9 +199,21 @@ class Net(nn.Module):
             "w0q" in lp and ops.gin_layer_supported(lp["w0"].shape[1], lp["w0"].shape[0], lp["w3"].shape[0]) for lp in p["gin"])
         last = len(p["gin"]) - 1
         lin_done = False
+        prec = self.dense_precision if dense_precision is None else dense_precision
+        if prec not in ("f32", "split"):
+            raise ops.GnnpnError(f"dense_precision must be 'f32' or 'split', got {prec!r}")
+        split = fused and prec == "split" and all("w0s" in lp for lp in p["gin"])
         for i, lp in enumerate(p["gin"]):                                                       # :139-142
             if fused:    # one launch per layer (the [rows x 256] intermediate stays on the CU), nodeLin behind the last: same bits
                 with_lin = i == last and "nodeLin_q" in p and ops.gin_layer_supported(lp["w0"].shape[1], 256, 128, n_lin)
+                if split and ops.gin_layer_split_supported(lp["w0"].shape[1], 256, 128):
+                    with_lin = with_lin and "nodeLin_s" in p
+                    h = torch.ops.gnnpn.gin_layer_split(wf_csr.rowptr, wf_csr.col, h, lp["eps"], *lp["w0s"], lp["b0"], lp["a1"], lp["s1"],
+                                                        *lp["w3s"], lp["b3"], lp["a2"], lp["s2"],
+                                                        *(p["nodeLin_s"] if with_lin else (None, None)),
+                                                        p["nodeLin"][1] if with_lin else None)
+                    lin_done = with_lin
+                    continue
                 h = torch.ops.gnnpn.gin_layer(wf_csr.rowptr, wf_csr.col, h, lp["eps"], lp["w0q"], lp["b0"], lp["a1"], lp["s1"],
                                               lp["w3q"], lp["b3"], lp["a2"], lp["s2"],
                                               p["nodeLin_q"] if with_lin else None, p["nodeLin"][1] if with_lin else None)
@@ -231,17 +251,17 @@ class Net(nn.Module):
         return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                                 # :164
 
     @torch.no_grad()
-    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr, service_emb=None, max_nodes=0):
+    def scores(self, x, wf_csr, seg_ptr, x_service, svc_csr, service_emb=None, max_nodes=0, dense_precision=None):
         """The two branches are independent until the score product: the service branch (GCN) is forked onto
         a side stream and joined before the GEMM, so ~20 small launch-latency-bound kernels run two abreast
         (fork/join is stream-capturable: inside a HIP graph it becomes two parallel branches).
         ``service_emb`` [S, hidden]: the service branch's result computed earlier (it depends on the weights and the
         service table only — pipeline.ML2PNPipeline caches it per (weights, table)); the branch is then skipped."""
         if service_emb is not None:
-            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
+            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes, dense_precision)
             return torch.ops.gnnpn.linear(xr, service_emb, act=ACT_SIGMOID)                                 # :173-176
         if not self.parallel_branches:
-            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
+            xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes, dense_precision)
             xs = self.service_embedding(x_service, svc_csr)
             return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                          # :173-176
         cur = torch.cuda.current_stream(x.device)
@@ -251,7 +271,7 @@ class Net(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             xs = self.service_embedding(x_service, svc_csr)
-        xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes)
+        xr = self.request_embedding(x, wf_csr, seg_ptr, max_nodes, dense_precision)
         cur.wait_stream(side)
         xs.record_stream(cur)
         return torch.ops.gnnpn.linear(xr, xs, act=ACT_SIGMOID)                                              # :173-176

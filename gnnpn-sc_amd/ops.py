@@ -242,6 +242,51 @@ def gin_layer(rowptr, col, x, eps, w1, b1, a1, s1, w2, b2, a2, s2, w3=None, b3=N
     return out
 
 
+def pack_split_weights(w):
+    """[N, K] fp32 weight (rows = output features, N a multiple of 16) -> (packed uint8 image, col_inv [N]) for ``gin_layer_split``:
+    every element decomposed exactly into three fp16 pieces under a per-column power-of-two scale, in the fp16 matrix core's
+    B-fragment order (gnnpn_pack_split_weights_f16).  Once per model."""
+    w = _rows2d(w, "pack_split_weights.w")
+    N, K = w.shape
+    nbytes = _lib.load().gnnpn_split_weights_bytes(N, K)
+    if nbytes <= 0:
+        raise GnnpnError(f"pack_split_weights: output features {N} must be a multiple of 16")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    inv = torch.empty(N, dtype=F32, device=w.device)
+    check(_lib.load().gnnpn_pack_split_weights_f16(dev_ptr(w, F32, "w"), K, N, K, dev_ptr(packed, torch.uint8, "packed"), dev_ptr(inv, F32, "col_inv"),
+                                                   stream_ptr()), "gnnpn_pack_split_weights_f16")
+    return packed, inv
+
+
+def gin_layer_split(rowptr, col, x, eps, w1, i1, b1, a1, s1, w2, i2, b2, a2, s2, w3=None, i3=None, b3=None):
+    """``gin_layer`` with the three dense products on the fp16 matrix cores through the exact split (gnnpn_gin_layer_split):
+    (w, i) pairs from ``pack_split_weights``.  Built for c_in -> 256 -> 128 (-> 128)."""
+    x = _rows2d(x, "gin_layer_split.x")
+    n, c_in = x.shape
+    lib = _lib.load()
+    k1 = (c_in + 31) // 32 * 32
+    if w1.dtype != torch.uint8 or w2.dtype != torch.uint8 or (w3 is not None and w3.dtype != torch.uint8) or i1 is None or i2 is None:
+        raise GnnpnError("gin_layer_split: weights must be packed with ops.pack_split_weights")
+    h1, h2 = i1.numel(), i2.numel()
+    h3 = i3.numel() if w3 is not None else 0
+    if (w1.numel() != lib.gnnpn_split_weights_bytes(h1, k1) or w2.numel() != lib.gnnpn_split_weights_bytes(h2, h1) or
+            (w3 is not None and w3.numel() != lib.gnnpn_split_weights_bytes(h3, h2))):
+        raise GnnpnError("gin_layer_split: packed weights do not chain (c_in -> h1 -> h2 [-> h3])")
+    out = torch.empty((n, h3 if w3 is not None else h2), dtype=F32, device=x.device)
+    u8 = lambda t, name, opt=False: None if (t is None and opt) else dev_ptr(t, torch.uint8, name)   # noqa: E731
+    check(lib.gnnpn_gin_layer_split(
+        dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(x, F32, "x"), c_in, c_in, dev_ptr(eps, F32, "eps"),
+        u8(w1, "w1"), dev_ptr(i1, F32, "i1"), dev_ptr(b1, F32, "b1", True), dev_ptr(a1, F32, "a1", True), dev_ptr(s1, F32, "s1", True), h1,
+        u8(w2, "w2"), dev_ptr(i2, F32, "i2"), dev_ptr(b2, F32, "b2", True), dev_ptr(a2, F32, "a2", True), dev_ptr(s2, F32, "s2", True), h2,
+        u8(w3, "w3", True), dev_ptr(i3, F32, "i3", True), dev_ptr(b3, F32, "b3", True), h3, dev_ptr(out, F32, "out"), out.shape[1], n,
+        stream_ptr()), "gnnpn_gin_layer_split")
+    return out
+
+
+def gin_layer_split_supported(c_in, h1, h2, h3=None):
+    return h1 == 256 and h2 == 128 and (h3 is None or h3 == 128) and 0 < c_in <= 128 and (c_in % 4 == 0 or c_in <= 32)
+
+
 def gin_layer_supported(c_in, h1, h2, h3=None):
     return h1 == 256 and h2 == 128 and (h3 is None or h3 == 128) and 0 < c_in <= 256
 

@@ -126,7 +126,7 @@ class ML2PNPipeline:
         """TrainML.test's forward (trainML.py:56-58)."""
         return self.net.scores(batch.x, batch.wf_csr, batch.seg_ptr, services.x_service, services.csr,
                                service_emb=self.service_embedding(services) if self.cache_service_embedding else None,
-                               max_nodes=batch.max_nodes)
+                               max_nodes=batch.max_nodes, dense_precision="split" if self.precision == "split" else "f32")
 
     @torch.no_grad()
     def candidates(self, services, batch, scores):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 4   /* 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 5   /* 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -158,7 +158,7 @@ int gnnpn_segment_mean_f32(const int32_t* segptr, const float* x, int64_t ldx, f
 
 /* One GIN layer of the workflow branch for LARGE graphs in one launch: neighbour aggregate ((1 + *eps) * x_i + sum_j x_j, CSR
  * order) -> Linear(c_in -> h1) + BN + ReLU -> Linear(h1 -> h2) + BN + ReLU [-> Linear(h2 -> h3) + bias when w3 != NULL: nodeLin
- * behind the last layer]; a workgroup owns 64 rows and the [rows x h1] intermediate stays in LDS (csrc/gin_layer.hip).  Built
+ * behind the last layer]; a workgroup owns 32 rows and the [rows x h1] intermediate stays in LDS (csrc/gin_layer.hip).  Built
  * for h1 = 256, h2 = 128, h3 = 128, c_in <= 256 (GNNPN_E_UNSUP otherwise: callers use the separate kernels).  w1 / w2 / w3: the
  * weights as v_mfma_f32_32x32x2_f32 B-fragments, packed[t][kp][lane] = W[32 t + lane % 32][2 kp + lane / 32] with K zero-padded
  * to a multiple of 32 (ops.pack_mfma_b32: layout only); BN folded to scale / shift (or NULL).  Stage for stage the arithmetic of
@@ -168,6 +168,27 @@ int gnnpn_gin_layer_f32(const int32_t* rowptr, const int32_t* col, const float* 
                         const float* w1, const float* b1, const float* bn1_scale, const float* bn1_shift, int32_t h1,
                         const float* w2, const float* b2, const float* bn2_scale, const float* bn2_shift, int32_t h2,
                         const float* w3, const float* b3, int32_t h3, float* out, int64_t ldo, int64_t n_rows, void* stream);
+
+/* The same layer with its dense products on the fp16 matrix cores through the EXACT SPLIT (csrc/gin_layer_split.hip; the
+ * arithmetic of the "split" precision of the recurrent kernels): every fp32 operand, activation or weight, is decomposed into three
+ * fp16 pieces that sum to it bit for bit and the six cross products that can reach 2^-24 of a term are accumulated in fp32; the
+ * aggregate, bias, BN and ReLU are the fp32 instructions of gnnpn_gin_layer_f32.  NOT bit-identical to the fp32 layer (another
+ * accumulation order of the same terms): tests/test_gpu_ops.py measures both against fp64.
+ *   gnnpn_split_weights_bytes(n_out, k): size of the packed image of an [n_out x k] weight (0 for shapes not supported).
+ *   gnnpn_pack_split_weights_f16: w [n_out x k] row-major fp32 (n_out a multiple of 16) -> packed (16-byte aligned) + col_inv
+ *     [n_out]: per output column a power-of-two scale (column maximum in [2^14, 2^15)), records (column tile of 16, k-block of
+ *     32) = {piece 0: 64 lanes x 16 B, piece 1: 64 x 16 B, piece 2: 64 x 8 B (upper bytes)} in v_mfma_f32_16x16x32_f16 B-fragment
+ *     order, lane (c, kq) holding W[16 t + c][32 kk + 8 kq + j]; col_inv[c] = 2^-scale.  Once per model.
+ *   gnnpn_gin_layer_split: as gnnpn_gin_layer_f32 with (w, inv) pairs from the packer; x rows of 4 k channels must be 16-byte
+ *     aligned, or c_in <= 32; c_in <= 128; 16-byte aligned vectors and output rows (GNNPN_E_UNSUP otherwise).
+ * Replaces the same reference lines as gnnpn_gin_layer_f32. */
+int64_t gnnpn_split_weights_bytes(int32_t n_out, int32_t k);
+int gnnpn_pack_split_weights_f16(const float* w, int64_t ldw, int32_t n_out, int32_t k, void* packed, float* col_inv, void* stream);
+int gnnpn_gin_layer_split(const int32_t* rowptr, const int32_t* col, const float* x, int64_t ldx, int32_t c_in, const float* eps,
+                          const void* w1, const float* inv1, const float* b1, const float* bn1_scale, const float* bn1_shift, int32_t h1,
+                          const void* w2, const float* inv2, const float* b2, const float* bn2_scale, const float* bn2_shift, int32_t h2,
+                          const void* w3, const float* inv3, const float* b3, int32_t h3, float* out, int64_t ldo, int64_t n_rows,
+                          void* stream);
 
 /* The whole workflow (GIN) branch of Net.forward in ONE launch, for batches whose workflow graphs have at most 16 nodes
  * (QWS / Normal requests: <= 11): embedding lookup + concat, n_layers x {GIN aggregate, Linear+BN+ReLU, Linear+BN+ReLU},

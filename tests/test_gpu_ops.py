@@ -672,6 +672,66 @@ def test_gin_layer_equals_the_separate_kernels(dev, n, c_in, nodes_per_graph, wi
         ops.gin_layer(csr.rowptr, csr.col, x, eps, w1, b1, a1, s1, w2, b2, a2, s2)                  # unpacked weights
 
 
+def _unpack_split_weights(packed, inv, N, K):
+    """The fp32 weight an image of ops.pack_split_weights stands for: (p0 + p1 / 2^11 + p2 / 2^22) * col_inv, in float64."""
+    kb = (K + 31) // 32
+    rec = packed.cpu().numpy().reshape(N // 16, kb, 2560)
+    p0 = rec[:, :, :1024].copy().view(np.float16).reshape(N // 16, kb, 64, 8).astype(np.float64)
+    p1 = rec[:, :, 1024:2048].copy().view(np.float16).reshape(N // 16, kb, 64, 8).astype(np.float64)
+    b2 = rec[:, :, 2048:].copy().reshape(N // 16, kb, 64, 8)
+    p2 = (b2.astype(np.uint16) << 8).view(np.float16).astype(np.float64)
+    v = (p0 + p1 / 2048.0 + p2 / 2048.0 ** 2).reshape(N // 16, kb, 4, 16, 8)        # [t, kk, kq, c, j]
+    w = v.transpose(0, 3, 1, 2, 4).reshape(N, kb * 32)[:, :K]
+    return w * inv.double().cpu().numpy()[:, None]
+
+
+@pytest.mark.parametrize("n,c_in,nodes_per_graph,with_lin", [(5000, 26, 1001, False), (5000, 128, 1001, True), (70, 26, 7, True),
+                                                             (4097, 128, 50, False), (300, 24, 11, True), (333, 64, 40, True)])
+def test_gin_layer_split_against_fp64(dev, n, c_in, nodes_per_graph, with_lin):
+    """gnnpn_gin_layer_split — the layer's three dense products on the fp16 matrix cores through the exact 3-piece split —
+    against an fp64 evaluation of the layer (from the SAME fp32 aggregate; intermediates rounded to fp32 where both kernels
+    round them), next to the fp32 layer's error: the split build must be at least as close (factor 1.25 of slack on the
+    maximum, none needed so far), and the packed weight pieces must sum to the weights bit for bit."""
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + c_in)
+    i = torch.arange(n - 1)
+    keep = (i + 1) % nodes_per_graph != 0
+    src = torch.stack([i[keep], i[keep] + 1], 1).reshape(-1)
+    dst = torch.stack([i[keep] + 1, i[keep]], 1).reshape(-1)
+    extra = torch.randint(0, n, (2, n // 3), generator=g)
+    csr = graph.csr_by_destination(torch.cat([torch.stack([src, dst]), extra], 1), n).to(dev)
+    x = (torch.randn(n, c_in, generator=g) * torch.exp(2 * torch.randn(n, 1, generator=g))).to(dev)   # rows of very different magnitude
+    x[5] = 0.0
+    eps = torch.tensor([0.07], device=dev)
+    mk = lambda *s: (torch.randn(*s, generator=g) / s[-1] ** 0.5).to(dev)   # noqa: E731
+    w1, b1, w2, b2, w3, b3 = mk(256, c_in), mk(256), mk(128, 256), mk(128), mk(128, 128), mk(128)
+    a1, s1, a2, s2 = (torch.rand(256, generator=g) + 0.5).to(dev), mk(256), (torch.rand(128, generator=g) + 0.5).to(dev), mk(128)
+    p1, p2, p3 = ops.pack_split_weights(w1), ops.pack_split_weights(w2), ops.pack_split_weights(w3)
+    for (pk, inv), w in ((p1, w1), (p2, w2), (p3, w3)):
+        assert np.array_equal(_unpack_split_weights(pk, inv, *w.shape), w.double().cpu().numpy())
+    got = ops.gin_layer_split(csr.rowptr, csr.col, x, eps, *p1, b1, a1, s1, *p2, b2, a2, s2,
+                              *(p3 if with_lin else (None, None)), b3 if with_lin else None)
+    f32 = ops.gin_layer(csr.rowptr, csr.col, x, eps, ops.pack_mfma_b32(w1), b1, a1, s1, ops.pack_mfma_b32(w2), b2, a2, s2,
+                        ops.pack_mfma_b32(w3) if with_lin else None, b3 if with_lin else None)
+    agg = ops.csr_aggregate(csr.rowptr, csr.col, None, x, self_coef=eps).double()
+    D = lambda t: t.double()   # noqa: E731
+    t = torch.relu((agg @ D(w1).t() + D(b1)) * D(a1) + D(s1)).float().double()           # both kernels hold T in fp32
+    ref = torch.relu((t @ D(w2).t() + D(b2)) * D(a2) + D(s2))
+    if with_lin:
+        ref = ref.float().double() @ D(w3).t() + D(b3)
+    assert got.shape == f32.shape == ref.shape
+    scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)                               # per row: rows differ by orders of magnitude
+    e_split, e_f32 = ((got.double() - ref).abs() / scale), ((f32.double() - ref).abs() / scale)
+    assert torch.isfinite(got).all()
+    assert e_split.max().item() <= 1.25 * e_f32.max().item() + 1e-7, (e_split.max().item(), e_f32.max().item())
+    assert e_split.mean().item() <= 1.25 * e_f32.mean().item() + 1e-9, (e_split.mean().item(), e_f32.mean().item())
+    assert e_split.max().item() < 5e-6
+    with pytest.raises(ops.GnnpnError):
+        ops.gin_layer_split(csr.rowptr, csr.col, x, eps, *p2, b1, a1, s1, *p2, b2, a2, s2)     # weights that do not chain
+    assert not ops.gin_layer_split_supported(256, 256, 128) and ops.gin_layer_split_supported(c_in, 256, 128, 128)
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation

@@ -565,7 +565,16 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
     runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
     assert runner.halves == (shape != "qws_two_slots")
     packed = [runner.pack(b) for b in batches]
+    # the single-stream reference runs use the device's default workspaces: their status is checked like the runner's (an eager
+    # launch that reported a failed hand-off would make a wrong REFERENCE — seen on some boxes of the pool, see DESIGN.md section 7;
+    # it is re-run once and the event recorded)
+    from gnnpn_sc_amd import ops as _ops_mod
+    eager_retries = 0
     refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    if _ops_mod.workspaces(dev).poll():
+        eager_retries = 1
+        refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+        _ops_mod.workspaces(dev).check("the single-stream reference run (second attempt)")
     keys = ("idx_low", "idx_high", "R")
     side = torch.cuda.Stream()
     lib = _lib.load()
@@ -607,7 +616,9 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
            "problems_per_s_with_interferer_every_step": round(with_it, 1), "loss_pct_every_step": round((1 - with_it / ref_rate) * 100, 2),
            "problems_per_s_with_interferer_every_8th_step": round(with_8, 1), "loss_pct_every_8th_step": round((1 - with_8 / ref_rate) * 100, 2),
            "interferer": "1-2 bursts of 8-32 workgroups x 64-96 KB LDS x 20-50 us on a third stream",
-           "placement_last_launch": [w.placement() for w in runner.workspaces]}
+           "placement_last_launch": [w.placement() for w in runner.workspaces],
+           "steps_with_wrong_outputs": {"without": [bad0, bad2], "every_step": bad1, "every_8th_step": bad3},
+           "reference_runs_repeated_after_a_failed_handoff": eager_retries}
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity", f"interferer_soak_{shape}.json"), "w") as f:
         json.dump(rec, f)

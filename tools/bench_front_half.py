@@ -1,5 +1,6 @@
 """The workflow (GIN) branch at the 1000-task shapes: one launch per GIN layer (gnnpn_gin_layer_f32, nodeLin behind the last)
-against the layered path (csr_aggregate + linear + linear per layer, nodeLin), same bits.
+against the layered path (csr_aggregate + linear + linear per layer, nodeLin), same bits; and the one-launch layer on the fp16
+matrix cores through the exact split (gnnpn_gin_layer_split).
     python tools/bench_front_half.py [--workload synth4] [--batch 512]"""
 import argparse, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,15 +35,19 @@ def timed(fn):
     return best
 
 
-run = lambda: net.request_embedding(batch.x, batch.wf_csr, batch.seg_ptr, batch.max_nodes)   # noqa: E731
+run = lambda prec="f32": net.request_embedding(batch.x, batch.wf_csr, batch.seg_ptr, batch.max_nodes, prec)   # noqa: E731
 net.fuse_gin_layers = False
 want = run()
 ms_layered = timed(run)
 net.fuse_gin_layers = True
 got = run()
 ms_fused = timed(run)
+split = run("split")
+ms_split = timed(lambda: run("split"))
+rel = ((split.double() - got.double()).abs().amax() / got.double().abs().amax()).item()
 rows = batch.x.shape[0]
 flop = rows * 2 * (26 * 256 + 256 * 128 + 128 * 256 + 256 * 128 + 128 * 128)
 print(json.dumps({"workload": a.workload, "problems": B, "rows": rows, "layered_ms": round(ms_layered, 4), "fused_ms": round(ms_fused, 4),
+                  "fused_split_ms": round(ms_split, 4), "split_vs_f32_max_rel_diff": rel,
                   "bit_identical": bool(torch.equal(got, want)), "dense_GFLOP": round(flop / 1e9, 1),
                   "fused_TFLOPs_incl_aggregate_and_mean": round(flop / ms_fused / 1e9, 1)}))
