@@ -552,12 +552,14 @@ def main():
 
     timers = KernelTimers()
     if not args.no_kernel_timers:
-        timers.wrap(ops, "lstm_encode", "lstm_encode")
-        timers.wrap(ops, "pointer_decode", "pointer_decode")
-        timers.wrap(ops, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
-        timers.wrap(ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
-        if hasattr(ops, "request_branch"):
-            timers.wrap(ops, "request_branch", "request_branch")
+        # the mirrors reach the kernels through the C++ operators: the two recurrent launches and the GCN aggregate through
+        # custom_ops' callers, the rest as torch.ops.gnnpn.* (an attribute of the namespace object: wrapped the same way)
+        from gnnpn_sc_amd import custom_ops
+        timers.wrap(custom_ops, "lstm_encode", "lstm_encode")
+        timers.wrap(custom_ops, "pointer_decode", "pointer_decode")
+        timers.wrap(torch.ops.gnnpn, "linear", "pregates_gemm", select=lambda a, wt, *r, **k: tuple(wt.shape) == (1024, 256))
+        timers.wrap(custom_ops, "csr_aggregate", "csr_aggregate_gcn", select=lambda rp, c, wv, *r, **k: wv is not None)
+        timers.wrap(torch.ops.gnnpn, "request_branch", "request_branch")
 
     # Steps are independent batches.  Default: pipeline.PipelinedRunner — `inflight` slots, each one
     # captured HIP graph of the whole pass with its own stream, static inputs/outputs and hand-off workspaces; step i

@@ -63,12 +63,37 @@ def build(force=False):
     _check_compiler()
     if force:
         for f in os.listdir(os.path.join(HERE, "build")):
-            os.remove(os.path.join(HERE, "build", f))
+            if os.path.isfile(os.path.join(HERE, "build", f)):
+                os.remove(os.path.join(HERE, "build", f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(LIB, objs):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    build_torch_ops(force)
     return LIB
+
+
+TORCH_LIB = os.path.join(HERE, "libgnnpn_torch.so")
+
+
+def build_torch_ops(force=False):
+    """libgnnpn_torch.so: the C++ registration of the ``gnnpn::`` operators (csrc/torch_ops.cpp — TORCH_LIBRARY schemas and CUDA
+    implementations over the C ABI).  Host code only: the host compiler against torch's headers, linked to torch's libraries and to
+    libgnnpn_hip.so (found beside it through $ORIGIN)."""
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    if not (force or _stale(TORCH_LIB, [src, os.path.join(ROOT, "include", "gnnpn_hip.h"), LIB])):
+        return TORCH_LIB
+    import torch
+    from torch.utils import cpp_extension
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"] +
+           ["-I" + p for p in cpp_extension.include_paths()] + ["-I" + os.path.join(rocm, "include"), "-I" + os.path.join(ROOT, "include"),
+            src, "-o", TORCH_LIB, "-L" + tlib, "-L" + HERE, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-lgnnpn_hip",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib])
+    subprocess.run(cmd, check=True)
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

@@ -1,10 +1,14 @@
-"""PyTorch-ROCm custom operators of the ML+2PN path: one ``gnnpn::`` namespace registered with ``torch.library``
-(SURVEY.md section 8b "Custom-op layer"), each operator implemented for the CUDA (= HIP on ROCm) dispatch key ONLY by a
-call into the C ABI of libgnnpn_hip.so (``ops.py`` -> ``include/gnnpn_hip.h``).  There is no CPU kernel registered:
-calling an operator with host tensors fails in the dispatcher ("Could not run 'gnnpn::...' with arguments from the
-'CPU' backend"), and a missing library raises ``GnnpnError`` — never a silent fallback.
+"""PyTorch-ROCm custom operators of the ML+2PN path: one ``gnnpn::`` namespace registered FROM C++ (``csrc/torch_ops.cpp``:
+TORCH_LIBRARY schemas + TORCH_LIBRARY_IMPL for the CUDA (= HIP on ROCm) dispatch key, built by ``build.py`` into the in-tree
+``libgnnpn_torch.so``; SURVEY.md section 8b "Custom-op layer").  Each operator is a C++ call into the C ABI of libgnnpn_hip.so
+(``include/gnnpn_hip.h``) on the current HIP stream.  There is no CPU kernel registered: calling an operator with host tensors
+fails in the dispatcher ("Could not run 'gnnpn::...' with arguments from the 'CPU' backend"), and a missing library raises
+``GnnpnError`` — never a silent fallback.  This module loads the library and keeps the few callers that turn the mirrors'
+dicts of tensors into the operators' flat argument lists (and resolve ``ops.Workspaces`` to the workspace / status tensors the
+recurrent operators take).  ``ops.py`` stays the ctypes binding of the same C ABI (tests, tools, the training step).
 
-    torch.ops.gnnpn.linear / embed_concat / csr_aggregate / gcn_norm / segment_mean
+    torch.ops.gnnpn.linear / embed_concat / gcn_norm / segment_mean
+    torch.ops.gnnpn.csr_aggregate (gather) / csr_aggregate_blocks / csr_aggregate_tiled   (form chosen by ``csr_aggregate`` below)
     torch.ops.gnnpn.request_branch             (the whole GIN branch of small workflow graphs in one launch)
     torch.ops.gnnpn.gin_layer                  (one GIN layer of large workflow graphs in one launch)
     torch.ops.gnnpn.gin_layer_split            (the same on the fp16 matrix cores through the exact split)
@@ -18,116 +22,83 @@ The mirrors of the reference's modules (modelML.Net, modelPN.PointerNet / Combin
 operators; operands are borrowed, outputs are allocated by the operator, work is enqueued on the current HIP stream
 (so the operators are capturable into HIP graphs).  Inference only: no autograd formulas are registered.
 """
+import os
+
 import torch
-from torch.library import Library
 
-from . import ops
+from . import _lib, ops
 
-_DEF = Library("gnnpn", "DEF")
-_IMPL = Library("gnnpn", "IMPL", "CUDA")
-
-# fixed order of the per-net operands of pointer_decode (None = absent)
 DECODE_KEYS = ("enc_out", "h0", "c0", "start", "wih", "whh", "bih", "bhh", "embedded", "emb_w", "emb_b",
                "xw_fold", "xb_fold", "start_fold", "latent_win")
 DECODE_OUTS = ("idx", "win_logits", "pick_prob", "actions", "queries")
 ENCODE_KEYS = ("pregates", "inputs", "w_in", "b_in", "whh", "bhh")
+REQUEST_LAYER_KEYS = ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")
+
+TORCH_LIB_PATH = os.environ.get("GNNPN_TORCH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgnnpn_torch.so")
 
 
-def _op(schema, fn):
-    _DEF.define(schema)
-    _IMPL.impl(schema.split("(")[0], fn)
+def _load():
+    """Load libgnnpn_torch.so (csrc/torch_ops.cpp): its static initialisers register the ``gnnpn::`` schemas and the CUDA
+    implementations with the dispatcher.  The kernel library is loaded first (same path the ctypes binding uses; an ABI mismatch or
+    a missing file raises GnnpnError) — the operator library links to it and finds it beside itself."""
+    _lib.load()
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise _lib.GnnpnError(f"{TORCH_LIB_PATH} is missing: build it with `python gnnpn-sc_amd/build.py` (the gnnpn:: operators are "
+                              "registered from C++; there is no Python or CPU fallback)")
+    torch.ops.load_library(TORCH_LIB_PATH)
 
 
-def _ws(ws_id):
-    return None if ws_id < 0 else ops.workspaces_by_id(ws_id)
+_load()
 
 
-_op("linear(Tensor a, Tensor weight, Tensor? bias=None, Tensor? scale=None, Tensor? shift=None, int act=0) -> Tensor",
-    lambda a, weight, bias=None, scale=None, shift=None, act=0: ops.linear(a, weight, bias, scale, shift, act))
-_op("embed_concat(Tensor x, Tensor table) -> Tensor", ops.embed_concat)
-_op("csr_aggregate(Tensor rowptr, Tensor col, Tensor? w, Tensor x, Tensor? self_coef=None, Tensor? bias=None, "
-    "Tensor? scale=None, Tensor? shift=None, int act=0, int block_rows=0) -> Tensor",
-    lambda rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0, block_rows=0:
-    ops.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act, block_rows))
-def _request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layer_tensors, lin_w_packed, lin_b, hidden):
-    keys = ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")
-    layers = [dict(zip(keys, layer_tensors[i:i + len(keys)])) for i in range(0, len(layer_tensors), len(keys))]
-    return ops.request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layers, lin_w_packed, lin_b, hidden)
+# ---- thin callers used by the mirrors: dict-of-tensors in, torch.ops.gnnpn.* (C++) underneath ---------------------------
+
+def _gnnpn_errors(fn):
+    """An operator's c10::Error (RuntimeError: bad operand, a shape the kernels are not built for, a failed launch) as the
+    package's GnnpnError, which the mirrors' callers catch (it IS a RuntimeError)."""
+    import functools
+
+    @functools.wraps(fn)
+    def call(*a, **k):
+        try:
+            return fn(*a, **k)
+        except _lib.GnnpnError:
+            raise
+        except RuntimeError as e:
+            raise _lib.GnnpnError(str(e).split("\nException raised from")[0]) from None
+    return call
 
 
-_op("request_branch(Tensor x, Tensor table, Tensor rowptr, Tensor col, Tensor seg_ptr, int max_nodes, "
-    "Tensor[] layer_tensors, Tensor lin_w_packed, Tensor lin_b, int hidden) -> Tensor", _request_branch)
-_op("gin_layer(Tensor rowptr, Tensor col, Tensor x, Tensor eps, Tensor w1, Tensor? b1, Tensor? a1, Tensor? s1, Tensor w2, Tensor? b2, "
-    "Tensor? a2, Tensor? s2, Tensor? w3=None, Tensor? b3=None) -> Tensor", ops.gin_layer)
-_op("gin_layer_split(Tensor rowptr, Tensor col, Tensor x, Tensor eps, Tensor w1, Tensor i1, Tensor? b1, Tensor? a1, Tensor? s1, "
-    "Tensor w2, Tensor i2, Tensor? b2, Tensor? a2, Tensor? s2, Tensor? w3=None, Tensor? i3=None, Tensor? b3=None) -> Tensor",
-    ops.gin_layer_split)
-_op("gcn_norm(Tensor rowptr, Tensor col, Tensor w_raw) -> Tensor", ops.gcn_norm)
-_op("segment_mean(Tensor segptr, Tensor x) -> Tensor", ops.segment_mean)
-_op("segment_topk_feasible(Tensor scores, Tensor cat_ptr, Tensor qos, Tensor local_bounds, Tensor present, "
-    "Tensor global_bounds, int n_per) -> (Tensor, Tensor)", ops.select_candidates)
-_op("rank_rows(Tensor scores) -> Tensor", ops.rank_rows)
-_op("precision_at_k(Tensor ranking, Tensor labels, int[] ks) -> Tensor",
-    lambda ranking, labels, ks: ops.precision_at_k(ranking, labels, tuple(ks)))
-_op("attention_logits(Tensor enc_out, Tensor queries, int step, Tensor idx, float tanh_c, bool use_tanh) -> Tensor",
-    ops.attention_logits)
-_op("qos_reward(Tensor actions, int level) -> Tensor",
-    lambda actions, level: ops.qos_reward(actions, "Low" if level == 0 else "High"))
+def _coop_ws(device, H, n_per, impl, ws):
+    """The workspaces a cooperative launch needs (None for shapes that take the streaming form)."""
+    return ops.workspaces(device, ws) if ops.coop_supported(H, n_per, impl) else None
 
 
-def _lstm_encode(net_tensors, n_nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, paired_start=False):   # defaults = the schema's: the dispatcher omits arguments that equal them
-    n = len(ENCODE_KEYS)
-    nets = [{k: net_tensors[i * n + j] for j, k in enumerate(ENCODE_KEYS)} for i in range(n_nets)]
-    enc, h_n, c_n = ops.lstm_encode(nets, precision, impl, lds_kb, write_through, _ws(ws_id), paired_start)
-    return list(enc) + list(h_n) + list(c_n)
-
-
-_op("lstm_encode(Tensor?[] net_tensors, int n_nets, str precision='f32', int impl=0, int lds_kb=0, "
-    "bool write_through=False, int ws=-1, bool paired_start=False) -> Tensor[]", _lstm_encode)
-
-
-def _pointer_decode(net_tensors, latent_from, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False,
-                    precision="f32", impl=0, lds_kb=0, write_through=False, ws_id=-1, sample_seeds=(), paired_start=False):
-    n = len(DECODE_KEYS)
-    nets = []
-    for i, lf in enumerate(latent_from):
-        d = {k: net_tensors[i * n + j] for j, k in enumerate(DECODE_KEYS)}
-        d["latent_from"] = lf
-        if i < len(sample_seeds) and sample_seeds[i] >= 0:      # >= 0: draw this net's picks from the stream of that seed
-            d["sample"], d["sample_seed"] = True, sample_seeds[i]
-        nets.append(d)
-    outs = ops.pointer_decode(nets, inputs, n_cat, n_per, tanh_c, use_tanh, want_queries, precision, impl, lds_kb,
-                              write_through, _ws(ws_id), paired_start)
-    flat = []
-    for o in outs:
-        for k in DECODE_OUTS:
-            flat.append(o[k] if o[k] is not None else inputs.new_empty(0))
-    return flat
-
-
-_op("pointer_decode(Tensor?[] net_tensors, int[] latent_from, Tensor inputs, int n_cat, int n_per, float tanh_c=10.0, "
-    "bool use_tanh=True, bool want_queries=False, str precision='f32', int impl=0, int lds_kb=0, "
-    "bool write_through=False, int ws=-1, int[] sample_seeds=[], bool paired_start=False) -> Tensor[]", _pointer_decode)
-
-
-# ---- thin callers used by the mirrors: dict-of-tensors in, torch.ops.gnnpn.* underneath ------------------------------
-
+@_gnnpn_errors
 def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws=None, paired_start=False):
+    """n nets in one launch (gnnpn_lstm_encode_f32): see ops.lstm_encode for the operands.  -> (enc_out list, h_n list, c_n list)"""
     flat = [d.get(k) for d in nets for k in ENCODE_KEYS]
+    first = nets[0]["pregates"] if nets[0].get("pregates") is not None else nets[0]["inputs"]
+    wsp = _coop_ws(first.device, nets[0]["bhh"].numel() // 4, 1, impl, ws)
     out = torch.ops.gnnpn.lstm_encode(flat, len(nets), precision, impl, lds_kb, bool(write_through),
-                                      -1 if ws is None else ws.id, bool(paired_start))
+                                      None if wsp is None else wsp.encode(), None if wsp is None else wsp.status, bool(paired_start))
     n = len(nets)
     return out[:n], out[n:2 * n], out[2 * n:]
 
 
+@_gnnpn_errors
 def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_queries=False, precision="f32", impl=0,
                    lds_kb=0, write_through=False, ws=None, paired_start=False):
+    """1 or 2 nets in one launch (gnnpn_pointer_decode_f32): see ops.pointer_decode.  -> one dict per net (DECODE_OUTS)"""
     flat = [d.get(k) for d in nets for k in DECODE_KEYS]
     lf = [int(d.get("latent_from", -1)) for d in nets]
     seeds = [int(d["sample_seed"]) & 0x7FFFFFFFFFFFFFFF if d.get("sample") else -1 for d in nets]
+    B, L, H = nets[0]["enc_out"].shape
+    wsp = _coop_ws(inputs.device, H, n_per, impl, ws)
     out = torch.ops.gnnpn.pointer_decode(flat, lf, inputs, n_cat, n_per, float(tanh_c), bool(use_tanh), bool(want_queries),
-                                         precision, impl, lds_kb, bool(write_through), -1 if ws is None else ws.id, seeds,
-                                         bool(paired_start))
+                                         precision, impl, lds_kb, bool(write_through),
+                                         None if wsp is None else wsp.decode(B, n_cat, n_per), None if wsp is None else wsp.status,
+                                         seeds, bool(paired_start))
     m = len(DECODE_OUTS)
     res = []
     for i in range(len(nets)):
@@ -136,3 +107,32 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
             d["queries"] = None
         res.append(d)
     return res
+
+
+@_gnnpn_errors
+def request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layers, lin_w_packed, lin_b, hidden):
+    """The whole GIN branch of small workflow graphs in one launch; ``layers``: list of dicts (REQUEST_LAYER_KEYS)."""
+    flat = [lp[k] for lp in layers for k in REQUEST_LAYER_KEYS]
+    return torch.ops.gnnpn.request_branch(x, table, rowptr, col, seg_ptr, int(max_nodes), flat, lin_w_packed, lin_b, int(hidden))
+
+
+@_gnnpn_errors
+def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0, block_rows=0):
+    """The CSR aggregate with the form chosen as ops.csr_aggregate chooses it (tiled where the graph's plan is valid, whole-block LDS
+    where a block fits with 16-channel slices, else the gather; bit-identical every way) — the policy and the per-graph caches
+    (tile plan, row order) live in ops.py, the launch goes through the C++ operators."""
+    n = rowptr.numel() - 1
+    C = x.shape[1]
+    if ops.PREFER_TILED_AGGREGATE is not False and block_rows > 0 and C % 16 == 0 and n > 0 and x.data_ptr() % 16 == 0 and \
+            (ops.PREFER_TILED_AGGREGATE or -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= ops.TILED_MIN_WORKGROUPS):
+        plan = ops.csr_tile_plan(rowptr, col, w, block_rows)
+        if plan is not None and plan.valid:
+            return torch.ops.gnnpn.csr_aggregate_tiled(plan.header, plan.order, plan.selfw, plan.batches, x, self_coef, bias, scale, shift,
+                                                       act, plan.n_rows, plan.block_rows)
+    rows_max = ops.LDS_BLOCK_ROWS_MAX if ops.PREFER_LDS_AGGREGATE else ops.LDS_SLICE16_ROWS_MAX
+    if ops.PREFER_LDS_AGGREGATE is not False and 0 < block_rows <= rows_max and C % 4 == 0 and n > 0:
+        lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and (block_rows + 1) * 16 * c <= 160 * 1024)
+        if (lpr == 4 or ops.PREFER_LDS_AGGREGATE) and -(-n // block_rows) * (C // (4 * lpr)) >= ops.LDS_MIN_WORKGROUPS:
+            order = ops.csr_block_row_order(rowptr, block_rows) if block_rows <= 16384 else None
+            return torch.ops.gnnpn.csr_aggregate_blocks(rowptr, col, w, x, self_coef, bias, scale, shift, act, int(block_rows), order)
+    return torch.ops.gnnpn.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act)

@@ -246,8 +246,8 @@ class Net(nn.Module):
                 svc_csr._gcn_norm = norm
         for lp in p["gcn"]:                                                                     # :152-155
             xw = torch.ops.gnnpn.linear(xs, lp["wt"])                                                       # transform first
-            xs = torch.ops.gnnpn.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
-                                               shift=lp["s"], act=ACT_RELU, block_rows=svc_csr.block_rows)
+            xs = custom_ops.csr_aggregate(svc_csr.rowptr, svc_csr.col, norm, xw, bias=lp["bias"], scale=lp["a"],
+                                          shift=lp["s"], act=ACT_RELU, block_rows=svc_csr.block_rows)   # form chosen per graph
         return torch.ops.gnnpn.linear(xs, *p["serviceLin"])                                                 # :164
 
     @torch.no_grad()

@@ -65,6 +65,40 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
         _lib.load()
 
 
+GNNPN_OPERATORS = ("linear", "embed_concat", "csr_aggregate", "csr_aggregate_blocks", "csr_aggregate_tiled", "gcn_norm", "segment_mean",
+                   "request_branch", "gin_layer", "gin_layer_split", "segment_topk_feasible", "rank_rows", "precision_at_k",
+                   "attention_logits", "qos_reward", "lstm_encode", "pointer_decode")
+
+
+def test_operators_are_registered_from_cpp():
+    """The gnnpn:: operators come from libgnnpn_torch.so (csrc/torch_ops.cpp, built in-tree by build.py): importing custom_ops
+    loads it, every operator is there with a C++ kernel for the CUDA key and none for the CPU key (host tensors fail in the
+    dispatcher — no fallback), and nothing in custom_ops.py registers an implementation from Python."""
+    import __graft_entry__ as entry
+    entry.build()
+    from gnnpn_sc_amd import custom_ops
+    assert os.path.exists(custom_ops.TORCH_LIB_PATH) and os.path.dirname(custom_ops.TORCH_LIB_PATH) == os.path.join(ROOT, "gnnpn-sc_amd")
+    with open("/proc/self/maps") as f:
+        assert "libgnnpn_torch.so" in f.read()
+    for name in GNNPN_OPERATORS:
+        op = getattr(torch.ops.gnnpn, name)
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"gnnpn::{name}", "CUDA"), name
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"gnnpn::{name}", "CPU"), name
+        assert op.default._schema.name == f"gnnpn::{name}"
+    with pytest.raises((NotImplementedError, RuntimeError), match="CPU"):
+        torch.ops.gnnpn.linear(torch.rand(4, 8), torch.rand(3, 8))
+    with open(os.path.join(ROOT, "gnnpn-sc_amd", "custom_ops.py")) as f:
+        src = f.read()
+    assert "torch.library" not in src and ".impl(" not in src and ".define(" not in src
+
+
+def test_missing_operator_library_is_loud(monkeypatch, tmp_path):
+    from gnnpn_sc_amd import _lib, custom_ops
+    monkeypatch.setattr(custom_ops, "TORCH_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.GnnpnError, match="no Python or CPU fallback"):
+        custom_ops._load()
+
+
 def test_product_does_not_import_oracle():
     """oracle/ is test infrastructure: nothing under gnnpn-sc_amd/ may reference it."""
     pkg = os.path.join(ROOT, "gnnpn-sc_amd")
