@@ -211,7 +211,23 @@ __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_glimpse_kern
             }
             float denom = 0.0f;
             for (int r = 0; r < n_per; ++r) denom = __fadd_rn(denom, expf(__fsub_rn(win[r], best)));
-            net.pick_prob[(int64_t)b * T + k] = 1.0f / denom;
+            float prob = 1.0f / denom;
+            if (net.sample) {   // multinomial(1) from the window softmax (modelPN.py:227-228): first r with u < cdf_r — the draw of
+                                // decode.hip, from the same counter-based stream (problem b, step k -> counter b * T + k)
+                const float u = stream_uniform24(net.sample_seed, (unsigned long long)b * T + k);
+                float cdf = 0.0f;
+                int pick = -1, last_pos = 0;
+                for (int r = 0; r < n_per; ++r) {
+                    const float pr = expf(__fsub_rn(win[r], best)) / denom;
+                    cdf = __fadd_rn(cdf, pr);
+                    if (pr > 0.0f) last_pos = r;
+                    if (pick < 0 && u < cdf) pick = r;
+                }
+                if (pick < 0) pick = last_pos;
+                best_r = pick;
+                prob = expf(__fsub_rn(win[pick], best)) / denom;
+            }
+            net.pick_prob[(int64_t)b * T + k] = prob;
             net.idx[(int64_t)b * T + k] = k * n_per + best_r;
             sel = k * n_per + best_r;
             chosen[k] = k * n_per + best_r;
@@ -263,7 +279,7 @@ extern "C" int gnnpn_pointer_decode_attn_f32(const gnnpn_decode_net_t* net_in, c
     GNNPN_REQUIRE(net.embedded && net.enc_out && net.h0 && net.c0 && net.start && net.wih && net.whh && net.bih && net.bhh,
                   "pointer_decode_attn: embedded, enc_out, h0, c0, start and the decoder weights are required");
     GNNPN_REQUIRE(net.idx && net.win_logits && net.pick_prob && net.actions, "pointer_decode_attn: output pointers required");
-    GNNPN_REQUIRE(!net.sample, "pointer_decode_attn: greedy only");
+    GNNPN_REQUIRE(net.sample == 0 || net.sample == 1, "pointer_decode_attn: sample must be 0 (greedy) or 1 (multinomial)");
     AttnSide ptr{attn->pointer_wq, attn->pointer_bq, attn->pointer_ref, attn->pointer_v};
     AttnSide gl{attn->glimpse_wq, attn->glimpse_bq, attn->glimpse_ref, attn->glimpse_v};
     if (attn->attention == 1) {

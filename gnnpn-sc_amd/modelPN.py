@@ -12,8 +12,9 @@ Scope of this build = the configuration the reference ships
 the sampling mode (``sample='sample'``: every pick drawn from the window softmax, modelPN.py:227-228 — SURVEY.md §8f
 row 3; its REINFORCE step is trainPNHigh.py here).  The attention forms those configurations leave switched off —
 ``attention='Bahdanau'`` (modelPN.py:80-90,103-109) and ``n_glimpses > 0`` (:208-211), SURVEY.md §8f row 4 — decode through
-the general kernel (gnnpn_pointer_decode_attn_f32: greedy, one net per call).  ``embedding_size != 0`` raises
-``NotImplementedError``.
+the general kernel (gnnpn_pointer_decode_attn_f32: one net per call, greedy or sampled).  ``embedding_size != 0``
+(embeddingTag=1: rows [category | 8 floats], modelPN.py:153-154,183-188) decodes one net per call as well; its sampled form takes
+the streaming decode kernel.  Those forms run in fp32 (the exact-split builds are the shipped configuration's).
 """
 import math
 
@@ -238,17 +239,16 @@ class PointerNet(nn.Module):
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
         enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
+        impl = 0
         if self.embedding_size != 0:          # the decode kernels gather 8-feature action rows: the category column rejoins below
-            if sample_seed is not None:
-                raise NotImplementedError("sampling with embedding_size != 0: the cooperative sampling build is the folded one")
             rows9, inputs = inputs, inputs[:, :, 1:].contiguous()
             fold = False
-        if self.general:
-            if sample_seed is not None:
-                raise NotImplementedError("sampling with 'Bahdanau' attention / glimpses: the general decode kernel is greedy")
+            if sample_seed is not None:       # the cooperative build that draws is the folded one: sampled decodes of the embedding
+                impl = 1                      # form take the per-workgroup streaming kernel (same draws, same arithmetic)
+        if self.general:                      # (greedy or drawn: gnnpn_pointer_decode_attn_f32 takes the same sample / seed fields)
             out = ops.pointer_decode_attn(
                 self.decode_args(embedded, enc[0], h_n[0], c_n[0], _window_tensor(latent, self.serCategory, self.serNumber),
-                                 fold=False),
+                                 fold=False, sample_seed=sample_seed),
                 inputs, self.serCategory, self.serNumber, self.attention, self.n_glimpses, self.pointer.side(),
                 self.glimpse.side(), self.C, self.use_tanh, want_queries)
             out["enc_out"] = enc[0]
@@ -256,7 +256,7 @@ class PointerNet(nn.Module):
         out = custom_ops.pointer_decode(
             [self.decode_args(embedded, enc[0], h_n[0], c_n[0],
                               _window_tensor(latent, self.serCategory, self.serNumber), fold=fold, sample_seed=sample_seed)],
-            inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries)[0]
+            inputs, self.serCategory, self.serNumber, self.C, self.use_tanh, want_queries, impl=impl)[0]
         out["enc_out"] = enc[0]
         return self._with_category(out, rows9) if self.embedding_size != 0 else out
 
@@ -394,10 +394,11 @@ def two_level_greedy(low, high, inputs, fold=None, precision=None, decode_impl=0
         precision = default_precision(low, high, fold, sample_high_seed is not None, decode_impl)
     if la.general or ha.general or la.embedding_size != 0 or ha.embedding_size != 0:
         # 'Bahdanau' attention / glimpses / the category embedding (embeddingTag=1): one net per call
-        if sample_high_seed is not None or precision != "f32":
-            raise NotImplementedError("the general attention forms and the embedding form decode greedily in fp32")
+        if precision != "f32":
+            raise NotImplementedError("the general attention forms and the embedding form decode in fp32")
         dl = la.run(inputs, None, fold=fold)
-        dh = ha.run(inputs, LatentWindows(dl["win_logits"], dl["idx"], None, None, la.C, la.use_tanh), fold=fold)
+        dh = ha.run(inputs, LatentWindows(dl["win_logits"], dl["idx"], None, None, la.C, la.use_tanh), fold=fold,
+                    sample_seed=sample_high_seed)                  # High drawn (modelPN.py:227-228) or greedy; Low greedy
         R = torch.ops.gnnpn.qos_reward(dh["actions"][..., -qosandcons:].contiguous(), 0 if high.level == "Low" else 1)
         return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
                 "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -692,6 +692,8 @@ def pointer_decode_attn(net, inputs, n_cat, n_per, attention="Dot", n_glimpses=0
     lw = net.get("latent_win")
     a.latent_win = None if lw is None else dev_ptr(lw, F32, "net.latent_win").value
     a.latent_from = -1
+    a.sample = int(bool(net.get("sample", False)))                 # draw every pick from the window softmax (stream of sample_seed)
+    a.sample_seed = int(net.get("sample_seed", 0)) & 0xFFFFFFFFFFFFFFFF
     a.idx = dev_ptr(out["idx"], I32, "idx").value
     a.win_logits = dev_ptr(out["win_logits"], F32, "win").value
     a.pick_prob = dev_ptr(out["pick_prob"], F32, "prob").value

@@ -425,7 +425,8 @@ int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* nets, const f
 
 /* The attention forms the reference's configurations leave switched off:
  * replaces PointerNet.forward's per-step body (modelPN.py:204-239) with attention 'Bahdanau' (:80-90,103-109) and / or
- * n_glimpses > 0 (:208-211).  One net per call (chain Low -> High through latent_win), greedy only.
+ * n_glimpses > 0 (:208-211).  One net per call (chain Low -> High through latent_win); greedy, or with net->sample the pick of
+ * every step drawn from the window softmax (:227-228) from the stream of net->sample_seed, as gnnpn_pointer_decode_f32 draws.
  *   attention    0 'Dot' | 1 'Bahdanau'
  *   n_glimpses   glimpse rounds per step (each: logits over all L positions, -inf at the positions chosen so far,
  *                softmax, query = ref' . softmax)

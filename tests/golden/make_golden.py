@@ -222,6 +222,59 @@ def gen_pn_sample(modelPN, name, H, T, K, B, seed, sample_seed):
           f"min draw margin {float(orc['margin_high'].min()):.2e}")
 
 
+def gen_pn_sample_forms(modelPN, name, H, T, K, B, seed, sample_seed, attention="Dot", n_glimpses=0, E=0):
+    """The sampling mode (modelPN.py:227-228) TOGETHER with the forms the shipped configurations leave switched off —
+    'Bahdanau' attention (:80-90,103-109), glimpse rounds (:208-211), the category embedding (:153-154,183-188) — through the
+    REAL modules: Low greedy -> latent, High with sample='sample', ``Tensor.multinomial`` routed to the counter-based stream as
+    in gen_pn_sample.  Inputs are stored (the embedding form's rows carry the category column)."""
+    sd_low = opn.make_state_dict(H, seed, attention=attention, embedding_size=E, n_cat=T)
+    sd_high = opn.make_state_dict(H, seed + 1, attention=attention, embedding_size=E, n_cat=T)
+    L = T * K
+
+    def build(level, sd):
+        m = modelPN.CombinatorialRL(E, H, L, n_glimpses, 10, 1, modelPN.reward, attention, K, T, use_cuda=False, level=level)
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+
+    low, high = build("Low", sd_low), build("High", sd_high)
+    x = pn_inputs(B, T, K, seed + 2, 0)
+    if E:
+        cat = torch.arange(T).repeat_interleave(K).float().view(1, L, 1).expand(B, L, 1)     # loadData.py:130-148: column 0 = the category
+        x = torch.cat([cat, x], 2).contiguous()
+    state = {"k": 0}
+    real = torch.Tensor.multinomial
+
+    def routed(self, num_samples=1, replacement=False, generator=None):
+        assert num_samples == 1
+        idx, _ = opn.multinomial_from_stream(self, state["k"], T, K, sample_seed)
+        state["k"] += 1
+        return idx.view(-1, 1)
+
+    torch.Tensor.multinomial = routed
+    buf = io.StringIO()
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(buf):
+            _, _, _, idx_low, latent = low(x, None, sample="greedy", training="SL")
+            R, probs, actions, idx_high, _ = high(x, None, latent)            # default sample="sample", training="RL"
+    finally:
+        torch.Tensor.multinomial = real
+    assert state["k"] == T and "RESAMPLE" not in buf.getvalue()
+    ref = {"idx_low": torch.stack(idx_low, 1), "idx_high": torch.stack(idx_high, 1), "R": R,
+           "actions": torch.stack(actions, 1), "action_probs": torch.stack(probs, 1)}
+    orc = opn.two_level_greedy(sd_low, sd_high, x, T, K, sample_high_seed=sample_seed, attention=attention, n_glimpses=n_glimpses)
+    for key in ref:
+        assert torch.equal(ref[key], orc[key]), f"oracle != reference on {key} ({name})"
+    greedy = opn.two_level_greedy(sd_low, sd_high, x, T, K, attention=attention, n_glimpses=n_glimpses)
+    frac = float((greedy["idx_high"] != ref["idx_high"]).float().mean())
+    out = {k: v.numpy() for k, v in ref.items()}
+    out.update(inputs=x.numpy(), hidden=H, n_cat=T, n_per=K, B=B, seed_low=seed, seed_high=seed + 1, sample_seed=sample_seed,
+               attention=attention, n_glimpses=n_glimpses, embedding_size=E,
+               margin_low=orc["margin_low"].numpy(), margin_high=orc["margin_high"].numpy())
+    np.savez_compressed(os.path.join(HERE, f"pn_sample_{name}.npz"), **out)
+    print(f"pn_sample_{name}: {attention} glimpses={n_glimpses} E={E} B={B} T={T} K={K} H={H}: {frac:.2f} of the sampled picks "
+          f"differ from the greedy ones; min draw margin {float(orc['margin_high'].min()):.2e}")
+
+
 def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
     """ONE REINFORCE step of the PNHigh trainer run on the REAL modules (trainPNHigh.py:83-108; the driver class itself
     imports IPython/matplotlib and is not importable here, so its loop body is driven by hand, line for line):
@@ -584,6 +637,11 @@ def main():
     gen_pn(modelPN, "saturated", H=256, T=12, K=5, B=8, seed=51, weight_scale=6.0)
     gen_pn_sample(modelPN, "small", H=32, T=6, K=3, B=8, seed=91, sample_seed=12345)
     gen_pn_sample(modelPN, "qws", H=256, T=47, K=5, B=64, seed=95, sample_seed=987654321)
+    gen_pn_sample_forms(modelPN, "bahdanau_g1_small", H=32, T=6, K=3, B=8, seed=151, sample_seed=2024, attention="Bahdanau", n_glimpses=1)
+    gen_pn_sample_forms(modelPN, "dot_g2_small", H=32, T=6, K=3, B=8, seed=153, sample_seed=2025, attention="Dot", n_glimpses=2)
+    gen_pn_sample_forms(modelPN, "embed_small", H=32, T=6, K=3, B=8, seed=155, sample_seed=2026, E=4)
+    gen_pn_sample_forms(modelPN, "bahdanau_g1_qws", H=256, T=47, K=5, B=16, seed=157, sample_seed=2027, attention="Bahdanau", n_glimpses=1)
+    gen_pn_sample_forms(modelPN, "embed_qws", H=256, T=47, K=5, B=16, seed=159, sample_seed=2028, E=20)
     gen_pn_train(modelPN, "small", H=32, T=6, K=3, B=8, seed=101, sample_seed=4242, full=True)
     gen_pn_train(modelPN, "qws", H=256, T=47, K=5, B=32, seed=105, sample_seed=777, full=False)
     gen_pn_attn(modelPN, "dot_g1_small", H=32, T=6, K=3, B=6, seed=111, attention="Dot", n_glimpses=1)

@@ -80,6 +80,49 @@ def test_attention_forms_golden(dev, name):
     assert torch.equal(R, out["R"])
 
 
+@pytest.mark.parametrize("name", ["bahdanau_g1_small", "dot_g2_small", "embed_small", "bahdanau_g1_qws", "embed_qws"])
+def test_sampled_attention_and_embedding_forms_golden(dev, name):
+    """The sampling mode (modelPN.py:227-228) combined with 'Bahdanau' attention, glimpse rounds and the category embedding
+    (:183-188,208-211): the general decode kernel (gnnpn_pointer_decode_attn_f32) and the streaming decoder draw every High pick
+    from the window softmax out of the counter-based stream — against fixtures the REAL modelPN.py produced in that mode with
+    Tensor.multinomial routed to the same stream.  Picks identical up to a problem's first fragile decision (a Low near-tie or a
+    draw within 1e-5 of a cdf boundary), action rows (with the category column) identical, action_probs within 1e-5, R."""
+    from conftest import record_agreement
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import CombinatorialRL, reward, two_level_greedy
+    from parity import TAU_DRAW
+    fx = golden(f"pn_sample_{name}.npz")
+    H, T, K, B, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"]), int(fx["embedding_size"])
+    att, ng, seed = str(fx["attention"]), int(fx["n_glimpses"]), int(fx["sample_seed"])
+    nets = []
+    for level, sd_seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
+        m = CombinatorialRL(E, H, T * K, ng, 10, 1, reward, att, K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, sd_seed, attention=att, embedding_size=E, n_cat=T), strict=True)
+        nets.append(m.to(dev).eval())
+    x = torch.from_numpy(fx["inputs"]).to(dev)
+    out = two_level_greedy(nets[0], nets[1], x, sample_high_seed=seed)
+    ops.check_status(dev)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, f"sample/{name}", fx["inputs"][:, :, -8:], tau_high=TAU_DRAW)
+    s = rec["same_mask"]
+    assert rec["identical_problems"] >= B - 2 and rec["robust_identical"] == rec["robust_problems"] > 0, rec
+    assert np.abs(out["action_probs"].cpu().numpy()[s] - fx["action_probs"][s]).max() < 1e-5
+    assert np.array_equal(out["actions"].cpu().numpy()[s], fx["actions"][s])
+    assert_R_parity(out["R"], fx["R"], f"sample/{name}", s)
+    rec.update(attention=att, n_glimpses=ng, embedding_size=E)
+    record_agreement(f"sampled_forms/{name}", rec)
+    greedy = two_level_greedy(nets[0], nets[1], x)
+    assert float((greedy["idx_high"] != out["idx_high"]).float().mean()) > 0.3          # the draws are not the argmax
+    # the reference's own entry point, default sample="sample": a function of (sample_seed, call number) of the actor
+    _, _, _, _, latent = nets[0](x, None, sample="greedy", training="SL")
+    nets[1].actor.sample_seed, nets[1].actor.sample_calls = 9, 0
+    R1, probs1, _, idx1, _ = nets[1](x, None, latent)
+    nets[1].actor.sample_calls = 0
+    R2, probs2, _, idx2, _ = nets[1](x, None, latent)
+    assert torch.equal(torch.stack(idx1), torch.stack(idx2)) and torch.equal(R1, R2) and torch.equal(torch.stack(probs1), torch.stack(probs2))
+    p = torch.stack(probs1, 1)
+    assert bool(((p > 0) & (p <= 1)).all())
+
+
 @pytest.mark.parametrize("name", ["small", "qws"])
 def test_category_embedding_golden(dev, name):
     """embedding_size != 0 (embeddingTag=1; modelPN.py:153-154,183-188): rows [category | 8 floats], the category embedded and
@@ -166,16 +209,17 @@ def test_reference_style_calls(dev, name):
 
 def test_unsupported_modes_fail_loudly(dev):
     from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
-    e = CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)      # the category embedding decodes greedily only
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    e = CombinatorialRL(20, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)      # the category embedding: greedy and sampled (round 4)
     xe = torch.cat([torch.arange(6.0).repeat_interleave(3).view(1, 18, 1).expand(2, 18, 1), torch.rand(2, 18, 8)], 2).to(dev)
-    with pytest.raises(NotImplementedError):
-        e(xe, None)                                                             # default sample="sample"
+    assert e(xe, None)[2][0].shape == (2, 9)                                    # default sample="sample"
     assert e(xe, None, sample="greedy")[2][0].shape == (2, 9)
     with pytest.raises(NotImplementedError):
         CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Luong", 3, 6)             # modelPN.py:116-117
-    g = CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Bahdanau", 3, 6).to(dev)  # the general forms decode greedily only
-    with pytest.raises(NotImplementedError):
-        g(torch.rand(2, 18, 8, device=dev), None)                               # default sample="sample"
+    g = CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Bahdanau", 3, 6).to(dev)  # the general forms: greedy and sampled (round 4)
+    assert len(g(torch.rand(2, 18, 8, device=dev), None)[3]) == 6               # default sample="sample"
+    with pytest.raises(NotImplementedError):                                    # ... in fp32: the exact-split builds are the shipped form's
+        two_level_greedy(g, g, torch.rand(2, 18, 8, device=dev), precision="split")
     m = CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)
     R, probs, actions, idxs, _ = m(torch.rand(2, 18, 8, device=dev), None)   # default sample="sample": the sampling forward
     assert R.shape == (2,) and len(idxs) == 6 and probs[0].shape == (2,)

@@ -236,6 +236,32 @@ def test_ml_oracle_batched_forward_reproduces_reference_glue():
     assert float((single - t("scores")).abs().max()) > 1e-3
 
 
+SAMPLED_FORMS = ["bahdanau_g1_small", "dot_g2_small", "embed_small", "bahdanau_g1_qws", "embed_qws"]
+
+
+@pytest.mark.parametrize("name", SAMPLED_FORMS)
+def test_pn_oracle_sampled_forms_reproduce_reference(name):
+    """pn_sample_<form>.npz: the real modelPN.py in sampling mode WITH 'Bahdanau' attention / glimpse rounds / the category
+    embedding (modelPN.py:183-188,208-211,227-228; Tensor.multinomial routed to the counter-based stream).  The oracle's sampled
+    forward of those forms reproduces picks, action_probs, action rows and R."""
+    from parity import TAU_DRAW, assert_R_parity, prefix_parity
+    fx = golden(f"pn_sample_{name}.npz")
+    torch.set_num_threads(1)
+    H, T, K, B, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"]), int(fx["embedding_size"])
+    att, ng = str(fx["attention"]), int(fx["n_glimpses"])
+    x = torch.from_numpy(fx["inputs"])
+    sds = [opn.make_state_dict(H, int(fx[k]), attention=att, embedding_size=E, n_cat=T) for k in ("seed_low", "seed_high")]
+    out = opn.two_level_greedy(sds[0], sds[1], x, T, K, sample_high_seed=int(fx["sample_seed"]), attention=att, n_glimpses=ng)
+    rec = prefix_parity(out["idx_low"], out["idx_high"], fx, name, x[:, :, -8:], tau_high=TAU_DRAW)
+    assert rec["identical_problems"] >= B - 1
+    s = rec["same_mask"]
+    assert np.allclose(out["action_probs"].numpy()[s], fx["action_probs"][s], rtol=0, atol=1e-6)
+    assert np.array_equal(out["actions"].numpy()[s], fx["actions"][s])
+    assert_R_parity(out["R"], fx["R"], name, s)
+    greedy = opn.two_level_greedy(sds[0], sds[1], x, T, K, attention=att, n_glimpses=ng)
+    assert float((greedy["idx_high"].numpy() != fx["idx_high"]).mean()) > 0.3
+
+
 @pytest.mark.parametrize("name", ["small", "qws"])
 def test_pn_oracle_sampling_mode_reproduces_reference(name):
     """pn_sample_*.npz: the real modelPN.py in sampling mode (Low greedy -> latent, High sample='sample', the forward of a
