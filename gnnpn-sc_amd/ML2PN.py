@@ -77,10 +77,10 @@ def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=
         hi = min(P, lo + batch_size)
         _, pb = ld.tables_from_dataset(ds, lo, hi)
         batch = DeviceBatch.from_problems(pb, dev)
-        out = pipe.run(svc, batch)
+        # a timed-out inter-workgroup hand-off must never reach an artefact file: checked per batch, repeated once if it happens
+        act = ops.run_checked(lambda attempt: pipe.run(svc, batch, write_through=attempt > 0)["actions"].cpu().numpy().astype(np.float64),
+                              dev)                                       # [b,T,8]
         rankings += pipe.rankings(svc, batch).cpu().tolist()
-        act = out["actions"].cpu().numpy().astype(np.float64)            # [b,T,8]
-        ops.check_status(dev)     # a timed-out inter-workgroup hand-off must never reach an artefact file
         for b in range(hi - lo):
             if lo + b >= n_train:
                 for t in range(T):

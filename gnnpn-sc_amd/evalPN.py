@@ -38,10 +38,12 @@ def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device=
     for lo in range(0, len(val_dataset), batch_size):
         items = [val_dataset[i][0] for i in range(lo, min(len(val_dataset), lo + batch_size))]
         inputs = torch.stack(items).to(dev)
-        out = two_level_greedy(low_model, model, inputs)
-        act = out["actions"].cpu().numpy()
-        ops.check_status(dev)     # a timed-out inter-workgroup hand-off must never reach the caller's artefacts
+        def batch_pass(attempt):
+            out = two_level_greedy(low_model, model, inputs, write_through=attempt > 0)
+            return out["actions"].cpu().numpy(), float(out["R"].mean().item())
+        # a timed-out inter-workgroup hand-off must never reach the caller's artefacts: checked per batch, repeated once if it happens
+        act, r_mean = ops.run_checked(batch_pass, dev)
         for a in range(serCategory):
             all_actions[a] += act[:, a, :].tolist()
-        val_tour.append(float(out["R"].mean().item()))
+        val_tour.append(r_mean)
     return all_actions, val_tour

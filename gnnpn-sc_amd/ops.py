@@ -522,6 +522,26 @@ def check_status(device=None):
             w.check()
 
 
+def run_checked(fn, device=None, retries=1):
+    """``fn(attempt)`` followed by ``check_status(device)``; if a cooperative launch of that attempt reported a failed
+    inter-workgroup hand-off (its outputs are invalid) the batch is run AGAIN — ``attempt`` 1, 2, .. — up to ``retries`` times
+    before the error is raised.  The drivers that write artefacts (ML2PN.infer, evalPN.evaluate) call their batches through this
+    and pass ``write_through = attempt > 0`` (the placement-independent hand-off form) to the repeat: a time-out is rare and
+    box-dependent, results never silently come from a failed launch, and one bad launch does not end a
+    run over thousands of batches.  Every repeat is reported with ``warnings.warn``."""
+    import warnings
+    for attempt in range(retries + 1):
+        out = fn(attempt)
+        try:
+            check_status(device)
+            return out
+        except GnnpnError as e:
+            if attempt == retries:
+                raise
+            warnings.warn(f"gnnpn: a cooperative launch reported a failed hand-off; running the batch again "
+                          f"(attempt {attempt + 2} of {retries + 1}, write-through hand-off): {str(e)[:200]}", RuntimeWarning)
+
+
 def _launch_opts(ws, impl, lds_kb, write_through, paired_start=False):
     o = _lib.LaunchOpts()
     o.impl, o.lds_kb, o.write_through = int(impl), int(lds_kb), int(bool(write_through))

@@ -400,3 +400,28 @@ def test_half_batch_split_keeps_whole_tiles_in_the_first_half():
         assert 0 < h < b and h % 16 == 0, (b, h)
         assert abs(h - (b - h)) <= 16 + 15, (b, h)
         assert -(-h // 16) + -(-(b - h) // 16) == -(-b // 16), (b, h)     # no extra tile
+
+
+def test_run_checked_repeats_a_batch_once_after_a_failed_handoff(monkeypatch):
+    """ops.run_checked: the batch is run again (attempt 1: the drivers switch to the write-through hand-off) when check_status
+    reports a failed hand-off, with a warning; a second failure is raised; a clean run is not repeated."""
+    import warnings
+    from gnnpn_sc_amd import ops
+    calls, fail = [], {"n": 1}
+
+    def fake_check(device=None):
+        if fail["n"] > 0:
+            fail["n"] -= 1
+            raise ops.GnnpnError("status 0x1 — an inter-workgroup hand-off timed out")
+    monkeypatch.setattr(ops, "check_status", fake_check)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert ops.run_checked(lambda attempt: calls.append(attempt) or ("result", attempt)) == ("result", 1)
+    assert calls == [0, 1] and len(w) == 1 and "failed hand-off" in str(w[0].message)
+    calls.clear()
+    assert ops.run_checked(lambda attempt: calls.append(attempt) or 7) == 7 and calls == [0]
+    fail["n"] = 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ops.GnnpnError):
+            ops.run_checked(lambda attempt: None)
