@@ -118,21 +118,13 @@ def request_branch(x, table, rowptr, col, seg_ptr, max_nodes, layers, lin_w_pack
 
 @_gnnpn_errors
 def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=0, block_rows=0):
-    """The CSR aggregate with the form chosen as ops.csr_aggregate chooses it (tiled where the graph's plan is valid, whole-block LDS
-    where a block fits with 16-channel slices, else the gather; bit-identical every way) — the policy and the per-graph caches
-    (tile plan, row order) live in ops.py, the launch goes through the C++ operators."""
-    n = rowptr.numel() - 1
-    C = x.shape[1]
-    if ops.PREFER_TILED_AGGREGATE is not False and block_rows > 0 and C % 16 == 0 and n > 0 and x.data_ptr() % 16 == 0 and \
-            (ops.PREFER_TILED_AGGREGATE or -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= ops.TILED_MIN_WORKGROUPS):
-        plan = ops.csr_tile_plan(rowptr, col, w, block_rows)
-        if plan is not None and plan.valid:
-            return torch.ops.gnnpn.csr_aggregate_tiled(plan.header, plan.order, plan.selfw, plan.batches, x, self_coef, bias, scale, shift,
-                                                       act, plan.n_rows, plan.block_rows)
-    rows_max = ops.LDS_BLOCK_ROWS_MAX if ops.PREFER_LDS_AGGREGATE else ops.LDS_SLICE16_ROWS_MAX
-    if ops.PREFER_LDS_AGGREGATE is not False and 0 < block_rows <= rows_max and C % 4 == 0 and n > 0:
-        lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and (block_rows + 1) * 16 * c <= 160 * 1024)
-        if (lpr == 4 or ops.PREFER_LDS_AGGREGATE) and -(-n // block_rows) * (C // (4 * lpr)) >= ops.LDS_MIN_WORKGROUPS:
-            order = ops.csr_block_row_order(rowptr, block_rows) if block_rows <= 16384 else None
-            return torch.ops.gnnpn.csr_aggregate_blocks(rowptr, col, w, x, self_coef, bias, scale, shift, act, int(block_rows), order)
+    """The CSR aggregate with the form chosen per graph by ops.csr_aggregate_form (tiled where the graph's plan is valid,
+    whole-block LDS where a block fits with 16-channel slices, else the gather; bit-identical every way) — the policy and the
+    per-graph caches (tile plan, row order) live in ops.py, the launch goes through the C++ operators."""
+    form, aux = ops.csr_aggregate_form(rowptr, col, w, x, block_rows)
+    if form == "tiled":
+        return torch.ops.gnnpn.csr_aggregate_tiled(aux.header, aux.order, aux.selfw, aux.batches, x, self_coef, bias, scale, shift, act,
+                                                   aux.n_rows, aux.block_rows)
+    if form == "blocks":
+        return torch.ops.gnnpn.csr_aggregate_blocks(rowptr, col, w, x, self_coef, bias, scale, shift, act, int(block_rows), aux)
     return torch.ops.gnnpn.csr_aggregate(rowptr, col, w, x, self_coef, bias, scale, shift, act)

@@ -151,33 +151,46 @@ def csr_tile_plan(rowptr, col, w, block_rows):
     return plan
 
 
-def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
-    """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
-    ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
-    records it).  With enough workgroups to fill the chip: the tiled form gnnpn_csr_aggregate_tiled_f32 where the graph's
-    plan is valid (rows in source-tile order; ``PREFER_TILED_AGGREGATE``), else the whole-block LDS form
-    gnnpn_csr_aggregate_blocks_f32 when a block fits the LDS with 16-channel slices (``PREFER_LDS_AGGREGATE``), else the
-    gather form; bit-identical every way."""
-    x = _rows2d(x, "csr_aggregate.x")
+def csr_aggregate_form(rowptr, col, w, x, block_rows=0):
+    """Which form of the aggregate this (graph, operand) takes — the ONE place the policy lives (this ctypes binding and the C++
+    operators' caller custom_ops.csr_aggregate both ask it): ("tiled", TilePlan) where the graph is block-local with ``block_rows``
+    rows per block, its plan is valid (rows in source-tile order) and the launch has enough (block, destination tile, slice)
+    workgroups to fill the chip (``PREFER_TILED_AGGREGATE``); ("blocks", row order or None) when a block fits the LDS with
+    16-channel slices (``PREFER_LDS_AGGREGATE``); else ("gather", None).  All three give the same bits."""
     n = rowptr.numel() - 1
     C = x.shape[1]
-    y = torch.empty((n, C), dtype=F32, device=x.device)
     if PREFER_TILED_AGGREGATE is not False and block_rows > 0 and C % 16 == 0 and n > 0 and x.data_ptr() % 16 == 0 and \
             (PREFER_TILED_AGGREGATE or -(-n // block_rows) * -(-block_rows // 2560) * (C // 16) >= TILED_MIN_WORKGROUPS):
         plan = csr_tile_plan(rowptr, col, w, block_rows)
         if plan is not None and plan.valid:
-            return plan.aggregate(x, self_coef, bias, scale, shift, act)
+            return "tiled", plan
     rows_max = LDS_BLOCK_ROWS_MAX if PREFER_LDS_AGGREGATE else LDS_SLICE16_ROWS_MAX
     if PREFER_LDS_AGGREGATE is not False and 0 < block_rows <= rows_max and C % 4 == 0 and n > 0:
         lpr = next(c for c in (4, 2, 1) if C % (4 * c) == 0 and (block_rows + 1) * 16 * c <= 160 * 1024)
         if (lpr == 4 or PREFER_LDS_AGGREGATE) and -(-n // block_rows) * (C // (4 * lpr)) >= LDS_MIN_WORKGROUPS:
-            order = csr_block_row_order(rowptr, block_rows) if block_rows <= 16384 else None
-            check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
-                dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
-                dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
-                dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act, dev_ptr(y, F32, "y"), C, n, C,
-                int(block_rows), dev_ptr(order, I32, "row_order", True), stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
-            return y
+            return "blocks", (csr_block_row_order(rowptr, block_rows) if block_rows <= 16384 else None)
+    return "gather", None
+
+
+def csr_aggregate(rowptr, col, w, x, self_coef=None, bias=None, scale=None, shift=None, act=ACT_NONE, block_rows=0):
+    """y[i] = epi(sum_e w[e] * x[col[e]] (+ (1+self_coef) * x[i]))   (gnnpn_csr_aggregate_f32).
+    ``block_rows`` > 0 = the caller's promise that the graph is block-local with blocks of that many rows (graph.CSR
+    records it); the form — tiled (gnnpn_csr_aggregate_tiled_f32), whole-block LDS (gnnpn_csr_aggregate_blocks_f32) or gather —
+    is ``csr_aggregate_form``'s choice; bit-identical every way."""
+    x = _rows2d(x, "csr_aggregate.x")
+    n = rowptr.numel() - 1
+    C = x.shape[1]
+    form, aux = csr_aggregate_form(rowptr, col, w, x, block_rows)
+    if form == "tiled":
+        return aux.aggregate(x, self_coef, bias, scale, shift, act)
+    y = torch.empty((n, C), dtype=F32, device=x.device)
+    if form == "blocks":
+        check(_lib.load().gnnpn_csr_aggregate_blocks_f32(
+            dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
+            dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
+            dev_ptr(scale, F32, "scale", True), dev_ptr(shift, F32, "shift", True), act, dev_ptr(y, F32, "y"), C, n, C,
+            int(block_rows), dev_ptr(aux, I32, "row_order", True), stream_ptr()), "gnnpn_csr_aggregate_blocks_f32")
+        return y
     check(_lib.load().gnnpn_csr_aggregate_f32(
         dev_ptr(rowptr, I32, "rowptr"), dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), dev_ptr(x, F32, "x"), C,
         dev_ptr(self_coef, F32, "self_coef", True), dev_ptr(bias, F32, "bias", True),
