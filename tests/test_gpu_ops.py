@@ -732,6 +732,32 @@ def test_gin_layer_split_against_fp64(dev, n, c_in, nodes_per_graph, with_lin):
     assert not ops.gin_layer_split_supported(256, 256, 128) and ops.gin_layer_split_supported(c_in, 256, 128, 128)
 
 
+@pytest.mark.parametrize("n", [0, 1, 47, 48, 49, 97])
+def test_gin_layer_split_row_tile_boundaries(dev, n):
+    """Empty input, a single row, and row counts on both sides of the 48-row workgroup tile: the split layer against the fp32
+    layer (same aggregate, same epilogues; the products differ by their summation order only)."""
+    from gnnpn_sc_amd import graph
+    ops = _ops()
+    g = torch.Generator().manual_seed(100 + n)
+    c_in = 128
+    mk = lambda *s: (torch.randn(*s, generator=g) / s[-1] ** 0.5).to(dev)   # noqa: E731
+    w1, b1, w2, b2, w3, b3 = mk(256, c_in), mk(256), mk(128, 256), mk(128), mk(128, 128), mk(128)
+    a1, s1, a2, s2 = (torch.rand(256, generator=g) + 0.5).to(dev), mk(256), (torch.rand(128, generator=g) + 0.5).to(dev), mk(128)
+    ei = torch.stack([torch.arange(max(n - 1, 0)), torch.arange(1, max(n, 1))]) if n > 1 else torch.zeros((2, 0), dtype=torch.long)
+    csr = graph.csr_by_destination(ei, n).to(dev)
+    x = torch.randn(n, c_in, generator=g).to(dev)
+    eps = torch.tensor([0.3], device=dev)
+    p1, p2, p3 = ops.pack_split_weights(w1), ops.pack_split_weights(w2), ops.pack_split_weights(w3)
+    got = ops.gin_layer_split(csr.rowptr, csr.col, x, eps, *p1, b1, a1, s1, *p2, b2, a2, s2, *p3, b3)
+    want = ops.gin_layer(csr.rowptr, csr.col, x, eps, ops.pack_mfma_b32(w1), b1, a1, s1, ops.pack_mfma_b32(w2), b2, a2, s2,
+                         ops.pack_mfma_b32(w3), b3)
+    assert got.shape == want.shape == (n, 128)
+    if n:
+        assert torch.isfinite(got).all() and float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    via_op = torch.ops.gnnpn.gin_layer_split(csr.rowptr, csr.col, x, eps, *p1, b1, a1, s1, *p2, b2, a2, s2, *p3, b3)   # the C++ operator
+    assert torch.equal(via_op, got)
+
+
 def test_gcn_layer_against_dense_fp64_formula(dev):
     """The HIP GCN layer (gcn_csr + gcn_norm + linear + csr_aggregate) against the dense float64 matrix formula
     D^-1/2 (A_w + I) D^-1/2 X W + b — an oracle-independent check of the arithmetic whose reference implementation

@@ -50,7 +50,8 @@ for src, dst in (("slot_parts_qws.txt", RN + "_slot_parts_qws_b256.txt"), ("stam
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 short = {"lstm_encode_coop_kernel": "lstm_encode", "pointer_decode_lean_kernel": "pointer_decode", "pointer_decode_coop_kernel": "pointer_decode", "gin_request_branch_kernel": "request_branch",
          "csr_aggregate_kernel<true>": "csr_aggregate_gcn", "select_candidates_kernel": "select_candidates", "select_candidates16_kernel": "select_candidates", "linear_f32_kernel<128": "linear_128",
-         "linear_f32_kernel<64": "linear_64", "segment_mean_kernel": "segment_mean"}
+         "linear_f32_kernel<64": "linear_64", "segment_mean_kernel": "segment_mean", "gin_layer_split_kernel<true>": "gin_layer1_split",
+         "gin_layer_split_kernel<false>": "gin_layer0_split", "gin_layer_kernel<true>": "gin_layer1_f32", "gin_layer_kernel<false>": "gin_layer0_f32"}
 out = {"unit": "bytes per launch",
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over `bench.py --graph 0 --inflight 1` "
                  "(eager, one stream); counters are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
