@@ -180,7 +180,7 @@ extern "C" int gnnpn_gin_layer_f32(const int32_t* rowptr, const int32_t* col, co
                                    const float* w3, const float* b3, int32_t h3, float* out, int64_t ldo, int64_t n_rows, void* stream) {
     GNNPN_REQUIRE(n_rows >= 0 && c_in > 0 && ldx >= c_in, "gin_layer: bad shape");
     if (n_rows == 0) return GNNPN_OK;
-    GNNPN_REQUIRE(rowptr && col && x && eps && w1 && w2 && out, "gin_layer: null operand");
+    GNNPN_REQUIRE(rowptr && x && eps && w1 && w2 && out, "gin_layer: null operand");                 // col may be NULL for a graph without edges (csr_aggregate allows it too)
     GNNPN_REQUIRE((bn1_scale == nullptr) == (bn1_shift == nullptr) && (bn2_scale == nullptr) == (bn2_shift == nullptr),
                   "gin_layer: scale and shift go together");
     GNNPN_REQUIRE(x != out, "gin_layer: in-place layers are not supported");

@@ -476,7 +476,7 @@ extern "C" int gnnpn_gin_layer_split(const int32_t* rowptr, const int32_t* col, 
                                      const float* b3, int32_t h3, float* out, int64_t ldo, int64_t n_rows, void* stream) {
     GNNPN_REQUIRE(n_rows >= 0 && c_in > 0 && ldx >= c_in, "gin_layer_split: bad shape");
     if (n_rows == 0) return GNNPN_OK;
-    GNNPN_REQUIRE(rowptr && col && x && eps && w1 && inv1 && w2 && inv2 && out, "gin_layer_split: null operand");
+    GNNPN_REQUIRE(rowptr && x && eps && w1 && inv1 && w2 && inv2 && out, "gin_layer_split: null operand");   // col may be NULL for a graph without edges
     GNNPN_REQUIRE((w3 == nullptr) == (inv3 == nullptr), "gin_layer_split: w3 and inv3 go together");
     GNNPN_REQUIRE((bn1_scale == nullptr) == (bn1_shift == nullptr) && (bn2_scale == nullptr) == (bn2_shift == nullptr),
                   "gin_layer_split: scale and shift go together");

@@ -40,3 +40,12 @@ def record_agreement(name, payload):
     clean = {k: v for k, v in payload.items() if k != "same_mask"}
     with open(os.path.join(AGREEMENT_DIR, name.replace("/", "_") + ".json"), "w") as f:
         json.dump(clean, f, indent=1)
+
+
+def eager_reference(pipe, svc, batch, **kw):
+    """The single-stream eager pass a pipelined / graph-replayed result is compared with — run through ops.run_checked: its
+    cooperative launches use the device's default workspaces, whose status nothing else in a test reads, and on some boxes of
+    the pool an eager launch right after a graph capture has ended in a hand-off time-out.  A failed
+    attempt is repeated once (write-through hand-off) with a RuntimeWarning that pytest lists; a second failure raises."""
+    from gnnpn_sc_amd import ops
+    return ops.run_checked(lambda attempt: pipe.run(svc, batch, write_through=attempt > 0, **kw), batch.x.device)

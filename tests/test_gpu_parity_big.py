@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, record_agreement
+from conftest import eager_reference, golden, record_agreement
 from oracle import ml as oml
 from oracle import pn as opn
 from parity import LOGIT_ATOL, assert_R_parity, prefix_parity
@@ -218,11 +218,11 @@ def test_whole_pipeline_at_synthetic_sizes(dev, T, S, K, B_full, n_ref):
     pbp = synth.ProblemBatch(np.ascontiguousarray(pb.x.reshape(B_full, -1, 7)[pn_].reshape(-1, 7)), pb.edge_index, pb.batch,
                              np.ascontiguousarray(pb.local_bounds[pn_]), np.ascontiguousarray(pb.present[pn_]),
                              np.ascontiguousarray(pb.global_bounds[pn_]))
-    outp = pipe.run(svc, DeviceBatch.from_problems(pbp, dev), decode_impl=runner.decode_impl)
+    outp = eager_reference(pipe, svc, DeviceBatch.from_problems(pbp, dev), decode_impl=runner.decode_impl)
     assert torch.equal(outp["idx_high"], a["idx_high"][perm.to(dev)]) and torch.equal(outp["R"], a["R"][perm.to(dev)])
     sub = synth.ProblemBatch(pb.x[:16 * (T + 1)], pb.edge_index[:, pb.edge_index[0] < 16 * (T + 1)], pb.batch[:16 * (T + 1)],
                              pb.local_bounds[:16], pb.present[:16], pb.global_bounds[:16])
-    outs16 = pipe.run(svc, DeviceBatch.from_problems(sub, dev), decode_impl=runner.decode_impl)
+    outs16 = eager_reference(pipe, svc, DeviceBatch.from_problems(sub, dev), decode_impl=runner.decode_impl)
     from gnnpn_sc_amd import ops
     ops.check_status(dev)
     assert torch.equal(outs16["idx_high"], a["idx_high"][:16]) and torch.equal(outs16["R"], a["R"][:16])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import eager_reference, golden
 from oracle import data as odata
 from oracle import ml as oml
 from oracle import pn as opn
@@ -247,7 +247,7 @@ def test_pipelined_runner_matches_single_stream(dev):
     runner.synchronize()
     ops.check_status(dev)
     for b, (idx, R, ids) in zip(batches, got):
-        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)                  # the decoder form the 2-slot runner uses
+        ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)                  # the decoder form the 2-slot runner uses
         assert torch.equal(ids, ref["candidate_ids"]) and torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
     with pytest.raises(ops.GnnpnError):
         runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
@@ -280,7 +280,7 @@ def test_half_batches_side_by_side_match_the_whole_batch(dev, B, precision):
     runner.synchronize(check=True)
     ops.check_status(dev)
     for b, g in zip(batches, got):
-        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)
+        ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)
         for k in keys:
             assert g[k].shape == ref[k].shape and torch.equal(g[k], ref[k]), k
     # the documented output contract holds in this mode too: a slot's static outputs stay intact until the slot
@@ -290,7 +290,7 @@ def test_half_batches_side_by_side_match_the_whole_batch(dev, B, precision):
     assert s0 != s1 and out0["idx_high"].data_ptr() != out1["idx_high"].data_ptr()
     runner.synchronize(check=True)
     for out, b in ((out0, batches[1]), (out1, batches[2])):
-        ref = pipe.run(svc, b, decode_impl=runner.decode_impl)
+        ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)
         for k in keys:
             assert torch.equal(out[k], ref[k]), k
     with pytest.raises(ops.GnnpnError):                     # nothing to put on the second stream
@@ -421,7 +421,7 @@ def test_two_slots_whichever_starts_first(dev):
     runner = PipelinedRunner(pipe, svc, batch, slots=2)
     assert runner.lds_kb == [0, 0]                               # no footprint steering (fp32 builds: 19 / 27 KB, nothing to equalise)
     assert PipelinedRunner(ML2PNPipeline(net, low, high, K), svc, batch, slots=2).lds_kb == [78, 78]   # the default (exact split): ONE footprint
-    ref = pipe.run(svc, batch, decode_impl=runner.decode_impl)
+    ref = eager_reference(pipe, svc, batch, decode_impl=runner.decode_impl)
     for first in (1, 0, 1):
         torch.cuda.synchronize()
         runner.count = first
@@ -454,7 +454,7 @@ def test_two_slots_beside_long_ordinary_kernels(dev):
     batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=4, tasks_per_problem=T), dev)
     runner = PipelinedRunner(pipe, svc, batch, slots=2, halves=False)      # two whole batches in flight (the default at this size pairs half-batches)
     assert runner.n_slots == 2 and runner.lockstep                       # 5000 recurrent steps: pairs start together
-    ref = pipe.run(svc, batch, decode_impl=runner.decode_impl)
+    ref = eager_reference(pipe, svc, batch, decode_impl=runner.decode_impl)
     for _ in range(24):
         runner.submit()
     runner.synchronize(check=True)
@@ -481,7 +481,7 @@ def test_two_slots_started_together_with_long_recurrences(dev):
     batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=300 + i, tasks_per_problem=T), dev) for i in range(3)]
     runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
     assert runner.n_slots == 2 and runner.lockstep and not runner.halves
-    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    refs = [eager_reference(pipe, svc, b, decode_impl=runner.decode_impl) for b in batches]
     torch.cuda.synchronize()      # the runner's streams do not wait for this one: a third cooperative launch in flight is not a supported mix
     pending, bad = [], []
     for i in range(60):
@@ -518,7 +518,7 @@ def test_soak_two_slots(dev, precision):
     batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=200 + i, tasks_per_problem=10), dev)
                for i in range(6)]
     runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
-    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
+    refs = [eager_reference(pipe, svc, b, decode_impl=runner.decode_impl) for b in batches]
     keys = ("idx_low", "idx_high", "R", "actions")
     pending, bad = [], 0
     for i in range(2000):
@@ -565,16 +565,13 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
     runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
     assert runner.halves == (shape != "qws_two_slots")
     packed = [runner.pack(b) for b in batches]
-    # the single-stream reference runs use the device's default workspaces: their status is checked like the runner's (an eager
-    # launch that reported a failed hand-off would make a wrong REFERENCE — seen on some boxes of the pool, see DESIGN.md section 7;
-    # it is re-run once and the event recorded)
-    from gnnpn_sc_amd import ops as _ops_mod
-    eager_retries = 0
-    refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
-    if _ops_mod.workspaces(dev).poll():
-        eager_retries = 1
-        refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]
-        _ops_mod.workspaces(dev).check("the single-stream reference run (second attempt)")
+    # the single-stream reference runs use the device's default workspaces: conftest.eager_reference checks their status like the
+    # runner's and repeats a failed attempt once (seen on some boxes of the pool); repeats are recorded
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        refs = [eager_reference(pipe, svc, b, decode_impl=runner.decode_impl) for b in batches]
+    eager_retries = sum("failed hand-off" in str(c.message) for c in caught)
     keys = ("idx_low", "idx_high", "R")
     side = torch.cuda.Stream()
     lib = _lib.load()
