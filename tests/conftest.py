@@ -20,11 +20,30 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def _record_box():
+    """Which card this run is on (unique id, partition modes, firmware): gpurun_out/parity/box_info.json — hand-off time-outs
+    have been box-dependent, so every GPU run of the suite says where it ran."""
+    import json
+    import subprocess
+    info = {}
+    try:
+        out = subprocess.run(["rocm-smi", "--showuniqueid", "--showmemorypartition", "--showcomputepartition", "--showfwinfo"],
+                             capture_output=True, text=True, timeout=30).stdout
+        info["rocm_smi"] = [ln.strip() for ln in out.splitlines() if ln.startswith("GPU[0]") and any(
+            k in ln for k in ("Unique ID", "Partition", "MEC firmware", "RLC firmware", "SMC firmware", "SDMA firmware"))]
+    except (OSError, subprocess.SubprocessError) as e:
+        info["rocm_smi_error"] = str(e)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "parity"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity", "box_info.json"), "w") as f:
+        json.dump(info, f, indent=1)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    _record_box()
     return torch.device("cuda:0")
 
 
