@@ -43,8 +43,15 @@ constexpr int META_WORDS = 128;
 constexpr int PASSES_MAX = 10;            // destination rows per lane group: 10 x 4 accumulator registers
 constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, META_STREAM_ROWS = 4, META_HIST = 8, HIST_BINS = 64;
 
-constexpr int WAVES = 16;                 // wavefronts per workgroup: one workgroup per CU
-constexpr int TILE_ROWS_MAX = 2559;       // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
+// (experiment switches: 8 waves with 1279-row tiles = two workgroups per CU; measured slower, see the notes below / DESIGN.md 13.1)
+#ifndef GNNPN_TILED_WAVES
+#define GNNPN_TILED_WAVES 16
+#endif
+#ifndef GNNPN_TILED_TILE_ROWS
+#define GNNPN_TILED_TILE_ROWS 2559
+#endif
+constexpr int WAVES = GNNPN_TILED_WAVES;  // wavefronts per workgroup: 16 = one workgroup per CU
+constexpr int TILE_ROWS_MAX = GNNPN_TILED_TILE_ROWS;   // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
 constexpr int DST_ROWS_MAX = WAVES * 16 * PASSES_MAX;   // destination rows per workgroup: 10 passes of 256 rows (1024 lanes, 4 per row)
 
 struct Geom {
