@@ -62,6 +62,10 @@ def test_embed_concat(dev):
     bad = x.clone()
     bad[5, 0] = 100
     assert torch.isnan(ops.embed_concat(bad.to(dev), table.to(dev)).cpu()[5, :20]).all()
+    wide = torch.randn(100, 40, generator=g)                 # rows wider than 32 columns: the general kernel
+    assert torch.equal(ops.embed_concat(x.to(dev), wide.to(dev)).cpu(), torch.cat([wide[x[:, 0].long()], x[:, 1:]], 1))
+    big = torch.cat([torch.randint(0, 100, (200003, 1), generator=g).float(), torch.rand(200003, 6, generator=g)], 1)
+    assert torch.equal(ops.embed_concat(big.to(dev), table.to(dev)).cpu(), torch.cat([table[big[:, 0].long()], big[:, 1:]], 1))
 
 
 def _rand_graph(n, e, seed, loops=True):
