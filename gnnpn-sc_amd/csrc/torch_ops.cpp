@@ -7,6 +7,7 @@
 // loaded by custom_ops.py with torch.ops.load_library.  The reference is pure Python with no operator layer of its own; the
 // operators stand for the torch / torch_geometric calls cited at each C entry point in gnnpn_hip.h.
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -20,7 +21,13 @@ namespace {
 using at::Tensor;
 using OptTensor = std::optional<Tensor>;
 
-void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// Every operator runs on the device of its first tensor operand: that device is made current for the call (the C library reads
+// hipGetDevice for its per-device tables) and the work goes to THAT device's current stream.
+#define GNNPN_ON_DEVICE_OF(t)                          \
+    TORCH_CHECK((t).is_cuda(), "gnnpn: expected a CUDA tensor (the hot path has no CPU implementation)"); \
+    const c10::DeviceGuard device_guard_((t).device()); \
+    void* const stream_ = (void*)c10::hip::getCurrentHIPStream((t).device().index()).stream()
+#define cur_stream() stream_
 
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == GNNPN_OK, what, " failed (", rc, "): ", gnnpn_last_error()); }
 
@@ -49,6 +56,7 @@ const Tensor& rows2d(const Tensor& t, const char* name) {
 
 // ---- dense / graph ---------------------------------------------------------------------------------------------------
 Tensor linear(const Tensor& a, const Tensor& weight, const OptTensor& bias, const OptTensor& scale, const OptTensor& shift, int64_t act) {
+    GNNPN_ON_DEVICE_OF(a);
     rows2d(a, "linear.a"), rows2d(weight, "linear.weight");
     const int64_t M = a.size(0), K = a.size(1), N = weight.size(0);
     TORCH_CHECK(weight.size(1) == K, "linear: K mismatch ", a.sizes(), " x ", weight.sizes());
@@ -59,6 +67,7 @@ Tensor linear(const Tensor& a, const Tensor& weight, const OptTensor& bias, cons
 }
 
 Tensor embed_concat(const Tensor& x, const Tensor& table) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "embed_concat.x"), rows2d(table, "embed_concat.table");
     const int64_t n = x.size(0), nfeat = x.size(1) - 1, vocab = table.size(0), emb = table.size(1);
     Tensor out = new_f32(x, {n, emb + nfeat});
@@ -70,6 +79,7 @@ Tensor embed_concat(const Tensor& x, const Tensor& table) {
 // the one-wave-per-row gather form (any graph)
 Tensor csr_aggregate(const Tensor& rowptr, const Tensor& col, const OptTensor& w, const Tensor& x, const OptTensor& self_coef,
                      const OptTensor& bias, const OptTensor& scale, const OptTensor& shift, int64_t act) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "csr_aggregate.x");
     const int64_t n = rowptr.numel() - 1, C = x.size(1);
     Tensor y = new_f32(x, {n, C});
@@ -82,6 +92,7 @@ Tensor csr_aggregate(const Tensor& rowptr, const Tensor& col, const OptTensor& w
 Tensor csr_aggregate_blocks(const Tensor& rowptr, const Tensor& col, const OptTensor& w, const Tensor& x, const OptTensor& self_coef,
                             const OptTensor& bias, const OptTensor& scale, const OptTensor& shift, int64_t act, int64_t block_rows,
                             const OptTensor& row_order) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "csr_aggregate_blocks.x");
     const int64_t n = rowptr.numel() - 1, C = x.size(1);
     Tensor y = new_f32(x, {n, C});
@@ -95,6 +106,7 @@ Tensor csr_aggregate_blocks(const Tensor& rowptr, const Tensor& col, const OptTe
 Tensor csr_aggregate_tiled(const Tensor& header, const Tensor& order, const Tensor& selfw, const Tensor& batches, const Tensor& x,
                            const OptTensor& self_coef, const OptTensor& bias, const OptTensor& scale, const OptTensor& shift, int64_t act,
                            int64_t n_rows, int64_t block_rows) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "csr_aggregate_tiled.x");
     const int64_t C = x.size(1);
     Tensor y = new_f32(x, {n_rows, C});
@@ -106,6 +118,7 @@ Tensor csr_aggregate_tiled(const Tensor& header, const Tensor& order, const Tens
 }
 
 Tensor gcn_norm(const Tensor& rowptr, const Tensor& col, const Tensor& w_raw) {
+    GNNPN_ON_DEVICE_OF(w_raw);
     const int64_t n = rowptr.numel() - 1;
     Tensor dis = new_f32(w_raw, {n}), norm = at::empty_like(w_raw);
     check_rc(gnnpn_gcn_norm_f32(i32(rowptr, "rowptr"), i32(col, "col"), f32(w_raw, "w_raw"), out_f32(dis), out_f32(norm), (int32_t)n,
@@ -114,6 +127,7 @@ Tensor gcn_norm(const Tensor& rowptr, const Tensor& col, const Tensor& w_raw) {
 }
 
 Tensor segment_mean(const Tensor& segptr, const Tensor& x) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "segment_mean.x");
     const int64_t n_seg = segptr.numel() - 1, C = x.size(1);
     Tensor out = new_f32(x, {n_seg, C});
@@ -125,6 +139,7 @@ Tensor segment_mean(const Tensor& segptr, const Tensor& x) {
 // layer_tensors: per layer w0p, b0, a1, s1, w3p, b3, a2, s2, eps (custom_ops.REQUEST_LAYER_KEYS)
 Tensor request_branch(const Tensor& x, const Tensor& table, const Tensor& rowptr, const Tensor& col, const Tensor& seg_ptr, int64_t max_nodes,
                       at::TensorList layer_tensors, const Tensor& lin_w_packed, const Tensor& lin_b, int64_t hidden) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "request_branch.x");
     TORCH_CHECK(layer_tensors.size() % 9 == 0, "request_branch: nine tensors per layer");
     const size_t n_layers = layer_tensors.size() / 9;
@@ -146,6 +161,7 @@ Tensor request_branch(const Tensor& x, const Tensor& table, const Tensor& rowptr
 Tensor gin_layer(const Tensor& rowptr, const Tensor& col, const Tensor& x, const Tensor& eps, const Tensor& w1, const OptTensor& b1,
                  const OptTensor& a1, const OptTensor& s1, const Tensor& w2, const OptTensor& b2, const OptTensor& a2, const OptTensor& s2,
                  const OptTensor& w3, const OptTensor& b3) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "gin_layer.x");
     const int64_t n = x.size(0), c_in = x.size(1);
     const bool lin3 = w3.has_value() && w3->defined();
@@ -163,6 +179,7 @@ Tensor gin_layer(const Tensor& rowptr, const Tensor& col, const Tensor& x, const
 Tensor gin_layer_split(const Tensor& rowptr, const Tensor& col, const Tensor& x, const Tensor& eps, const Tensor& w1, const Tensor& i1,
                        const OptTensor& b1, const OptTensor& a1, const OptTensor& s1, const Tensor& w2, const Tensor& i2, const OptTensor& b2,
                        const OptTensor& a2, const OptTensor& s2, const OptTensor& w3, const OptTensor& i3, const OptTensor& b3) {
+    GNNPN_ON_DEVICE_OF(x);
     rows2d(x, "gin_layer_split.x");
     const int64_t n = x.size(0), c_in = x.size(1), k1 = (c_in + 31) / 32 * 32;
     const bool lin3 = w3.has_value() && w3->defined();
@@ -182,6 +199,7 @@ Tensor gin_layer_split(const Tensor& rowptr, const Tensor& col, const Tensor& x,
 // ---- ranking / candidate reduction -------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor> segment_topk_feasible(const Tensor& scores, const Tensor& cat_ptr, const Tensor& qos, const Tensor& local_bounds,
                                                  const Tensor& present, const Tensor& global_bounds, int64_t n_per) {
+    GNNPN_ON_DEVICE_OF(scores);
     rows2d(scores, "select.scores");
     const int64_t B = scores.size(0), S = scores.size(1), T = cat_ptr.numel() - 1;
     TORCH_CHECK(qos.sizes() == at::IntArrayRef({S, 4}) && local_bounds.sizes() == at::IntArrayRef({B, T, 4}) &&
@@ -197,6 +215,7 @@ std::tuple<Tensor, Tensor> segment_topk_feasible(const Tensor& scores, const Ten
 }
 
 Tensor rank_rows(const Tensor& scores) {
+    GNNPN_ON_DEVICE_OF(scores);
     rows2d(scores, "rank_rows.scores");
     const int64_t B = scores.size(0), S = scores.size(1);
     Tensor ranking = new_i32(scores, {B, S});
@@ -206,6 +225,7 @@ Tensor rank_rows(const Tensor& scores) {
 }
 
 Tensor precision_at_k(const Tensor& ranking, const Tensor& labels, at::IntArrayRef ks) {
+    GNNPN_ON_DEVICE_OF(labels);
     const int64_t B = labels.size(0), S = labels.size(1);
     std::vector<int32_t> k32(ks.begin(), ks.end());
     Tensor kt = at::tensor(k32, at::TensorOptions().dtype(at::kInt)).to(labels.device());
@@ -216,6 +236,7 @@ Tensor precision_at_k(const Tensor& ranking, const Tensor& labels, at::IntArrayR
 }
 
 Tensor attention_logits(const Tensor& enc_out, const Tensor& queries, int64_t step, const Tensor& idx, double tanh_c, bool use_tanh) {
+    GNNPN_ON_DEVICE_OF(enc_out);
     const int64_t B = enc_out.size(0), L = enc_out.size(1), H = enc_out.size(2), T = queries.size(1);
     f32(enc_out, "enc_out"), f32(queries, "queries");
     Tensor out = new_f32(enc_out, {B, L});
@@ -226,6 +247,7 @@ Tensor attention_logits(const Tensor& enc_out, const Tensor& queries, int64_t st
 }
 
 Tensor qos_reward(const Tensor& actions, int64_t level) {
+    GNNPN_ON_DEVICE_OF(actions);
     const int64_t B = actions.size(0), T = actions.size(1);
     Tensor R = new_f32(actions, {B});
     check_rc(gnnpn_qos_reward_f32(f32(actions, "actions"), out_f32(R), (int32_t)B, (int32_t)T, (int)level, cur_stream()), "gnnpn_qos_reward_f32");
@@ -259,6 +281,7 @@ std::vector<Tensor> lstm_encode(const c10::List<OptTensor>& net_tensors, int64_t
     for (size_t i = 0; i < t.size(); ++i) t[i] = net_tensors.get(i);
     auto has = [&](size_t i) { return t[i].has_value() && t[i]->defined(); };
     TORCH_CHECK(has(5), "lstm_encode: nets[0].bhh required");
+    GNNPN_ON_DEVICE_OF(*t[5]);
     const int64_t H = t[5]->numel() / 4;
     const Tensor& first = has(0) ? *t[0] : *t[1];
     TORCH_CHECK(first.dim() == 3, "lstm_encode: pregates / inputs must be [B, L, .]");
@@ -306,6 +329,7 @@ std::vector<Tensor> pointer_decode(const c10::List<OptTensor>& net_tensors, at::
                                    int64_t n_per, double tanh_c, bool use_tanh, bool want_queries, std::string precision, int64_t impl,
                                    int64_t lds_kb, bool write_through, const OptTensor& workspace, const OptTensor& status,
                                    at::IntArrayRef sample_seeds, bool paired_start) {
+    GNNPN_ON_DEVICE_OF(inputs);
     constexpr size_t NK = 15;
     const size_t n_nets = latent_from.size();
     TORCH_CHECK(n_nets >= 1 && n_nets <= 2 && net_tensors.size() == NK * n_nets, "pointer_decode: fifteen tensors per net, 1 or 2 nets");
