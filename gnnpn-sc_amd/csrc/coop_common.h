@@ -199,16 +199,20 @@ inline unsigned coop_lds_padding(const void* func, int target_kb) {
 // garbage in the status area after a few hundred steps, results wrong from then on) — the fill pattern of a captured
 // memset lives in runtime-managed memory that gets recycled; a kernel node carries its arguments by value.
 namespace {   // one copy per translation unit
-__global__ __launch_bounds__(256) void coop_zero_kernel(uint4* __restrict__ p, size_t n16) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = make_uint4(0u, 0u, 0u, 0u);
+// The zeros are written with AGENT-scope stores (sc1: write-through to the level the cooperative kernel's atomics and sc1 loads
+// work on), not left dirty in the L2 of whichever XCD ran the block: the words of the status area are modified by device-scope
+// atomics of the next kernel, and a failure record of round 4 showed a launch that started on seat counters of 32 + 3 and 32 + 20
+// on two XCDs — the previous launch's totals, i.e. zeros that had not arrived.
+__global__ __launch_bounds__(256) void coop_zero_kernel(unsigned long long* __restrict__ p, size_t n8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x)
+        __hip_atomic_store(p + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
 inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t s) {   // bytes: a multiple of 16
-    const size_t n16 = bytes / 16;
-    unsigned blocks = (unsigned)((n16 + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(coop_zero_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint4*>(workspace), n16);
+    const size_t n8 = bytes / 8;
+    unsigned blocks = (unsigned)((n8 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(coop_zero_kernel, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long*>(workspace), n8);
     return hipGetLastError();
 }
 
@@ -250,7 +254,7 @@ __device__ __forceinline__ void coop_note_staffed(unsigned* status, const unsign
 }
 template <int G>
 __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats,
-                                           bool paired_start = false) {
+                                           bool paired_start = false, unsigned* sticky = nullptr) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned xcc = xcc_id();
@@ -264,10 +268,19 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
             return __all(ok);
         };
         int g = -1, m = 0;
-        if (!staffed()) {
-            unsigned arrival = 0;
+        // Every workgroup takes an arrival index, also the ones that find the launch staffed — and with it checks that the status
+        // area was CLEAN when the launch began: a launch is staffed only after `target` arrivals on every XCD, and an XCD receives
+        // gridDim.x / 8 workgroups, so "staffed" seen by one of an XCD's first `target` arrivals, or an arrival index beyond the
+        // XCD's share, means counters left over from the previous launch on this workspace (the zeroing kernel's stores not seen:
+        // every workgroup would then leave as surplus and the outputs would be garbage WITHOUT anyone timing out).  Code 8.
+        const bool staffed_at_entry = staffed();
+        unsigned arrival = 0;
+        if (lane == 0) {
+            arrival = atomicAdd(arrive + xcc, 1u);
+            if (arrival >= gridDim.x / 8 || (staffed_at_entry && arrival < target)) coop_raise(status, sticky, 8u);
+        }
+        if (!staffed_at_entry) {
             if (lane == 0) {
-                arrival = atomicAdd(arrive + xcc, 1u);
                 const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
                 const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
                 atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);      // statistics: workgroups of this launch that reached the CU

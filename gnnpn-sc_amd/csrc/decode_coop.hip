@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     const int kq = lane >> 4, c = lane & 15;
     __shared__ int place[2];
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
+    if (!coop_place<G>(err, gpx, place, group, member, seats, false, sticky)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];

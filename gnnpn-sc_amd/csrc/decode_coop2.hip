@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void pointer_decode_coop2_kernel(DecodeArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, c = lane & 15, gate = c >> 2;
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
+    if (!coop_place<G>(err, gpx, place, group, member, seats, false, sticky)) return;   // surplus workgroup of the over-subscribed launch (coop_common.h)
     const int net_id = group / groups_per_net, gi = group % groups_per_net;
     if (net_id >= n_nets) return;
     const DecodeNet& net = a.net[net_id];

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, c = lane & 15;
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats, (write_through & 2) != 0)) return;   // surplus workgroup of the over-subscribed launch (bit 1: opts.paired_start)
+    if (!coop_place<G>(err, gpx, place, group, member, seats, (write_through & 2) != 0, sticky)) return;   // surplus workgroup of the over-subscribed launch (bit 1: opts.paired_start)
     // seat numbers come out of LDS, i.e. in vector registers: say that they are uniform — every base address, resource and
     // scalar offset below then lives in SGPRs (a resource the compiler cannot prove uniform costs a waterfall loop per access)
     group = __builtin_amdgcn_readfirstlane(group);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     // placement by claim (coop_common.h): one member per CU, a group's members on one XCD
     __shared__ int place[2];
     int group, member;
-    if (!coop_place<G>(err, gpx, place, group, member, seats, (ablate_arg & 0x1000) != 0)) return;   // surplus workgroup of the over-subscribed launch (bit 12: opts.paired_start)
+    if (!coop_place<G>(err, gpx, place, group, member, seats, (ablate_arg & 0x1000) != 0, sticky)) return;   // surplus workgroup of the over-subscribed launch (bit 12: opts.paired_start)
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets net
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, c = lane & 15;
     int group, member;
-    if (!coop_place<G16>(err, gpx, place, group, member, seats)) return;
+    if (!coop_place<G16>(err, gpx, place, group, member, seats, false, sticky)) return;
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;
     if (threadIdx.x == 0) abort_flag = 0;

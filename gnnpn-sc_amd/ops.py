@@ -474,7 +474,8 @@ class Workspaces:
                 detail = f"; decoder failure record: {rec['failures']} sweeps, first: {rec['records'][:4]}"
             raise GnnpnError(f"{what}: status {word:#x} — an inter-workgroup hand-off timed out in at least one launch "
                              f"since the last check (its outputs are invalid); bits: 1 encoder sweep, 2 decoder sweep, 4 a "
-                             f"group member never showed up; last launches' own words (encoder, decoder) = {last}{detail}")
+                             f"group member never showed up, 8 the workspace was not clean when a launch began; last launches' own words "
+                             f"(encoder, decoder) = {last}{detail}")
 
 
 def decode_failure_record(clear=True):
