@@ -273,6 +273,12 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         // gridDim.x / 8 workgroups, so "staffed" seen by one of an XCD's first `target` arrivals, or an arrival index beyond the
         // XCD's share, means counters left over from the previous launch on this workspace (the zeroing kernel's stores not seen:
         // every workgroup would then leave as surplus and the outputs would be garbage WITHOUT anyone timing out).  Code 8.
+#ifndef GNNPN_COOP_NO_ENTRY_ACQUIRE
+        // agent-scope acquire before the first look at the status area: what the kernel boundary behind the zeroing kernel is
+        // supposed to give anyway (clean lines of another kernel's data dropped from this XCD's L2) — said explicitly, once per
+        // workgroup (this wavefront), because the stale counters above are what a missing invalidate looks like
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         const bool staffed_at_entry = staffed();
         unsigned arrival = 0;
         if (lane == 0) {
