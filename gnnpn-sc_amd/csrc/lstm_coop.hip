@@ -595,8 +595,9 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
     const int64_t need = COOP_STATUS_BYTES + (int64_t)groups * GROUP_GRANULES * sizeof(u64);
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
-    // zero the status word and every tag before each launch (tags start at 1)
-    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
+    // zero the status word and every tag before each launch (tags start at 1).  Test hook (lstm_ablate bit 13, tests only): leave
+    // the workspace as the previous launch left it — every workgroup must then notice (status code 8) instead of running on it
+    if (!(gnnpn_option_lstm_ablate() & 0x2000) && coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
     unsigned* p_seats = gnnpn_cu_seat_table();
     if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "%s: cannot allocate the seat table", "lstm_encode");
@@ -607,7 +608,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
-    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000 | 0x2000)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder, 13 to the launch (above)
     const int abl_arg = abl | (opts.paired_start ? 0x1000 : 0);   // bit 12 rides the kernel argument only (placement, coop_place)
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;

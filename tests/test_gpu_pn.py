@@ -475,6 +475,32 @@ def test_split_precision_needs_the_cooperative_form(dev):
     ops.check_status(dev)
 
 
+def test_a_launch_on_a_dirty_workspace_is_loud(dev):
+    """coop_place's check that the status area was clean when the launch began (status code 8): with the per-launch zeroing
+    switched off (test hook: lstm_ablate bit 13) a second encoder launch on the same workspace finds the first one's seat and
+    arrival counters — every workgroup would leave as surplus and the outputs would be garbage with nothing timing out; instead the
+    launch's own word and the sticky word carry code 8 and ops.check_status raises.  (Seen for real: DESIGN.md section 13.3.)"""
+    from gnnpn_sc_amd import custom_ops, ops
+    cfg = {"hidden": 256, "n_cat": 6, "n_per": 4, "seed_low": 1, "seed_high": 2}
+    low, high = build(cfg, dev)
+    x = torch.rand(32, 24, 8).to(dev)
+    ws = ops.new_workspaces(dev)
+    args, _ = low.actor.encode_args(x, None)
+    enc0 = custom_ops.lstm_encode([args], ws=ws)[0][0].clone()
+    ws.check()
+    try:
+        ops.set_option("lstm_ablate", 0x2000)
+        custom_ops.lstm_encode([args], ws=ws)
+        torch.cuda.synchronize()
+        assert int(ws._encode[:4].view(torch.int32).item()) & 8 and int(ws.status[0].item()) & 8
+        with pytest.raises(ops.GnnpnError, match="not clean"):
+            ws.check()
+    finally:
+        ops.set_option("lstm_ablate", 0)
+    assert torch.equal(custom_ops.lstm_encode([args], ws=ws)[0][0], enc0)       # and the next ordinary launch is fine again
+    ws.check()
+
+
 def test_weights_outside_fp16_range(dev):
     """A recurrent weight beyond fp16's largest finite number: the plain-fp16 encoder ("f16") refuses it; the exact split
     scales every gate column by its own power of two and takes it, as fp32 does — same picks, logits within 1e-5."""
