@@ -234,6 +234,32 @@ def test_cpu_tensors_are_rejected(dev):
         ops.linear(torch.rand(4, 8), torch.rand(3, 8))
 
 
+def test_cpp_operators_validate_their_operands(dev):
+    """The C++ operators refuse what the ctypes wrappers refuse: wrong dtype, non-contiguous and host operands, inconsistent
+    shapes, a cooperative launch without its workspace — as exceptions, before anything is enqueued."""
+    from gnnpn_sc_amd import custom_ops                                        # loads libgnnpn_torch.so: the operators register themselves
+    a, w = torch.rand(4, 8, device=dev), torch.rand(3, 8, device=dev)
+    assert torch.ops.gnnpn.linear(a, w).shape == (4, 3)
+    with pytest.raises(RuntimeError, match="dtype"):
+        torch.ops.gnnpn.linear(a.double(), w)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        torch.ops.gnnpn.linear(torch.rand(8, 4, device=dev).t(), w)
+    with pytest.raises(RuntimeError, match="K mismatch"):
+        torch.ops.gnnpn.linear(a, torch.rand(3, 7, device=dev))
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.gnnpn.linear(a.cpu(), w.cpu())
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        torch.ops.gnnpn.linear(a, w, bias=torch.rand(3))                       # one host operand among device ones
+    cfg = {"hidden": 256, "n_cat": 3, "n_per": 2, "seed_low": 1, "seed_high": 2}
+    low, _ = build(cfg, dev)
+    args, _ = low.actor.encode_args(torch.rand(2, 6, 8, device=dev), None)
+    flat = [args.get(k) for k in custom_ops.ENCODE_KEYS]
+    with pytest.raises(RuntimeError, match="workspace"):
+        torch.ops.gnnpn.lstm_encode(flat, 1)                                   # H = 256: the cooperative form needs its workspace
+    with pytest.raises(RuntimeError, match="precision"):
+        torch.ops.gnnpn.lstm_encode(flat, 1, "bf16")
+
+
 def test_fresh_oracle_batch(dev):
     """A batch that is not a stored fixture: oracle run live on the CPU vs the HIP path."""
     from gnnpn_sc_amd.modelPN import two_level_greedy
