@@ -88,6 +88,7 @@ class DeviceBatch:
 # True = agent-scope write-through stores (valid by the HIP memory model, placement independent).  Settled by measurement in
 # round 4: DESIGN.md section 11.
 DEFAULT_WRITE_THROUGH = False
+HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
 
 
 def half_batch_split(n_problems):
@@ -287,6 +288,8 @@ class PipelinedRunner:
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
         self.lockstep = self.n_streams == 2 and (env == "1" or (env is None and long_steps))
         self._open_leader, self._last_done = None, [None, None]
+        self._slot_done = [None] * self.n_slots
+        self._copy_streams = [torch.cuda.Stream() for _ in range(self.n_slots)]   # host-to-device transfers of pinned arenas (submit)
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
@@ -354,7 +357,21 @@ class PipelinedRunner:
                                          f"{lim} nodes); this batch has max_nodes = {batch.max_nodes}")
                 if getattr(batch, "_layout", None) is not None and batch._layout == dst._layout and \
                         (batch._arena.device == dst._arena.device or (batch._arena.device.type == "cpu" and batch._arena.is_pinned())):
-                    dst._arena.copy_(batch._arena, non_blocking=True)          # packed alike: one copy (device-to-device, or pinned host to device)
+                    if batch._arena.device.type == "cpu" and HOST_COPY_ON_ITS_OWN_STREAM:
+                        # pinned host arena: the copy engine's transfer goes on a stream of its own, behind the replay that last read
+                        # this slot's static inputs and in front of its next one (events) — in half-batch mode the next batch then
+                        # crosses PCIe under the current batch's kernels, and a transfer no longer sits between the replays of a
+                        # PAIR of slots (lockstep: it cost 40 % at the 2000-task shape on the slot's own stream, tools/bench_pcie.py)
+                        cs = self._copy_streams[s]
+                        if self._slot_done[s] is not None:
+                            cs.wait_event(self._slot_done[s])      # the replay that last read this slot's static inputs
+                        else:
+                            cs.wait_stream(self.stream(s))
+                        with torch.cuda.stream(cs):
+                            dst._arena.copy_(batch._arena, non_blocking=True)
+                        self.stream(s).wait_stream(cs)
+                    else:
+                        dst._arena.copy_(batch._arena, non_blocking=True)      # packed alike: one copy (device-to-device, or pinned host to device)
                 else:
                     for a, b in zip(self._fields(dst), self._fields(batch)):
                         if a.shape != b.shape:
@@ -376,9 +393,10 @@ class PipelinedRunner:
                     started = torch.cuda.Event()
                     started.record(st)
             out = self.graphs[s]()
+            done = torch.cuda.Event()
+            done.record(self.stream(s))
+            self._slot_done[s] = done               # what the next transfer into this slot's static inputs waits for
             if self.lockstep:
-                done = torch.cuda.Event()
-                done.record(self.stream(s))
                 self._last_done[s] = done
                 if leader:
                     self._open_leader = (s, started, done)

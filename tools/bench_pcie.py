@@ -67,7 +67,11 @@ def run(batches, copy_back, steps):
 resident = max(run(pbs, None, a.steps) for _ in range(2))
 seven = max(run(hbs, "two", a.steps) for _ in range(2))
 one = max(run(ahs, "one", a.steps) for _ in range(2))
+h2d_only = max(run(ahs, None, a.steps) for _ in range(2))          # which direction costs what
+d2h_only = max(run(pbs, "one", a.steps) for _ in range(2))
 print(f"{a.workload} B={B} {a.precision}: inputs resident in HBM {resident / 1e3:.1f} k problems/s; every batch from pinned host memory and "
       f"results back to pinned host memory: {seven / 1e3:.1f} k problems/s with seven host-to-device copies and two device-to-host "
       f"copies per step, {one / 1e3:.1f} k ({one / resident:.3f} of the resident rate) with ONE copy each way "
-      f"(PipelinedRunner.pack_host; {in_bytes / 1024:.0f} KB in, {out_bytes / 1024:.0f} KB out per step of {B} problems)")
+      f"(PipelinedRunner.pack_host; {in_bytes / 1024:.0f} KB in, {out_bytes / 1024:.0f} KB out per step of {B} problems); "
+      f"host-to-device only {h2d_only / resident:.3f}, device-to-host only {d2h_only / resident:.3f} of the resident rate; "
+      f"runner: halves={runner.halves} lockstep={runner.lockstep}")
