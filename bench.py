@@ -313,14 +313,15 @@ def pcie_inclusive_rate(runner, batches, B, T, steps, dev):
     host_out = [torch.empty(B * T + B, dtype=torch.int32).pin_memory() for _ in range(runner.n_slots)]
     dev_out = [torch.empty(B * T + B, dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
 
+    def results_home(out, s):             # on the slot's stream, right behind its replay (PipelinedRunner.submit's `after`)
+        d = dev_out[s]
+        d[: B * T].copy_(out["idx_high"].reshape(-1), non_blocking=True)
+        d[B * T:].copy_(out["R"].view(torch.int32), non_blocking=True)
+        host_out[s].copy_(d, non_blocking=True)
+
     def run(n):
         for i in range(n):
-            out, s = runner.submit(hosts[i % len(hosts)])
-            with torch.cuda.stream(runner.stream(s)):
-                d = dev_out[s]
-                d[: B * T].copy_(out["idx_high"].reshape(-1), non_blocking=True)
-                d[B * T:].copy_(out["R"].view(torch.int32), non_blocking=True)
-                host_out[s].copy_(d, non_blocking=True)
+            runner.submit(hosts[i % len(hosts)], after=results_home)
         runner.synchronize(check=False)
     run(8)
     best = 0.0

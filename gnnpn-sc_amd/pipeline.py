@@ -289,6 +289,7 @@ class PipelinedRunner:
         self.lockstep = self.n_streams == 2 and (env == "1" or (env is None and long_steps))
         self._open_leader, self._last_done = None, [None, None]
         self._slot_done = [None] * self.n_slots
+        self._deferred = None                    # (slot, after): a leader whose replay waits for its partner's submission (submit)
         self._copy_streams = [torch.cuda.Stream() for _ in range(self.n_slots)]   # host-to-device transfers of pinned arenas (submit)
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
@@ -342,13 +343,22 @@ class PipelinedRunner:
         arena before that copy has run (record an event on ``stream(slot)``)."""
         return self._clone(batch, host=True)
 
-    def submit(self, batch=None):
+    def submit(self, batch=None, after=None):
         """Enqueue one batch; returns (outputs dict, slot).  The outputs are the slot's static tensors:
         consume them (or record an event on ``stream(slot)``) before the slot comes round again, ``n_slots`` submits
-        later — in every mode (half-batch mode included: there the slots alternate on one stream)."""
+        later — in every mode (half-batch mode included: there the slots alternate on one stream).
+        ``after(outputs, slot)``: called with the slot's stream current, right behind the enqueued replay — the place for the
+        device-to-host copies of the results.  It matters for slots that start in PAIRS (``lockstep``) when the batch comes from a
+        pinned host arena: the leader's replay is then enqueued together with its partner's, once BOTH transfers are on their way
+        (each replay waits for both), so that the pair still starts together; ``after`` of the leader runs at that moment.
+        Touching ``stream(slot)``, ``poll`` or ``synchronize`` enqueues a waiting leader at once (alone)."""
         s = self.count % self.n_slots
         self.count += 1
-        with torch.cuda.stream(self.stream(s)):
+        if self._deferred is not None and self._deferred[0] == s:
+            self._flush_deferred()
+        staged = False                                   # a transfer of this batch is on the slot's copy stream
+        st = self._stream(s)
+        with torch.cuda.stream(st):
             if batch is not None:
                 dst = self.batches[s]
                 lim = ops.REQUEST_BRANCH_MAX_NODES        # the captured graph holds the one-launch GIN branch (small
@@ -360,16 +370,16 @@ class PipelinedRunner:
                     if batch._arena.device.type == "cpu" and HOST_COPY_ON_ITS_OWN_STREAM:
                         # pinned host arena: the copy engine's transfer goes on a stream of its own, behind the replay that last read
                         # this slot's static inputs and in front of its next one (events) — in half-batch mode the next batch then
-                        # crosses PCIe under the current batch's kernels, and a transfer no longer sits between the replays of a
-                        # PAIR of slots (lockstep: it cost 40 % at the 2000-task shape on the slot's own stream, tools/bench_pcie.py)
+                        # crosses PCIe under the current batch's kernels
                         cs = self._copy_streams[s]
                         if self._slot_done[s] is not None:
                             cs.wait_event(self._slot_done[s])      # the replay that last read this slot's static inputs
                         else:
-                            cs.wait_stream(self.stream(s))
+                            cs.wait_stream(st)
                         with torch.cuda.stream(cs):
                             dst._arena.copy_(batch._arena, non_blocking=True)
-                        self.stream(s).wait_stream(cs)
+                        st.wait_stream(cs)
+                        staged = True
                     else:
                         dst._arena.copy_(batch._arena, non_blocking=True)      # packed alike: one copy (device-to-device, or pinned host to device)
                 else:
@@ -377,12 +387,31 @@ class PipelinedRunner:
                         if a.shape != b.shape:
                             raise ops.GnnpnError(f"PipelinedRunner: batch shape {tuple(b.shape)} != captured {tuple(a.shape)}")
                         a.copy_(b, non_blocking=True)
+        if self.lockstep and staged:
+            # Pairs and transfers: two transfers of a pair run one after the other on the copy engine (0.7 ms each at the 2000-task
+            # shape), so a leader that starts behind ITS transfer is that far ahead of its partner, its encoder arrives while the
+            # partner's front half still holds CUs, and the common start the pairing exists for is gone (PCIe-inclusive rate 0.57
+            # of the resident one).  The leader's replay therefore waits here, on the host side, for its partner's submission.
+            if self._deferred is None:
+                self._deferred = (s, after)
+                return self.graphs[s].outputs, s
+            lead, after_lead = self._deferred
+            self._deferred = None
+            return self._replay_pair(lead, after_lead, s, after), s
+        if self._deferred is not None:
+            self._flush_deferred()
+        return self._replay(s, after), s
+
+    def _replay(self, s, after=None):
+        """One slot's replay, with the pairing of ``lockstep`` for submissions that come one at a time."""
+        st = self._stream(s)
+        with torch.cuda.stream(st):
             leader = False
             if self.lockstep:
                 # A submission joins the leader that is waiting for a partner (and starts with it) if that leader has not
                 # finished yet — the host runs ahead of the device, so back-to-back submissions always pair —; otherwise it
                 # leads a new pair, behind whatever the other slot ran last.
-                st, lead = self.stream(s), self._open_leader
+                lead = self._open_leader
                 if lead is not None and lead[0] != s and not lead[2].query():
                     st.wait_event(lead[1])
                     self._open_leader = None
@@ -394,17 +423,53 @@ class PipelinedRunner:
                     started.record(st)
             out = self.graphs[s]()
             done = torch.cuda.Event()
-            done.record(self.stream(s))
+            done.record(st)
             self._slot_done[s] = done               # what the next transfer into this slot's static inputs waits for
             if self.lockstep:
                 self._last_done[s] = done
                 if leader:
                     self._open_leader = (s, started, done)
-        return out, s
+            if after is not None:
+                after(out, s)
+        return out
+
+    def _replay_pair(self, lead, after_lead, s, after):
+        """Leader and partner enqueued together: each replay behind BOTH transfers, the leader behind whatever the partner's slot
+        ran last, the partner behind the leader's start."""
+        st_l, st_f = self._stream(lead), self._stream(s)
+        st_l.wait_stream(self._copy_streams[s])
+        st_f.wait_stream(self._copy_streams[lead])
+        if self._last_done[s] is not None:
+            st_l.wait_event(self._last_done[s])
+        started = torch.cuda.Event()
+        started.record(st_l)
+        st_f.wait_event(started)
+        outs = {}
+        for slot, stream, cb in ((lead, st_l, after_lead), (s, st_f, after)):
+            with torch.cuda.stream(stream):
+                outs[slot] = self.graphs[slot]()
+                done = torch.cuda.Event()
+                done.record(stream)
+                self._slot_done[slot] = self._last_done[slot] = done
+                if cb is not None:
+                    cb(outs[slot], slot)
+        self._open_leader = None
+        return outs[s]
+
+    def _flush_deferred(self):
+        if self._deferred is not None:
+            lead, after_lead = self._deferred
+            self._deferred = None
+            self._replay(lead, after_lead)
+
+    def _stream(self, slot):
+        return self.streams[slot % self.n_streams]
 
     def stream(self, slot):
-        """The HIP stream slot ``slot``'s replays run on (half-batch mode: every slot's, there is one step in flight)."""
-        return self.streams[slot % self.n_streams]
+        """The HIP stream slot ``slot``'s replays run on (half-batch mode: every slot's, there is one step in flight).  A leader
+        that is waiting for its partner (``submit``) is enqueued first: work a caller puts on the stream comes behind the replay."""
+        self._flush_deferred()
+        return self._stream(slot)
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
@@ -413,6 +478,7 @@ class PipelinedRunner:
     def poll(self):
         """Wait for every slot's stream; the OR of the slots' sticky status words since the last poll / check, cleared — 0: no
         launch reported a failed hand-off.  The non-raising form of ``synchronize(check=True)``."""
+        self._flush_deferred()
         for st in self.streams:
             st.synchronize()
         word = 0
@@ -423,6 +489,7 @@ class PipelinedRunner:
     def synchronize(self, check=True):
         """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a
         failed inter-workgroup hand-off (its outputs would be garbage) — the sticky status words of the slots."""
+        self._flush_deferred()
         for st in self.streams:
             st.synchronize()
         if check:

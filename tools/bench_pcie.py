@@ -44,22 +44,22 @@ out_bytes = host_idx[0].numel() * 4 + host_R[0].numel() * 4
 
 
 def run(batches, copy_back, steps):
+    def two(out, s):
+        host_idx[s].copy_(out["idx_high"], non_blocking=True)
+        host_R[s].copy_(out["R"], non_blocking=True)
+
+    def one(out, s):                                       # idx_high and R packed on the device, one device-to-host copy
+        d = dev_out[s]
+        d[: B * T].copy_(out["idx_high"].view(-1), non_blocking=True)
+        d[B * T:].copy_(out["R"].view(torch.int32), non_blocking=True)
+        host_out[s].copy_(d, non_blocking=True)
+    after = {"two": two, "one": one}.get(copy_back)      # runs on the slot's stream right behind its replay (submit's `after`)
     for i in range(8):
         runner.submit(batches[i % 4])
     runner.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        out, s = runner.submit(batches[i % 4])
-        if copy_back == "two":
-            with torch.cuda.stream(runner.stream(s)):
-                host_idx[i % 2].copy_(out["idx_high"], non_blocking=True)
-                host_R[i % 2].copy_(out["R"], non_blocking=True)
-        elif copy_back == "one":                           # idx_high and R packed on the device, one device-to-host copy
-            with torch.cuda.stream(runner.stream(s)):
-                d = dev_out[i % 2]
-                d[: B * T].copy_(out["idx_high"].view(-1), non_blocking=True)
-                d[B * T:].copy_(out["R"].view(torch.int32), non_blocking=True)
-                host_out[i % 2].copy_(d, non_blocking=True)
+        runner.submit(batches[i % 4], after=after)
     runner.synchronize()
     return B * steps / (time.perf_counter() - t0)
 
