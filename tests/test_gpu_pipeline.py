@@ -403,6 +403,50 @@ def test_infer_writes_artifacts_that_check_scores(dev, tmp_path, monkeypatch):
     assert os.path.exists(p_rank) and os.path.exists(p_act)
 
 
+def test_paired_slots_with_batches_from_pinned_host_memory(dev, monkeypatch):
+    """Slots that start in pairs (``lockstep``; forced here at the QWS shape) fed from pinned host arenas: ``submit`` holds the
+    leader back until its partner is submitted and enqueues both replays behind both transfers; ``after`` runs on the slot's
+    stream right behind the replay (the results' way home); an odd submission is released by ``synchronize`` / ``stream``.  Every
+    step's results equal the single-stream run's, in submission order."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    monkeypatch.setenv("GNNPN_PIPE_LOCKSTEP", "1")
+    T, S, K, B = 47, 940, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=70 + i, tasks_per_problem=10), dev) for i in range(3)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    assert runner.lockstep and not runner.halves
+    refs = [eager_reference(pipe, svc, b, decode_impl=runner.decode_impl) for b in batches]
+    hosts = [runner.pack_host(b) for b in batches]
+    got, order = [], []
+
+    def home(out, s):                                        # on the slot's stream, behind its replay
+        h = {k: torch.empty_like(out[k], device="cpu").pin_memory() for k in ("idx_high", "R")}
+        for k in h:
+            h[k].copy_(out[k], non_blocking=True)
+        got.append(h)
+        order.append(s)
+    n = 7                                                    # odd: the last leader has no partner
+    for i in range(n):
+        runner.submit(hosts[i % 3], after=home)
+        assert len(got) == (i + 1) // 2 * 2                  # a leader's replay (and its `after`) waits for the partner's submission
+    assert runner._deferred is not None
+    runner.synchronize(check=True)                           # releases the waiting leader
+    assert runner._deferred is None and len(got) == n and order == [i % 2 for i in range(n)]
+    for i, h in enumerate(got):
+        assert torch.equal(h["idx_high"], refs[i % 3]["idx_high"].cpu()) and torch.equal(h["R"], refs[i % 3]["R"].cpu()), i
+    runner.submit(hosts[0], after=home)                      # a waiting leader is also released by asking for its stream
+    assert len(got) == n
+    runner.stream(1).synchronize()
+    assert len(got) == n + 1
+    runner.synchronize(check=True)
+    assert torch.equal(got[-1]["idx_high"], refs[0]["idx_high"].cpu())
+
+
 def test_two_slots_whichever_starts_first(dev):
     """Placement by claim (csrc/coop_common.h): every cooperative launch staffs all its groups one workgroup per CU no
     matter what else is resident.  Round 1's LDS-footprint steering only held while slot 0 led; here the two-slot runner
