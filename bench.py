@@ -334,6 +334,35 @@ def pcie_inclusive_rate(runner, batches, B, T, steps, dev):
     return best
 
 
+def gpu_identity(local_rank):
+    """Which physical card a rank runs on — the card's unique id and PCI location from the KFD topology in sysfs (the GPU nodes this
+    process may open, in node order = HIP's device order; no exec, no GPU call): hand-off time-outs have been card-dependent
+    (DESIGN.md section 13.3), so every rank says where it ran (`per_rank` of the bench line)."""
+    import glob
+    try:
+        gpus = []
+        for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(os.path.basename(p))):
+            props = {}
+            try:
+                with open(os.path.join(d, "properties")) as f:
+                    for ln in f:
+                        k, _, v = ln.partition(" ")
+                        props[k] = v.strip()
+            except OSError:                     # a node of another tenant's card: not readable from this container
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                loc = int(props.get("location_id", "0"))
+                gpus.append({"unique_id": hex(int(props["unique_id"])) if props.get("unique_id", "0") != "0" else None,
+                             "pci": f"{int(props.get('domain', '0')):04x}:{loc >> 8:02x}:{(loc >> 3) & 31:02x}.{loc & 7}"})
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+            vis = os.environ.get(var)
+            if vis and all(v.strip().isdigit() for v in vis.split(",")) and all(int(v) < len(gpus) for v in vis.split(",")):
+                gpus = [gpus[int(v)] for v in vis.split(",")]
+        return gpus[local_rank] if local_rank < len(gpus) else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def bind_to_gpu_numa_node(local_rank):
     """Pin this rank's process to the CPUs of the NUMA node its GPU hangs off (eight ranks replaying two HIP graphs every
     0.4-0.8 ms are launch-rate-sensitive: a rank whose host threads sit on the far socket pays for every doorbell).  Reads
@@ -781,7 +810,8 @@ def main():
     # counters of its slots' last encoder launches (members placed, seats off their canonical CU, declined seats)
     lr = sorted(timed_rounds.local)
     mine = {"rank": rank, "ms_per_step_local": round(lr[len(lr) // 2] / args.steps * 1e3, 4) if lr else None,
-            "degraded": cur["degraded"], "placement_last_launch": [w.placement() for w in runner.workspaces] if runner is not None else None}
+            "degraded": cur["degraded"], "placement_last_launch": [w.placement() for w in runner.workspaces] if runner is not None else None,
+            "gpu": gpu_identity(0 if share else local_rank)}
     per_rank = [mine]
     if world > 1:
         import torch.distributed as td
