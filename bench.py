@@ -388,9 +388,18 @@ def bind_to_gpu_numa_node(local_rank):
             vis = os.environ.get(var)
             if vis and all(v.strip().isdigit() for v in vis.split(",")):
                 cards = [cards[int(v)] for v in vis.split(",") if int(v) < len(cards)]
-        if local_rank >= len(cards):
-            return {"bound": False, "why": f"{len(cards)} AMD GPU(s) in sysfs, local rank {local_rank}"}
-        pci, node = cards[local_rank]
+        ident = gpu_identity(local_rank)      # the KFD topology lists the cards THIS process may open (a shared host shows every card
+        pci = node = None                     # under /sys/class/drm): its PCI address wins where it is known
+        if ident is not None:
+            try:
+                with open(f"/sys/bus/pci/devices/{ident['pci']}/numa_node") as f:
+                    pci, node = ident["pci"], int(f.read().strip())
+            except (OSError, ValueError):
+                pci = node = None
+        if pci is None:
+            if local_rank >= len(cards):
+                return {"bound": False, "why": f"{len(cards)} AMD GPU(s) in sysfs, local rank {local_rank}"}
+            pci, node = cards[local_rank]
         if node < 0:
             return {"bound": False, "gpu_pci": pci, "why": "the GPU reports no NUMA node"}
         with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
