@@ -33,6 +33,13 @@ def _record_box():
             k in ln for k in ("Unique ID", "Partition", "MEC firmware", "RLC firmware", "SMC firmware", "SDMA firmware"))]
     except (OSError, subprocess.SubprocessError) as e:
         info["rocm_smi_error"] = str(e)
+    info["amdgpu_parameters"] = {}
+    for name in ("mtype_local", "enforce_isolation", "sched_policy", "hws_max_conc_proc", "mes", "cwsr_enable", "noretry", "mcbp"):
+        try:     # how the host's driver caches local memory across the XCDs' L2s, isolates tenants, schedules queues
+            with open(f"/sys/module/amdgpu/parameters/{name}") as f:
+                info["amdgpu_parameters"][name] = f.read().strip()
+        except OSError:
+            pass
     os.makedirs(os.path.join(ROOT, "gpurun_out", "parity"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity", "box_info.json"), "w") as f:
         json.dump(info, f, indent=1)
