@@ -665,7 +665,7 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
         json.dump(rec, f)
     assert bad0 == bad1 == bad2 == bad3 == 0, rec
     assert lib.gnnpn_coop_staffing_count() == 0
-    assert with_it >= 0.75 * ref_rate and with_8 >= 0.93 * ref_rate, rec           # measured: 13 % / 2 % at the QWS shape (r04_interferer_soak.json)
+    assert with_it >= 0.70 * ref_rate and with_8 >= 0.88 * ref_rate, rec           # measured at the QWS shape: 5-17 % / -1.5-6 % over the round's runs (600 steps are ~1 s: the rates themselves move by a few %)
 
 
 def test_bench_line_contract(dev):
