@@ -614,6 +614,44 @@ def test_csr_aggregate_tiled_skewed_degrees_and_invalid_graphs(dev):
         ops.PREFER_TILED_AGGREGATE = saved
 
 
+@pytest.mark.parametrize("S,copies,degree,weighted,ragged,self_loops,shuffle", [
+    (300, 3, 8, True, False, True, False),          # one source tile, one destination tile
+    (2600, 2, 12, True, True, True, False),         # two source and two destination tiles, a shorter last block
+    (5000, 2, 32, True, False, True, False),        # the 1000-task shape: 2 x 2 tiles, self loops in and out of the last tile
+    (5200, 1, 6, False, False, False, False),       # three source tiles, no weights, no self loops
+    (5000, 1, 16, True, False, True, True),         # edge lists in another order: rows that break the tile order are counted
+])
+def test_tile_plan_equals_the_numpy_restatement(dev, S, copies, degree, weighted, ragged, self_loops, shuffle):
+    """The plan of the tiled aggregate is integer work — tile geometry, the per-row validity rule (does the row's list visit the
+    source tiles in order?), the rows' order inside their units, quads per (unit, source tile), the sliced-ELL stream of LDS
+    offsets and weight bits: bit for bit the plan of oracle/tile_plan.py, an independent numpy restatement."""
+    from oracle import tile_plan as otp
+    ops = _ops()
+    rp, col, w, n = _scan_graph_copies(S, copies, degree, 11, dev, ragged=ragged, self_loops=self_loops)
+    if shuffle:                                                   # reverse every other row's list (self loop kept last)
+        rpc, colc = rp.cpu(), col.cpu().clone()
+        for r in range(0, n, 2):
+            lo, hi = int(rpc[r]), int(rpc[r + 1]) - 1
+            colc[lo:hi] = colc[lo:hi].flip(0)
+        col = colc.to(dev)
+    wd = w if weighted else None
+    plan = ops.TilePlan(rp, col, wd, S)
+    ref = otp.build(rp.cpu().numpy(), col.cpu().numpy(), None if wd is None else wd.cpu().numpy(), n, S)
+    g = ref["geometry"]
+    assert plan.geom == {"n_blocks": g["n_blocks"], "src_tiles": g["NT"], "src_tile_rows": g["TR"], "dst_tiles": g["ND"],
+                         "dst_tile_rows": g["DR"], "units": g["U"], "wavefronts": otp.WAVES, "passes": g["passes"]}
+    for k in ("invalid_rows", "edges", "slots", "rows", "run_histogram"):
+        assert plan.stats[k] == ref["stats"][k], k
+    assert plan.valid == ref["valid"] == (not shuffle)
+    assert np.array_equal(plan.order.cpu().numpy(), ref["order"])
+    assert np.array_equal(plan.selfw.view(torch.int32).cpu().numpy().view(np.uint32), ref["selfw_bits"])
+    assert np.array_equal(plan.header.cpu().numpy().reshape(-1, 2)[:, 1], ref["header"][:, 1])          # quads per (unit, source tile)
+    if plan.valid:
+        assert plan.stats["quads"] == ref["stats"]["quads"]
+        assert np.array_equal(plan.header.cpu().numpy().reshape(-1, 2), ref["header"])
+        assert np.array_equal(plan.batches.cpu().numpy().view(np.uint32), ref["batches"])
+
+
 def test_csr_aggregate_dispatch_prefers_the_tiled_form_on_the_reference_edge_order(dev):
     """ops.csr_aggregate with the block_rows promise on copies of a graph in the reference's emission order: the tiled form runs
     (its plan is built once and cached), results equal the gather form's; through Net.service_embedding the normalised weights
