@@ -342,22 +342,37 @@ __global__ __launch_bounds__(256) void qos_reward_kernel(const float* __restrict
     float prod2 = 1.0f, prod3 = 1.0f, mn = INFINITY;               // 1.0f * z == z: the first row needs no special case
     double sum0 = 0.0;
     int n_real = 0;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + lane;
-        float4 q = make_float4(0.0f, INFINITY, 1.0f, 1.0f);
-        if (t < T) q = *reinterpret_cast<const float4*>(a + (int64_t)t * 8);
+    // 64 rows per batch: one 16-byte load per lane (from a clamped row; lanes beyond T are neutralised when the batch is
+    // consumed), the NEXT batch requested before this batch's serial chain starts — two named buffers, so that no register copy
+    // makes the chain wait for the load it is supposed to hide
+    auto fetch = [&](int t) { return *reinterpret_cast<const float4*>(a + (int64_t)min(t, T - 1) * 8); };
+    auto consume = [&](float4 q, int t0) {
+        if (t0 + lane >= T) q = make_float4(0.0f, INFINITY, 1.0f, 1.0f);
         n_real += q.x > 0.0f;                                      // :26-28 (a padded lane holds 0)
         mn = fminf(mn, q.y);
         const double xd = (double)q.x;                             // np.sum(float32) is pairwise; fp64 then one rounding
         const int lo = __double2loint(xd), hi = __double2hiint(xd);
         const int zi = __float_as_int(q.z), wi = __float_as_int(q.w);
         const int cnt = min(64, T - t0);
-#pragma unroll 8
-        for (int i = 0; i < cnt; ++i) {                            // strictly in step order
-            prod2 = __fmul_rn(prod2, __int_as_float(__builtin_amdgcn_readlane(zi, i)));
-            prod3 = __fmul_rn(prod3, __int_as_float(__builtin_amdgcn_readlane(wi, i)));
-            sum0 += __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
+#define GNNPN_REWARD_STEP(i)                                                                                      \
+    prod2 = __fmul_rn(prod2, __int_as_float(__builtin_amdgcn_readlane(zi, i)));                                   \
+    prod3 = __fmul_rn(prod3, __int_as_float(__builtin_amdgcn_readlane(wi, i)));                                   \
+    sum0 += __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
+        if (cnt == 64) {                                           // strictly in step order; lane numbers as immediates
+#pragma unroll
+            for (int i = 0; i < 64; ++i) { GNNPN_REWARD_STEP(i) }
+        } else {
+            for (int i = 0; i < cnt; ++i) { GNNPN_REWARD_STEP(i) }
         }
+#undef GNNPN_REWARD_STEP
+    };
+    float4 qa = fetch(lane), qb;
+    for (int t0 = 0; t0 < T; t0 += 128) {
+        qb = fetch(t0 + 64 + lane);
+        consume(qa, t0);
+        if (t0 + 64 >= T) break;
+        qa = fetch(t0 + 128 + lane);
+        consume(qb, t0 + 64);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -504,29 +504,40 @@ struct PickProbArgs {
     const int32_t* idx[2];
     float* out[2];
 };
-// blockIdx.y = net: both nets' normalisers in ONE launch
+// blockIdx.y = net: both nets' normalisers in ONE launch.  One LANE per (problem, step): its <= 16 logits in registers, the sum
+// formed by the same tree the 16-lane DPP form walks (rotations 8, 4, 2, 1 seen from lane 0: p_i = e_i + e_{i+8}, q_i = p_i + p_{i+4},
+// r_i = q_i + q_{i+2}, r_0 + r_1; absent entries are exact zeros) — the same bits with a sixteenth of the waves.
 __global__ __launch_bounds__(256) void pick_prob_kernel(PickProbArgs a, int64_t rows, int T, int K) {
     const int net = blockIdx.y;
     const float* __restrict__ win = a.win[net];
     const float* __restrict__ lat = a.lat[net];
     const int32_t* __restrict__ idx = a.idx[net];
     float* __restrict__ out = a.out[net];
-    const int64_t row = blockIdx.x * 16ll + (threadIdx.x >> 4);
-    const int r = threadIdx.x & 15, lane = threadIdx.x & 63;
-    const bool live = r < K && row < rows;
-    float v = 0.0f;
-    if (live) {
-        v = win[row * K + r];
-        if (lat) v = __fadd_rn(v, lat[row * K + r]);
-    }
-    int pick_r = 0;
-    if (row < rows) pick_r = idx[row] - (int)(row % T) * K;
-    pick_r = min(max(pick_r, 0), 15);
-    const float best = __shfl(v, (lane & ~15) + pick_r, 64);
-    float e = live ? expf(__fsub_rn(v, best)) : 0.0f;
+    const int64_t row = blockIdx.x * 256ll + threadIdx.x;
+    if (row >= rows) return;
+    // the step of this row: one 64-bit remainder per workgroup (scalar), a 32-bit one per lane
+    const unsigned t_base = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256ll) % T));
+    const int t = (int)((t_base + threadIdx.x) % (unsigned)T);
+    float v[16];
 #pragma unroll
-    for (int n = 8; n >= 1; n >>= 1) e = __fadd_rn(e, dpp_ror(e, n));
-    if (r == 0 && row < rows) out[row] = 1.0f / e;
+    for (int j = 0; j < 16; ++j) {
+        v[j] = 0.0f;
+        if (j < K) {
+            v[j] = win[row * K + j];
+            if (lat) v[j] = __fadd_rn(v[j], lat[row * K + j]);
+        }
+    }
+    const int pick_r = min(max(idx[row] - t * K, 0), 15);
+    float best = v[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) best = j == pick_r ? v[j] : best;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = j < K ? expf(__fsub_rn(v[j], best)) : 0.0f;
+#pragma unroll
+    for (int n = 8; n >= 1; n >>= 1)
+#pragma unroll
+        for (int j = 0; j < n; ++j) v[j] = __fadd_rn(v[j], v[j + n]);
+    out[row] = 1.0f / v[0];
 }
 
 int64_t gnnpn_decode_lean_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
@@ -604,7 +615,7 @@ int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, 
             pa.idx[n] = d.idx;
             pa.out[n] = d.pick_prob;
         }
-        hipLaunchKernelGGL(pick_prob_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)cnt), dim3(256), 0, s, pa, rows, args.T, args.K);
+        hipLaunchKernelGGL(pick_prob_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)cnt), dim3(256), 0, s, pa, rows, args.T, args.K);
     }
     return GNNPN_OK;
 }

@@ -109,7 +109,23 @@ __global__ __launch_bounds__(256) void select_candidates16_kernel(
     unsigned long long last = ~0ull;
     int my_pick = -1;   // lane r of the row keeps the r-th pick
     int n_found = 0;
-    if (pres) {
+    if (pres && s_end - s_begin <= 16) {
+        // a category of at most 16 services (the 1000-task shapes: 5): every lane forms its ONE key once — 0 if the service is
+        // infeasible or absent — and the rounds are max-reductions over registers (no re-read of the scores and bounds per pick)
+        unsigned long long key = 0ull;
+        const int s = s_begin + sub;
+        if (s < s_end) {
+            const double cost = qos[(int64_t)s * 4 + 2], qual = qos[(int64_t)s * 4 + 3];
+            if (lo_c <= cost && cost <= hi_c && lo_q <= qual && qual <= hi_q) key = rank_key(srow[s], (uint32_t)s);
+        }
+        for (int r = 0; r < n_per; ++r) {
+            const unsigned long long best = row16_max_u64(key < last ? key : 0ull);
+            if (best == 0ull) break;
+            if (sub == r) my_pick = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            last = best;
+            ++n_found;
+        }
+    } else if (pres) {
         for (int r = 0; r < n_per; ++r) {
             unsigned long long best = 0ull;
             for (int s = s_begin + sub; s < s_end; s += 16) {

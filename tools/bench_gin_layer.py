@@ -10,6 +10,7 @@ ap.add_argument("--rows", type=int, default=512 * 1001)
 ap.add_argument("--nodes", type=int, default=1001)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--forms", default="f32,split")
+ap.add_argument("--pad0", action="store_true", help="also time layer 0 on the input zero-padded to 32 channels (16-byte gathers)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = a.rows
@@ -51,4 +52,12 @@ for name, c_in, lin in (("layer0", 26, False), ("layer1", 128, True)):
         ms = timed(lambda: ops.gin_layer_split(csr.rowptr, csr.col, x, eps, *p[0], b1, a1, s1, *p[1], b2, a2, s2,
                                                *(p[2] if lin else (None, None)), b3 if lin else None))
         out[name + "_split"] = {"ms": round(ms, 4), "TFLOPs_fp32_equivalent": round(flop / ms / 1e9, 1)}
+    if a.pad0 and c_in % 4:
+        xp = torch.nn.functional.pad(x, (0, 32 - c_in)).contiguous()
+        if "split" in a.forms:
+            f = lambda xx: ops.gin_layer_split(csr.rowptr, csr.col, xx, eps, *p[0], b1, a1, s1, *p[1], b2, a2, s2, None, None, None)   # noqa: E731
+            out[name + "_split_padded32"] = {"ms": round(timed(lambda: f(xp)), 4), "same_bits": bool(torch.equal(f(xp), f(x)))}
+        if "f32" in a.forms:
+            f = lambda xx: ops.gin_layer(csr.rowptr, csr.col, xx, eps, q[0], b1, a1, s1, q[1], b2, a2, s2, None, None)   # noqa: E731
+            out[name + "_f32_padded32"] = {"ms": round(timed(lambda: f(xp)), 4), "same_bits": bool(torch.equal(f(xp), f(x)))}
 print(json.dumps(out))
