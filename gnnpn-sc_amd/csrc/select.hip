@@ -70,56 +70,64 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
 // maximum is four DPP rotations instead of six cross-wave shuffles on each key half, and a category of 5 services (the
 // 1000-task shapes) no longer occupies a whole wave.  Same keys, same order of picks, same emitted rows.
 __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int n = 1; n <= 8; n <<= 1) {
-        const int ctrl = 0x120 + n;                                    // row_ror:n
-        unsigned lo, hi;
-        switch (n) {
-            case 1: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x121, 0xF, 0xF, true);
-                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x121, 0xF, 0xF, true); break;
-            case 2: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x122, 0xF, 0xF, true);
-                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x122, 0xF, 0xF, true); break;
-            case 4: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x124, 0xF, 0xF, true);
-                    hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x124, 0xF, 0xF, true); break;
-            default: lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x128, 0xF, 0xF, true);
-                     hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x128, 0xF, 0xF, true); break;
-        }
-        (void)ctrl;
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
+#define GNNPN_MAX_STEP(CTRL)                                                                                       \
+    {                                                                                                              \
+        const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);                \
+        const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);        \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                          \
+        v = o > v ? o : v;                                                                                         \
     }
+    GNNPN_MAX_STEP(0x121) GNNPN_MAX_STEP(0x122) GNNPN_MAX_STEP(0x124) GNNPN_MAX_STEP(0x128)   // row_ror:1, 2, 4, 8
     return v;
 }
+// ... and over groups of 8 lanes: the neighbour, the other pair (quad_perm), the other quad (row_half_mirror); a maximum does
+// not depend on the order it is formed in
+__device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v) {
+    GNNPN_MAX_STEP(0xB1) GNNPN_MAX_STEP(0x4E) GNNPN_MAX_STEP(0x141)
+    return v;
+#undef GNNPN_MAX_STEP
+}
 
+// W = 16 or 8 lanes per segment; 8 (n_per <= 8, categories of about 8 services or fewer: the 1000-task shapes have 5) puts eight
+// segments into a wave — the kernel is bound by its vector instructions, which are per wave.
+template <int W>
 __global__ __launch_bounds__(256) void select_candidates16_kernel(
     const float* __restrict__ scores, int64_t ld_scores, const int32_t* __restrict__ cat_ptr,
     const double* __restrict__ qos, const double* __restrict__ local_bounds, const uint8_t* __restrict__ present,
     const double* __restrict__ global_bounds, float* __restrict__ out_rows, int32_t* __restrict__ out_ids,
     int32_t B, int32_t T, int32_t n_per) {
-    const int lane = threadIdx.x & 63, sub = lane & 15;
-    const int64_t seg = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    if (seg >= (int64_t)B * T) return;                                  // whole 16-lane rows leave together
-    const int b = (int)(seg / T), c = (int)(seg - (int64_t)b * T);
+    const int lane = threadIdx.x & 63, sub = lane & (W - 1);
+    const int64_t seg = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / W) + lane / W;
+    if (seg >= (int64_t)B * T) return;                                  // whole W-lane groups leave together
+    const int b = (int64_t)B * T <= 0x7fffffffll ? (int)((unsigned)seg / (unsigned)T) : (int)(seg / T);   // (a 64-bit division per lane is ~100 instructions)
+    const int c = (int)(seg - (int64_t)b * T);
     const int s_begin = cat_ptr[c], s_end = cat_ptr[c + 1];
     const bool pres = present[seg] != 0;
     const double* lb = local_bounds + seg * 4;
     const double lo_c = lb[0], hi_c = lb[1], lo_q = lb[2], hi_q = lb[3];
     const float* srow = scores + (int64_t)b * ld_scores;
 
+    auto group_max = [](unsigned long long v) { return W == 16 ? row16_max_u64(v) : row8_max_u64(v); };
     unsigned long long last = ~0ull;
     int my_pick = -1;   // lane r of the row keeps the r-th pick
     int n_found = 0;
-    if (pres && s_end - s_begin <= 16) {
-        // a category of at most 16 services (the 1000-task shapes: 5): every lane forms its ONE key once — 0 if the service is
-        // infeasible or absent — and the rounds are max-reductions over registers (no re-read of the scores and bounds per pick)
+    const bool small = s_end - s_begin <= W;
+    float4 own = make_float4(0.f, 1.f, 1.f, 1.f);                      // this lane's service's QoS row (small categories)
+    if (pres && small) {
+        // a category of at most W services (the 1000-task shapes: 5): every lane forms its ONE key once — 0 if the service is
+        // infeasible or absent — and the rounds are max-reductions over registers (no re-read of the scores and bounds per pick);
+        // the lane keeps its service's whole QoS row, so the emitted rows come from a lane exchange, not from a second,
+        // dependent round of loads
         unsigned long long key = 0ull;
         const int s = s_begin + sub;
         if (s < s_end) {
-            const double cost = qos[(int64_t)s * 4 + 2], qual = qos[(int64_t)s * 4 + 3];
+            const double* qs = qos + (int64_t)s * 4;
+            const double q0 = qs[0], q1 = qs[1], cost = qs[2], qual = qs[3];
+            own = make_float4((float)q0, (float)q1, (float)cost, (float)qual);
             if (lo_c <= cost && cost <= hi_c && lo_q <= qual && qual <= hi_q) key = rank_key(srow[s], (uint32_t)s);
         }
         for (int r = 0; r < n_per; ++r) {
-            const unsigned long long best = row16_max_u64(key < last ? key : 0ull);
+            const unsigned long long best = group_max(key < last ? key : 0ull);
             if (best == 0ull) break;
             if (sub == r) my_pick = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
             last = best;
@@ -128,13 +136,13 @@ __global__ __launch_bounds__(256) void select_candidates16_kernel(
     } else if (pres) {
         for (int r = 0; r < n_per; ++r) {
             unsigned long long best = 0ull;
-            for (int s = s_begin + sub; s < s_end; s += 16) {
+            for (int s = s_begin + sub; s < s_end; s += W) {
                 const double cost = qos[(int64_t)s * 4 + 2], qual = qos[(int64_t)s * 4 + 3];
                 const bool feas = lo_c <= cost && cost <= hi_c && lo_q <= qual && qual <= hi_q;
                 const unsigned long long key = rank_key(srow[s], (uint32_t)s);
                 if (feas && key < last && key > best) best = key;
             }
-            best = row16_max_u64(best);
+            best = group_max(best);
             if (best == 0ull) break;
             if (sub == r) my_pick = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
             last = best;
@@ -142,17 +150,20 @@ __global__ __launch_bounds__(256) void select_candidates16_kernel(
         }
     }
     // emit n_per rows: picks repeated cyclically (loadData.py:137-141), dummy rows otherwise (:148)
-    const int src_lane = (lane & ~15) + (n_found > 0 ? sub % n_found : 0);
+    const int src_lane = (lane & ~(W - 1)) + (n_found > 0 ? sub % n_found : 0);
     const int id = __shfl(my_pick, src_lane, 64);
+    float4 q = make_float4(0.f, 1.f, 1.f, 1.f);
+    if (small) {                                                       // (the whole group of W lanes takes this branch together)
+        const int owner = n_found > 0 ? (lane & ~(W - 1)) + (id - s_begin) : lane;
+        const float4 g = make_float4(__shfl(own.x, owner, 64), __shfl(own.y, owner, 64), __shfl(own.z, owner, 64), __shfl(own.w, owner, 64));
+        if (n_found > 0) q = g;
+    } else if (n_found > 0 && sub < n_per) {
+        const double* qs = qos + (int64_t)id * 4;
+        q = make_float4((float)qs[0], (float)qs[1], (float)qs[2], (float)qs[3]);
+    }
     if (sub < n_per) {
         const int64_t pos = (int64_t)b * T * n_per + (int64_t)c * n_per + sub;
-        float4 q, tail = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n_found > 0) {
-            const double* qs = qos + (int64_t)id * 4;
-            q = make_float4((float)qs[0], (float)qs[1], (float)qs[2], (float)qs[3]);
-        } else {
-            q = make_float4(0.f, 1.f, 1.f, 1.f);
-        }
+        float4 tail = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c == 0) {
             const double* g = global_bounds + (int64_t)b * 4;
             tail = make_float4((float)g[0], (float)g[1], (float)g[2], (float)g[3]);
@@ -176,8 +187,12 @@ extern "C" int gnnpn_select_candidates(const float* scores, int64_t ld_scores, c
     GNNPN_REQUIRE(gnnpn_aligned(out_rows, 16), "select_candidates: out_rows must be 16-byte aligned");
     if (B == 0) return GNNPN_OK;
     const int64_t n_seg = (int64_t)B * T;
-    if (n_per <= 16)
-        hipLaunchKernelGGL(select_candidates16_kernel, dim3((unsigned)((n_seg + 15) / 16)), dim3(256), 0,
+    if (n_per <= 8 && ld_scores <= 8ll * T)                            // (ld_scores >= the number of services: mean category <= 8)
+        hipLaunchKernelGGL(select_candidates16_kernel<8>, dim3((unsigned)((n_seg + 31) / 32)), dim3(256), 0,
+                           (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
+                           out_rows, out_ids, B, T, n_per);
+    else if (n_per <= 16)
+        hipLaunchKernelGGL(select_candidates16_kernel<16>, dim3((unsigned)((n_seg + 15) / 16)), dim3(256), 0,
                            (hipStream_t)stream, scores, ld_scores, cat_ptr, qos, local_bounds, present, global_bounds,
                            out_rows, out_ids, B, T, n_per);
     else

@@ -336,19 +336,21 @@ def test_select_candidates_vs_oracle(dev):
     assert (ids.cpu()[(want[:, :, :4] == torch.tensor([0., 1., 1., 1.])).all(-1)] == -1).all()
 
 
-@pytest.mark.parametrize("K", [1, 5, 16])
-def test_select_candidates_16_lane_form_equals_wave_form(dev, K):
-    """n_per <= 16 runs with 16 lanes per (problem, category) segment (four segments per wave), larger n_per with a whole
+@pytest.mark.parametrize("K,max_size", [(1, 70), (5, 70), (16, 70), (1, 12), (5, 12), (8, 12), (5, 5), (9, 12)])
+def test_select_candidates_16_lane_form_equals_wave_form(dev, K, max_size):
+    """n_per <= 16 runs with 16 lanes per (problem, category) segment (four segments per wave) — 8 lanes (eight segments per wave)
+    when n_per <= 8 and the categories average at most 8 services, the 1000-task shapes —, larger n_per with a whole
     wave per segment.  The picks are the same sequence, so the first K of a 20-pick selection (emitted cyclically when
-    fewer are feasible) are the K-pick selection: categories of 1..70 services, absent categories, tight and loose bounds,
-    score ties."""
+    fewer are feasible) are the K-pick selection: categories of 1..max_size services (both sides of the group width, i.e. the
+    keys-in-registers path and the strided scan), absent categories, tight and loose bounds, score ties."""
     ops = _ops()
-    g = torch.Generator().manual_seed(70 + K)
-    sizes = torch.randint(1, 71, (37,), generator=g)
-    sizes[3], sizes[11] = 1, 70
+    g = torch.Generator().manual_seed(70 + K + max_size)
+    sizes = torch.randint(1, max_size + 1, (37,), generator=g)
+    sizes[3], sizes[11] = 1, max_size
     cat_ptr = torch.zeros(38, dtype=torch.int32)
     cat_ptr[1:] = torch.cumsum(sizes, 0).int()
     S, T, B = int(cat_ptr[-1]), 37, 9
+    assert (S <= 8 * T) == (max_size <= 12)                              # which launch the case exercises (csrc/select.hip)
     qos = torch.rand(S, 4, generator=g, dtype=torch.float64)
     scores = torch.rand(B, S, generator=g)
     n7 = scores[:, 1::7].shape[1]
