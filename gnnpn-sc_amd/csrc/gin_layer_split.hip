@@ -201,6 +201,48 @@ __device__ __forceinline__ void store_global(const f32x4 (&v)[RT][NCT], float* _
     }
 }
 
+// xs (already times the row's power-of-two factor) -> its three fp16 pieces, four features at a time.  Three forms of the residual
+// (x - p) 2^11, all exact and therefore the same bits: 0 = convert the piece back, subtract, multiply (10 instructions per four
+// features); 1 = fma(p, -2^11, x 2^11) written in C (the compiler packs it behind the conversions: 8); 2 = the same fma as
+// v_fma_mix_f32, which reads the fp16 piece itself (6).  Measured on one box, layer 0 / layer 1 (tools/ablate_gin_layer.py
+// F0..F2): 0.408 / 0.624-0.629, 0.411-0.416 / 0.628-0.631, 0.410 / 0.614-0.622 ms — the ~190 vector instructions per wave the
+// third form saves are not what binds the layer (section 13.2), so the plain form stays the default.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifndef GNNPN_GIN_SPLIT_FORM
+#define GNNPN_GIN_SPLIT_FORM 0
+#endif
+// fma(half `hi` of the fp16 pair `pair`, neg_scale, c) with the piece read as fp16 by the instruction itself
+template <int HI>
+__device__ __forceinline__ float fma_mix_f16(unsigned pair, float neg_scale, float c) {
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "s"(neg_scale), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "s"(neg_scale), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x4 residual_x4(const f32x4 x, const f16x4 p) {
+#if GNNPN_GIN_SPLIT_FORM == 0
+    return (x - __builtin_convertvector(p, f32x4)) * SPLIT_SCALE;
+#elif GNNPN_GIN_SPLIT_FORM == 1
+    const f32x4 up = x * SPLIT_SCALE;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmaf((float)p[i], -SPLIT_SCALE, up[i]);
+    return r;
+#else
+    const f32x4 up = x * SPLIT_SCALE;
+    const u32x2 pp = __builtin_bit_cast(u32x2, p);
+    const float ns = -SPLIT_SCALE;
+    return f32x4{fma_mix_f16<0>(pp[0], ns, up[0]), fma_mix_f16<1>(pp[0], ns, up[1]), fma_mix_f16<0>(pp[1], ns, up[2]),
+                 fma_mix_f16<1>(pp[1], ns, up[3])};
+#endif
+}
+__device__ __forceinline__ void split3x4(const f32x4 xs, f16x4& p0, f16x4& p1, f16x4& p2) {
+    p0 = __builtin_convertvector(xs, f16x4);
+    const f32x4 r1 = residual_x4(xs, p0);
+    p1 = __builtin_convertvector(r1, f16x4);
+    p2 = __builtin_convertvector(residual_x4(r1, p1), f16x4);
+}
+
 // per-row maximum of |v| over this wave's features -> rowmax[wave][BM]
 template <int NP>
 __device__ __forceinline__ void publish_row_max(const f32x4 (&v)[NP][RT][NCT], float* rowmax, int wave, int c, int kq) {
@@ -232,12 +274,8 @@ __device__ __forceinline__ void split_rows_to_lds(const f32x4 (&v)[NP][RT][NCT],
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int n = 0; n < NCT; ++n) {
-                const f32x4 xs = v[p][rt][n] * up;
-                const f16x4 p0 = __builtin_convertvector(xs, f16x4);
-                const f32x4 r1 = (xs - __builtin_convertvector(p0, f32x4)) * SPLIT_SCALE;
-                const f16x4 p1 = __builtin_convertvector(r1, f16x4);
-                const f32x4 r2 = (r1 - __builtin_convertvector(p1, f32x4)) * SPLIT_SCALE;
-                const f16x4 p2 = __builtin_convertvector(r2, f16x4);
+                f16x4 p0, p1, p2;
+                split3x4(v[p][rt][n] * up, p0, p1, p2);
                 _Float16* at = dst + row * ld + 16 * (ct0[p] + n) + 4 * kq;
                 *reinterpret_cast<f16x4*>(at) = p0;
 #if !(GNNPN_GIN_ABLATE & 8)
@@ -343,15 +381,12 @@ __global__ __launch_bounds__(256, GNNPN_GIN_WGS) void gin_layer_split_kernel(
         for (int i = 0; i < NCH_MAX; ++i) {
             const int ch = 4 * (sub + 8 * i);
             if (ch < k1a) {                                 // (chunks beyond c_in: the zero padding of the last k-block)
-                const f32x4 xs = f32x4{acc[i].x, acc[i].y, acc[i].z, acc[i].w} * up;
-                const f16x4 p0 = __builtin_convertvector(xs, f16x4);
-                const f32x4 r1 = (xs - __builtin_convertvector(p0, f32x4)) * SPLIT_SCALE;
-                const f16x4 p1 = __builtin_convertvector(r1, f16x4);
-                const f32x4 r2 = (r1 - __builtin_convertvector(p1, f32x4)) * SPLIT_SCALE;
+                f16x4 p0, p1, p2;
+                split3x4(f32x4{acc[i].x, acc[i].y, acc[i].z, acc[i].w} * up, p0, p1, p2);
                 _Float16* at = As + r * lda + ch;
                 *reinterpret_cast<f16x4*>(at) = p0;
                 *reinterpret_cast<f16x4*>(at + pieceA) = p1;
-                *reinterpret_cast<f16x4*>(at + 2 * pieceA) = __builtin_convertvector(r2, f16x4);
+                *reinterpret_cast<f16x4*>(at + 2 * pieceA) = p2;
             }
         }
     }

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _ops():
     import gnnpn_sc_amd.ops as ops
+    import gnnpn_sc_amd.custom_ops  # noqa: F401  (registers torch.ops.gnnpn.* from libgnnpn_torch.so: tests here call both layers)
     return ops
 
 
