@@ -311,6 +311,27 @@ def test_qos_reward_golden(dev):
     assert float((ops.qos_reward(a, "High").cpu() - torch.from_numpy(fx["R_high"])).abs().max()) <= 1.0001e-5
 
 
+@pytest.mark.parametrize("T", [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 1000])
+def test_qos_reward_batches_of_64_rows(dev, T):
+    """The reward kernel walks a problem's T action rows in batches of 64 (two alternating row buffers, the chain of a full
+    batch unrolled, a shorter last one looped): both sides of every batch boundary against the oracle's reward
+    (modelPN.py:15-72), Low (violation counts, exact) and High (rounded to 1e-5)."""
+    from oracle import pn as opn
+    ops = _ops()
+    g = torch.Generator().manual_seed(T)
+    B = 9
+    act = torch.rand(B, T, 8, generator=g)
+    act[:, :, 2:4] = 1.0 - act[:, :, 2:4] * (2.0 / max(T, 2))          # products over T rows that stay near the bounds
+    act[:, :, 4:] = 0.0
+    act[:, 0, 4:8] = torch.tensor([0.2, 0.9, 0.2, 0.9])
+    act[1, :, 0:4] = torch.tensor([0.0, 1.0, 1.0, 1.0])                 # dummy rows except one
+    act[1, T // 2, 0] = 0.4
+    rows = [act[:, t] for t in range(T)]
+    assert torch.equal(ops.qos_reward(act.to(dev), "Low").cpu(), opn.reward(rows, "Low"))
+    assert float((ops.qos_reward(act.to(dev), "High").cpu() - opn.reward(rows, "High")).abs().max()) <= 1.0001e-5
+    assert len(set(opn.reward(rows, "Low").tolist())) > 1 or T < 3     # the bounds do separate the problems
+
+
 def test_select_candidates_vs_oracle(dev):
     """Same selections as the oracle's rank-ordered loadDataPN on a dataset in the reference's JSON
     format, including padding and absent categories."""

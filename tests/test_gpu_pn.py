@@ -318,6 +318,15 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
           assert_index_parity(out8["idx_high"], ref["idx_high"], robust, "coop8/high", 0.8, x.cpu())).to(dev)
     assert float((out8["win_low"][s8] - ref["win_low"][s8]).abs().max()) < 1e-4
     assert float((out8["R"][s8] - ref["R"][s8]).abs().max()) <= R_ATOL
+    # the pick's probability: the 256-register build forms it in a kernel of its own (pick_prob_kernel, one lane per (problem,
+    # step)), the other builds inside the decoder (lane 0 of a 16-lane DPP reduction) — the same tree of sums, so wherever the
+    # logits and picks of two builds are the same bits, so are the probabilities
+    for other in (out8, out):
+        eq = (out4["idx_high"] == other["idx_high"]).all(1) & (out4["win_high_raw"] == other["win_high_raw"]).flatten(1).all(1) & \
+            (out4["win_low"] == other["win_low"]).flatten(1).all(1)
+        if K <= 8:                                                # (K > 8: impl 4 IS the 16-CU form)
+            assert bool(eq.any())
+        assert torch.equal(out4["action_probs"][eq], other["action_probs"][eq])
     s4 = (assert_index_parity(out4["idx_low"], ref["idx_low"], robust, "coop8x2/low", 0.8, x.cpu()) &
           assert_index_parity(out4["idx_high"], ref["idx_high"], robust, "coop8x2/high", 0.8, x.cpu())).to(dev)
     assert float((out4["win_low"][s4] - ref["win_low"][s4]).abs().max()) < 1e-4
