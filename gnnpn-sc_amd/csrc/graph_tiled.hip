@@ -50,6 +50,18 @@ constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, 
 #ifndef GNNPN_TILED_TILE_ROWS
 #define GNNPN_TILED_TILE_ROWS 2559
 #endif
+// (experiment switch: 1 = one workgroup per CU that walks its XCD's items in a loop, the register-staged fill of the next item's
+// first tile right behind this item's stores — 0.665 / 0.841 / 0.496 ms against 0.645 / 0.787 / 0.452 at 2507 x 256 / 5000 x 128 /
+// 20000 x 8 (tools/ablate_aggregate.py build+run P0= P1=-DGNNPN_TILED_PERSISTENT=1): the hardware's dispatch of 4096 workgroups
+// balances the CUs better than a static walk, and a workgroup launch costs less than the imbalance)
+#ifndef GNNPN_TILED_PERSISTENT
+#define GNNPN_TILED_PERSISTENT 0
+#endif
+#if GNNPN_TILED_PERSISTENT
+#define GNNPN_TILED_NEXT continue
+#else
+#define GNNPN_TILED_NEXT return
+#endif
 constexpr int WAVES = GNNPN_TILED_WAVES;  // wavefronts per workgroup: 16 = one workgroup per CU
 constexpr int TILE_ROWS_MAX = GNNPN_TILED_TILE_ROWS;   // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
 constexpr int DST_ROWS_MAX = WAVES * 16 * PASSES_MAX;   // destination rows per workgroup: 10 passes of 256 rows (1024 lanes, 4 per row)
@@ -323,19 +335,31 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int2* __restrict__ header, const int32_t* __restrict__ order, const float* __restrict__ selfw,
     const uint4* __restrict__ batches, const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef,
     const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ y, int64_t ldy, int32_t n_rows, Geom g, int32_t n_slices) {
+    float* __restrict__ y, int64_t ldy, int32_t n_rows, Geom g, int32_t n_slices, int32_t n_jj) {
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [TR + 1][16]: the source tile's slice and one all-zero row
     constexpr int RPP = WAVES * 16;                                       // rows per pass of the workgroup (4 lanes per row)
     // placement (speed only): the (destination tile, slice) workgroups of one block get equal blockIdx % 8 — one XCD — so
     // that the four 64-byte pieces of every 256-byte stretch of x (four slices) and the block's stream meet in that XCD's L2
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
     const int per_block = g.ND * n_slices;
+    const int tid = threadIdx.x, sub = tid & 3, lane = tid & 63, wave = tid >> 6;
+#if GNNPN_TILED_PERSISTENT
+    // one workgroup per CU walks its XCD's items: the next item's first fill is requested right behind this item's stores
+    // (no drain of the stores, no workgroup launch, between two items)
+    bool first_item = true;
+    for (int jj = blockIdx.x >> 3; jj < n_jj; jj += (int)(gridDim.x >> 3)) {
+    if (!first_item) __syncthreads();                                     // every gather from the previous item's last tile is done
+    first_item = false;
+#else
+    const int jj = blockIdx.x >> 3;
+    (void)n_jj;
+    {
+#endif
     const int b = (jj / per_block) * 8 + xcd;
-    if (b >= g.n_blocks) return;
+    if (b >= g.n_blocks) GNNPN_TILED_NEXT;
     const int d = (jj % per_block) / n_slices, s = (jj % per_block) % n_slices;
     const int r0 = b * g.R, Rb = min(g.R, n_rows - r0);
-    if (Rb - d * g.DR <= 0) return;                                       // ragged last block: no rows in this destination tile
-    const int tid = threadIdx.x, sub = tid & 3, lane = tid & 63, wave = tid >> 6;
+    if (Rb - d * g.DR <= 0) GNNPN_TILED_NEXT;                             // ragged last block: no rows in this destination tile
     const int c = s * 16 + 4 * sub;
     const char* tile_b = reinterpret_cast<const char*>(tile);
     const int lane_off = 16 * sub;
@@ -453,6 +477,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         if (!(GNNPN_AGG_ABLATE & 8) || acc[0] == 1.2345e30f)
             *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+    }   // item
 }
 
 }  // namespace
@@ -534,7 +559,17 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
                    SRC_TILES_MAX, TILE_ROWS_MAX);
     const int n_slices = C / 16;
     const unsigned lds = (unsigned)(g.TR + 1) * 64u;
-    dim3 grid((unsigned)(((g.n_blocks + 7) / 8) * g.ND * n_slices * 8)), block(WAVES * 64);
+    const int n_jj = ((g.n_blocks + 7) / 8) * g.ND * n_slices;
+    dim3 grid((unsigned)(n_jj * 8)), block(WAVES * 64);
+#if GNNPN_TILED_PERSISTENT
+    {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8)
+            GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot query the device");
+        const unsigned per_xcd = (unsigned)(n_cu / 8) * (unsigned)(16 / WAVES > 0 ? 16 / WAVES : 1);
+        if (grid.x > per_xcd * 8) grid.x = per_xcd * 8;
+    }
+#endif
     hipStream_t st = (hipStream_t)stream;
 #define GNNPN_AGG_TILED(P_, H_)                                                                                             \
     do {                                                                                                                  \
@@ -543,7 +578,7 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
             GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot reserve %u B of LDS", lds);                           \
         hipLaunchKernelGGL((csr_aggregate_tiled_kernel<P_, H_>), grid, block, lds, st, reinterpret_cast<const int2*>(header), \
                            order, selfw, static_cast<const uint4*>(batches), x, ldx, self_coef, bias, scale, shift, act, \
-                           y, ldy, n_rows, g, n_slices);                                                                  \
+                           y, ldy, n_rows, g, n_slices, n_jj);                                                            \
     } while (0)
     // more than 64 (source tile, pass) headers per wavefront only occur with 7 or 8 source tiles, i.e. full destination tiles
     switch (g.passes) {

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gnnpn-sc_amd")
 OUT = os.path.join(PKG, "build", "ablate")
 VARIANTS = [0, 1, 2, 3, 4, 8, 12, 16, 19, 31]
+EXTRA = {}            # name -> -D flags of an experiment build: python tools/ablate_aggregate.py build P1=-DGNNPN_TILED_PERSISTENT=1 ...
 
 
 def build():
@@ -23,11 +24,12 @@ def build():
     b.build()
     os.makedirs(OUT, exist_ok=True)
     objs = [os.path.join(PKG, "build", s.replace(".hip", ".o")) for s in b.SOURCES]
-    for v in VARIANTS:
+    todo = {v: [f"-DGNNPN_AGG_ABLATE={v}"] for v in VARIANTS} if not EXTRA else EXTRA
+    for v, flags in todo.items():
         mine = []
         for src in ("graph.hip", "graph_tiled.hip"):
             o = os.path.join(OUT, f"{src[:-4]}_abl{v}.o")
-            subprocess.run(["hipcc"] + b.FLAGS + [f"-DGNNPN_AGG_ABLATE={v}", "-c", os.path.join(b.CSRC, src), "-o", o], check=True)
+            subprocess.run(["hipcc"] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", o], check=True)
             mine.append(o)
         rest = [o for o in objs if os.path.basename(o) not in ("graph.o", "graph_tiled.o")]
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(OUT, f"libgnnpn_hip_abl{v}.so")] + rest + mine, check=True)
@@ -35,7 +37,7 @@ def build():
 
 
 def run(configs):
-    for v in VARIANTS:
+    for v in (EXTRA or VARIANTS):
         env = dict(os.environ, GNNPN_LIB=os.path.join(OUT, f"libgnnpn_hip_abl{v}.so"), PYTHONPATH=ROOT)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_aggregate.py"), "--configs", ",".join(configs),
                             "--forms", "tiled", "--no-check"], env=env, capture_output=True, text=True)
@@ -50,7 +52,14 @@ def run(configs):
 
 
 if __name__ == "__main__":
+    rest = []
+    for a in sys.argv[2:]:
+        name, eq, flags = a.partition("=")
+        if eq:
+            EXTRA[name] = [f for f in flags.split(",") if f]
+        else:
+            rest.append(a)
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
     else:
-        run(sys.argv[2:] or ["2507:256", "5000:128", "20000:8"])
+        run(rest or ["2507:256", "5000:128", "20000:8"])
