@@ -54,6 +54,9 @@ constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, 
 // first tile right behind this item's stores — 0.665 / 0.841 / 0.496 ms against 0.645 / 0.787 / 0.452 at 2507 x 256 / 5000 x 128 /
 // 20000 x 8 (tools/ablate_aggregate.py build+run P0= P1=-DGNNPN_TILED_PERSISTENT=1): the hardware's dispatch of 4096 workgroups
 // balances the CUs better than a static walk, and a workgroup launch costs less than the imbalance)
+#ifndef GNNPN_TILED_SHARED_PLAN
+#define GNNPN_TILED_SHARED_PLAN 0
+#endif
 #ifndef GNNPN_TILED_PERSISTENT
 #define GNNPN_TILED_PERSISTENT 0
 #endif
@@ -365,7 +368,11 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int lane_off = 16 * sub;
     const unsigned lane_boff = (unsigned)(sub * 512 + (lane >> 2) * 16);  // this lane's 16 bytes of quad `sub` of a unit, from the unit's first byte
     const char* stream_b = reinterpret_cast<const char*>(batches);
+#if GNNPN_TILED_SHARED_PLAN
+    const int64_t bd = d;                                                 // (experiment: every block walks block 0's plan — right only for identical blocks)
+#else
     const int64_t bd = (int64_t)b * g.ND + d;
+#endif
     if (tid < 16) tile[g.TR * 16 + tid] = 0.0f;                          // the all-zero row: no fill writes it
     // the headers {first quad, quads} of this wavefront's units in EVERY source tile, fetched once: entry e = t * PASSES + p
     // sits in lane e % 64 of register e / 64 and is read back into scalar registers where it is needed
