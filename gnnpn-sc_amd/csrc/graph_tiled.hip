@@ -296,6 +296,51 @@ __device__ __forceinline__ void tiled_unit(const char* __restrict__ bp, const ch
     }
 }
 
+#ifndef GNNPN_TILED_DEEP
+#define GNNPN_TILED_DEEP 0
+#endif
+// (experiment, GNNPN_TILED_DEEP=1) The same walk with EIGHT quads of look-ahead: (c0, w0) hold quads 0..3 and (c1, w1) quads 4..7
+// of the unit on entry (the second pair only if the unit has more than four), and of the next unit — nq_next quads at nb — on
+// exit; each pair is re-requested right after it has been copied out, so a unit's stream is on its way a whole unit earlier.
+__device__ __forceinline__ void load_pair(const char* __restrict__ at, unsigned lane_boff, uint4& c, uint4& w) {
+    c = *reinterpret_cast<const uint4*>(at + lane_boff);
+    w = *reinterpret_cast<const uint4*>(at + lane_boff + 256);
+}
+template <int NQ>
+__device__ __forceinline__ void consume_upto4(int nq, const char* __restrict__ tile_b, const int (&cc)[4], const float (&ww)[4], int lane_off,
+                                              f32x2& a01, f32x2& a23) {
+    if (nq >= 4) lds_agg_consume<4, true, 4>(tile_b, cc, ww, lane_off, a01, a23);
+    else if (nq == 3) lds_agg_consume<4, true, 3>(tile_b, cc, ww, lane_off, a01, a23);
+    else if (nq == 2) lds_agg_consume<4, true, 2>(tile_b, cc, ww, lane_off, a01, a23);
+    else lds_agg_consume<4, true, 1>(tile_b, cc, ww, lane_off, a01, a23);
+}
+__device__ __forceinline__ void tiled_unit_deep(const char* __restrict__ bp, const char* __restrict__ nb, int nq_next, unsigned lane_boff,
+                                                int nq, uint4& c0, uint4& w0, uint4& c1, uint4& w1, const char* __restrict__ tile_b,
+                                                int lane_off, f32x2& a01, f32x2& a23) {
+    for (;;) {
+        const bool more = nq > 8;                                         // this unit goes on after these eight quads
+        const char* nx = more ? bp + 4096 : nb;                           // where the following eight quads are
+        const int nq_nx = more ? nq - 8 : nq_next;
+        {
+            const int cc[4] = {(int)c0.x, (int)c0.y, (int)c0.z, (int)c0.w};
+            const float ww[4] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+            load_pair(nx, lane_boff, c0, w0);
+            consume_upto4<0>(nq, tile_b, cc, ww, lane_off, a01, a23);
+        }
+        if (nq > 4) {
+            const int cc[4] = {(int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
+            const float ww[4] = {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w)};
+            if (nq_nx > 4) load_pair(nx + 2048, lane_boff, c1, w1);
+            consume_upto4<1>(nq - 4, tile_b, cc, ww, lane_off, a01, a23);
+        } else if (nq_nx > 4) {
+            load_pair(nx + 2048, lane_boff, c1, w1);
+        }
+        if (!more) break;
+        nq -= 8;
+        bp += 4096;
+    }
+}
+
 // The unit of wavefront `wave` in pass p.  The units are sorted by descending work, so the passes deal them serpentine:
 // with every pass giving wave 0 the heaviest of its units, wave 0 would carry the difference between the first and the
 // last unit of the tile more than the last wave, and every source-tile switch (a workgroup barrier) waits for the slowest wave.
@@ -405,6 +450,9 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         a23[p] = f32x2{0.f, 0.f};
     }
     uint4 co, wv;                                                         // the pair of loads in flight (tiled_unit)
+#if GNNPN_TILED_DEEP
+    uint4 co1 = make_uint4(0, 0, 0, 0), wv1 = make_uint4(0, 0, 0, 0);     // ... and the second pair (tiled_unit_deep)
+#endif
 #if GNNPN_AGG_ABLATE & 16
     co = make_uint4(lane_off * 64u, lane_off * 128u, lane_off * 192u, lane_off * 256u);
     wv = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);
@@ -413,6 +461,9 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         const char* b0 = stream_b + (int64_t)first_of(0) * 512;
         co = *reinterpret_cast<const uint4*>(b0 + lane_boff);
         wv = *reinterpret_cast<const uint4*>(b0 + lane_boff + 256);
+#if GNNPN_TILED_DEEP
+        if (quads_of(0) > 4) load_pair(b0 + 2048, lane_boff, co1, wv1);
+#endif
     }
 #endif
     for (int t = 0; t < g.NT; ++t) {
@@ -428,6 +479,16 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
             // the unit after this one (the next pass, or the first pass of the next source tile; after the last: any valid address)
             const int e_next = e + 1 < g.NT * PASSES ? e + 1 : 0;
             const char* nb = stream_b + (int64_t)first_of(e_next) * 512;
+#if GNNPN_TILED_DEEP
+            const int nq_next = e + 1 < g.NT * PASSES ? quads_of(e_next) : 0;
+            if (nq > 0) {
+                tiled_unit_deep(stream_b + (int64_t)first_of(e) * 512, nb, nq_next, lane_boff, nq, co, wv, co1, wv1, tile_b, lane_off,
+                                a01[p], a23[p]);
+            } else {
+                load_pair(nb, lane_boff, co, wv);
+                if (nq_next > 4) load_pair(nb + 2048, lane_boff, co1, wv1);
+            }
+#else
             if (nq > 0) {
                 tiled_unit(stream_b + (int64_t)first_of(e) * 512, nb, lane_boff, nq, co, wv, tile_b, lane_off, a01[p], a23[p]);
             } else {                                  // no edges into this tile: the pair in flight was this unit's — replace it
@@ -436,6 +497,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
                 wv = *reinterpret_cast<const uint4*>(nb + lane_boff + 256);
 #endif
             }
+#endif
         }
     }
     // ---- epilogue: the trailing self loop of rows outside the last source tile, then what the gather form's epilogue does
