@@ -54,6 +54,9 @@ constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, 
 // first tile right behind this item's stores — 0.665 / 0.841 / 0.496 ms against 0.645 / 0.787 / 0.452 at 2507 x 256 / 5000 x 128 /
 // 20000 x 8 (tools/ablate_aggregate.py build+run P0= P1=-DGNNPN_TILED_PERSISTENT=1): the hardware's dispatch of 4096 workgroups
 // balances the CUs better than a static walk, and a workgroup launch costs less than the imbalance)
+#ifndef GNNPN_TILED_FILL_LATER
+#define GNNPN_TILED_FILL_LATER 5                        // rows in flight per lane when a later source tile is filled (the accumulators are live)
+#endif
 #ifndef GNNPN_TILED_SHARED_PLAN
 #define GNNPN_TILED_SHARED_PLAN 0
 #endif
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     for (int t = 0; t < g.NT; ++t) {
         if (t) {
             __syncthreads();                                              // every gather from the previous tile is done
-            fill_tile<5>(tile, x + (int64_t)(r0 + t * g.TR) * ldx + c, ldx, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
+            fill_tile<GNNPN_TILED_FILL_LATER>(tile, x + (int64_t)(r0 + t * g.TR) * ldx + c, ldx, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
         }
         __syncthreads();
 #pragma unroll
