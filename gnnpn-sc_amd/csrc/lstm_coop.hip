@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     // placement by claim (coop_common.h): one member per CU, a group's members on one XCD
     __shared__ int place[2];
     int group, member;
+    u64 p_entry = 0, p_placed = 0, p_weights = 0;          // diagnostic build: stamps of the launch's fixed part (prof[7..9] below)
+    if constexpr (DIAG) p_entry = phase_stamp();
     if (!coop_place<G>(err, gpx, place, group, member, seats, (ablate_arg & 0x1000) != 0, sticky)) return;   // surplus workgroup of the over-subscribed launch (bit 12: opts.paired_start)
+    if constexpr (DIAG) p_placed = phase_stamp();
     const int net = group / groups_per_net, gi = group % groups_per_net;
     if (net >= n_nets) return;                            // spare group: takes part in no exchange
     if (threadIdx.x == 0) abort_flag = 0;
@@ -165,6 +168,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
         }
     }
 
+    if constexpr (DIAG) {
+        asm volatile("" ::"v"(winv[0]), "v"(winv[1]), "v"(bh[0]), "v"(bh[1]));
+        p_weights = phase_stamp();
+    }
     const int n_tiles = (B + ROWS - 1) / ROWS;
     unsigned step = 0;                                     // running step counter: tag = step+1, parity = step&1
     bool first_tile = true;
@@ -342,6 +349,11 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                     prof[3] += s4 - s3;   // input projection + barrier
                     prof[4] += s5 - s4;   // cell update + publish
                     prof[5] += 1;
+                    if (t == 1 && first_tile) {           // the launch's fixed part, once: placement, weights into registers, the first step
+                        prof[7] = p_placed - p_entry;
+                        prof[8] = p_weights - p_placed;
+                        prof[9] = s0 - p_weights;         // (step 0 and what precedes step 1's first stamp)
+                    }
                 }
             }
         }

@@ -25,7 +25,9 @@ for prec in ("f32", "split"):
     ops.set_option("lstm_ablate", 32)
     ops.lstm_encode(nets, precision=prec); torch.cuda.synchronize()
     ws = ops.workspaces(dev).encode()
-    prof = ws[32:32 + 64].view(torch.int64).cpu().tolist()
+    prof = ws[32:32 + 80].view(torch.int64).cpu().tolist()
     ops.set_option("lstm_ablate", 0)
     n = max(prof[5], 1)
     print(prec, {k: round(prof[i] / n) for i, k in enumerate(names) if k}, "steps", n, "total", round(sum(prof[:5]) / n), flush=True)
+    print(prec, "fixed part of the launch (workgroup 0, cycles): placement", prof[7], "weights into registers", prof[8],
+          "first step (no stamps of its own)", prof[9], flush=True)
