@@ -705,14 +705,20 @@ def main():
                         st["work"][i].wait()
                         st["work"][i] = None
 
-    def timed_rounds(run_step):
+    def timed_rounds(run_step, runner=None):
         """The contract's timed region — barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks —
-        repeated until --min-time seconds have been measured (every rank sees the same maxima, so they stop together)."""
+        repeated until --min-time seconds have been measured (every rank sees the same maxima, so they stop together).
+        Between two rounds the runner is waited for through ITS synchronize() (besides the device-wide one), as a caller that
+        works in bursts of K steps would: the runner then starts the next burst's two slots together (pipeline.COMMON_START_US;
+        the hold is inside the timed region)."""
         rounds, total, i0, res = [], 0.0, args.warmup, None
         timed_rounds.local = []
 
         def one_round():
             nonlocal i0, res
+            rn = runner if runner is not None else cur["runner"]
+            if rn is not None:
+                rn.synchronize(check=False)
             torch.cuda.synchronize()
             gdist.barrier(world)
             torch.cuda.synchronize()
@@ -905,7 +911,7 @@ def main():
         gc.disable()
         for i in range(args.warmup):
             step(i, runner_s)
-        rounds_s, _ = timed_rounds(lambda i: step(i, runner_s))
+        rounds_s, _ = timed_rounds(lambda i: step(i, runner_s), runner_s)
         el_s, timing_s = summarise(rounds_s)
         bad_s = runner_s.poll()                    # the second line is not worth the first: a failed hand-off here is recorded, not fatal
         out_s = runner_s.graphs[0].outputs

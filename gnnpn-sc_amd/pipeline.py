@@ -89,6 +89,23 @@ class DeviceBatch:
 # round 4: DESIGN.md section 11.
 DEFAULT_WRITE_THROUGH = False
 HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
+COMMON_START_US = 150.0     # PipelinedRunner: how long the first replays of a burst are held so that both slots start together (0: off)
+_SPIN_CYCLES_PER_US = {}    # device index -> cycles of torch.cuda._sleep per microsecond (measured once)
+
+
+def _spin_cycles_per_us(device):
+    """torch.cuda._sleep counts device clock cycles; their rate is measured once per device (two timed spins of ~0.3 ms)."""
+    idx = torch.device(device).index or 0
+    if idx not in _SPIN_CYCLES_PER_US:
+        with torch.cuda.device(idx):
+            torch.cuda._sleep(100_000)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda._sleep(1_000_000)
+            e1.record()
+            e1.synchronize()
+            _SPIN_CYCLES_PER_US[idx] = 1_000_000 / max(e0.elapsed_time(e1) * 1e3, 1.0)
+    return _SPIN_CYCLES_PER_US[idx]
 
 
 def half_batch_split(n_problems):
@@ -291,6 +308,22 @@ class PipelinedRunner:
         self._slot_done = [None] * self.n_slots
         self._deferred = None                    # (slot, after): a leader whose replay waits for its partner's submission (submit)
         self._copy_streams = [torch.cuda.Stream() for _ in range(self.n_slots)]   # host-to-device transfers of pinned arenas (submit)
+        # Common start of a burst (two free-running slots only).  Two slots that begin a burst a host enqueue apart (~0.1 ms:
+        # the second replay is not in its queue yet when the first starts) run in step for a few steps and then slip apart ONCE
+        # — one slot's step takes 1.7 instead of 1.2 ms at the QWS shape — which costs a 20-step burst 0.5 ms (4 %); slots
+        # released TOGETHER stay in step (tools/probes/stagger_probe.py: 11.50 against 12.01 ms per 20 steps, the hold included;
+        # 30 and 60 us are too short, 90 and more work).  So the first replay after the runner has been idle is held behind a
+        # gate on a third stream that opens COMMON_START_US later, and so is the other slot's first one; later replays are not.
+        # "Idle" = since the last synchronize() / poll() of this runner: a caller that works in bursts waits for them that way.
+        self.common_start_us = float(os.environ.get("GNNPN_PIPE_COMMON_START_US", COMMON_START_US)) \
+            if (self.n_slots == 2 and self.n_streams == 2 and not self.lockstep) else 0.0
+        self._gate = None                        # [event, slots still to be held behind it]
+        self._drained = True                     # nothing in flight: set by synchronize / poll, cleared by the next replay
+        # (the gate's spin runs on slot 0's transfer stream, idle whenever the batches are resident: one more stream of its own
+        # changed which streams share a hardware queue and cost the pinned-host path 1.7 %)
+        self._gate_stream = self._copy_streams[0] if self.common_start_us > 0 else None
+        if self.common_start_us > 0:
+            _spin_cycles_per_us(torch.cuda.current_device())     # measured here, not inside somebody's timed region
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
@@ -400,6 +433,11 @@ class PipelinedRunner:
             return self._replay_pair(lead, after_lead, s, after), s
         if self._deferred is not None:
             self._flush_deferred()
+        if batch is not None and self.common_start_us > 0:
+            arena = getattr(batch, "_arena", None)
+            if (arena if arena is not None else batch.x).device.type == "cpu":
+                self._drained = False                # batches from host memory: no common start (their transfers share the copy
+                #                                      engine, slots in step wait for each other's: 436 against 442 k problems/s)
         return self._replay(s, after), s
 
     def _replay(self, s, after=None):
@@ -421,6 +459,8 @@ class PipelinedRunner:
                         st.wait_event(self._last_done[1 - s])
                     started = torch.cuda.Event()
                     started.record(st)
+            if self.common_start_us > 0:
+                self._hold_for_common_start(s, st)
             out = self.graphs[s]()
             done = torch.cuda.Event()
             done.record(st)
@@ -432,6 +472,26 @@ class PipelinedRunner:
             if after is not None:
                 after(out, s)
         return out
+
+    def _hold_for_common_start(self, s, st):
+        """First replay after an idle period: open a gate COMMON_START_US from now (a spin kernel on a third stream) and hold this
+        replay and the other slot's next one behind it (see __init__)."""
+        if self._gate is None and self._drained:
+            # the first replay after the pipeline was waited for (synchronize / poll, or the very first one): a burst begins.
+            # (Deliberately NOT "whenever the streams happen to be empty": a host-paced caller whose device catches up now and
+            # then would pay the hold every time — measured with the pinned-host batches of tools/bench_pcie.py: -2.7 %.)
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self._gate_stream):
+                torch.cuda._sleep(int(self.common_start_us * _spin_cycles_per_us(st.device)))
+                ev.record(self._gate_stream)
+            self._gate = [ev, set(range(self.n_slots))]
+        self._drained = False
+        if self._gate is not None:
+            if s in self._gate[1]:
+                st.wait_event(self._gate[0])
+                self._gate[1].discard(s)
+            if not self._gate[1] or s not in self._gate[1] and self._gate[0].query():
+                self._gate = None                    # both held, or the gate has opened long ago (a one-slot burst)
 
     def _replay_pair(self, lead, after_lead, s, after):
         """Leader and partner enqueued together: each replay behind BOTH transfers, the leader behind whatever the partner's slot
@@ -481,6 +541,7 @@ class PipelinedRunner:
         self._flush_deferred()
         for st in self.streams:
             st.synchronize()
+        self._drained = True
         word = 0
         for w in self.workspaces:
             word |= w.poll()
@@ -492,6 +553,7 @@ class PipelinedRunner:
         self._flush_deferred()
         for st in self.streams:
             st.synchronize()
+        self._drained = True
         if check:
             for w in self.workspaces:
                 w.check("PipelinedRunner")

@@ -1,5 +1,6 @@
 """-m gpu: the GNN mirror (Net) against the golden vectors of the reference's own Net glue, and the
 fused device pipeline (scores -> candidates -> two-level decode -> reward) against the oracle chain."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -251,6 +252,67 @@ def test_pipelined_runner_matches_single_stream(dev):
         assert torch.equal(ids, ref["candidate_ids"]) and torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
     with pytest.raises(ops.GnnpnError):
         runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
+
+
+def test_first_replays_of_a_burst_start_together(dev):
+    """Two free-running slots: the first replay after the runner was waited for (synchronize / poll, or the first ever) and the
+    other slot's first one are held behind ONE gate (pipeline.COMMON_START_US, a spin on slot 0's transfer stream) — the later
+    ones are not, batches from host memory are not, a runner without the option is not; the results are what a single stream
+    gives.  (What the common start is worth is a measurement: tools/probes/stagger_probe.py)"""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops, pipeline
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 48
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=40 + i, tasks_per_problem=10), dev) for i in range(3)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    assert runner.common_start_us == pipeline.COMMON_START_US and runner._drained and runner._gate is None
+
+    def burst(n, source):
+        starts, outs = [], []
+        for i in range(n):
+            s = runner.count % runner.n_slots
+            out, slot = runner.submit(source[i % len(source)])
+            assert slot == s
+            starts.append(runner._gate is not None)
+            with torch.cuda.stream(runner.stream(slot)):
+                outs.append((i % len(source), out["idx_high"].clone(), out["R"].clone()))
+        return starts, outs
+
+    starts, outs = burst(5, batches)
+    assert starts == [True, False, False, False, False]          # (the gate is pending after the first held replay, gone after the second)
+    assert not runner._drained
+    runner.synchronize()
+    assert runner._drained
+    starts2, outs2 = burst(4, batches)
+    assert starts2[0] and not any(starts2[1:])
+    runner.synchronize()
+    ops.check_status(dev)
+    for j, idx, R in outs + outs2:
+        ref = eager_reference(pipe, svc, batches[j], decode_impl=runner.decode_impl)
+        assert torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
+    # batches from pinned host memory: no hold (their transfers share the copy engine; slots in step wait for each other's)
+    host = [runner.pack_host(b) for b in batches[:2]]
+    runner.synchronize()
+    runner.submit(host[0])
+    assert runner._gate is None and not runner._drained
+    runner.submit(host[1])
+    runner.synchronize()
+    ops.check_status(dev)
+    # the option off
+    os.environ["GNNPN_PIPE_COMMON_START_US"] = "0"
+    try:
+        plain = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    finally:
+        del os.environ["GNNPN_PIPE_COMMON_START_US"]
+    assert plain.common_start_us == 0
+    plain.submit(batches[0])
+    assert plain._gate is None
+    plain.synchronize()
 
 
 @pytest.mark.parametrize("B,precision", [(88, "f32"), (88, "split"), (50, "split"), (33, "f32")])

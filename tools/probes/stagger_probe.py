@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="qws")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=30)
-ap.add_argument("--delays", default="0,150,300,450,600")
+ap.add_argument("--delays", default="0,-150,-250,150,600")
 ap.add_argument("--precision", default="split")
 a = ap.parse_args()
 w = dict(WORKLOADS[a.workload])
@@ -40,12 +40,24 @@ cyc_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
 print(f"{a.workload} B={B}: spin kernel {cyc_per_us:.1f} cycles/us", flush=True)
 
 
+gate_stream = torch.cuda.Stream()
+
+
 def one_round(delay_us):
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
-    for s in range(2):
-        runner.stream(s).wait_event(t0)
+    if delay_us < 0:                                   # negative: BOTH slots held behind one gate that opens |d| us after t0 — an exactly common start
+        gate = torch.cuda.Event()
+        with torch.cuda.stream(gate_stream):
+            gate_stream.wait_event(t0)
+            torch.cuda._sleep(int(-delay_us * cyc_per_us))
+            gate.record()
+        for s in range(2):
+            runner.stream(s).wait_event(gate)
+    else:
+        for s in range(2):
+            runner.stream(s).wait_event(t0)
     if delay_us > 0:
         with torch.cuda.stream(runner.stream(1)):
             torch.cuda._sleep(int(delay_us * cyc_per_us))

@@ -44,7 +44,7 @@ for r in range(a.rounds):
             e1.record()
         ev.append((s, e0, e1))
     runner.synchronize()
-    print(f"round {r}: " + "  ".join(f"slot{s} [{t0.elapsed_time(e0):7.1f} .. {t0.elapsed_time(e1):7.1f}]" for s, e0, e1 in ev), flush=True)
+    print(f"round {r}: " + "  ".join(f"slot{s} [{t0.elapsed_time(e0):8.3f} .. {t0.elapsed_time(e1):8.3f}]" for s, e0, e1 in ev), flush=True)
     # status area of each slot's LAST encoder / decoder launch: [status, workgroups on the same-XCD path, seats taken off the canonical CU, -]
     print("         " + "  ".join(f"ws{i}: enc {x.encode()[:16].view(torch.int32).tolist()} dec {x._decode[:16].view(torch.int32).tolist()}"
                                    for i, x in enumerate(runner.workspaces)), flush=True)
