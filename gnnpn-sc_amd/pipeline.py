@@ -316,7 +316,7 @@ class PipelinedRunner:
         # gate on a third stream that opens COMMON_START_US later, and so is the other slot's first one; later replays are not.
         # "Idle" = since the last synchronize() / poll() of this runner: a caller that works in bursts waits for them that way.
         self.common_start_us = float(os.environ.get("GNNPN_PIPE_COMMON_START_US", COMMON_START_US)) \
-            if (self.n_slots == 2 and self.n_streams == 2 and not self.lockstep) else 0.0
+            if (self.n_slots == 2 and self.n_streams == 2 and not self.lockstep and hasattr(torch.cuda, "_sleep")) else 0.0
         self._gate = None                        # [event, slots still to be held behind it]
         self._drained = True                     # nothing in flight: set by synchronize / poll, cleared by the next replay
         # (the gate's spin runs on slot 0's transfer stream, idle whenever the batches are resident: one more stream of its own
