@@ -6,14 +6,14 @@ stream; tensors cross the boundary as raw device pointers + sizes.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
 LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -81,6 +81,7 @@ _SIGNATURES = {
     "gnnpn_eswoa_wide_f64": (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "gnnpn_debug_cell_activations": (c_int, [_P, _P, _P, c_int64, _P]),
     "gnnpn_debug_lds_interferer": (c_int, [c_int32, c_int32, c_int32, _P]),
+    "gnnpn_gate_wait": (c_int, [_P, c_uint32, c_int32, _P]),
     "gnnpn_debug_mfma_f16": (c_int, [_P, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

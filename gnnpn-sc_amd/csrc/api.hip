@@ -83,3 +83,26 @@ extern "C" int gnnpn_debug_cell_activations(const float* x, float* sig, float* t
     GNNPN_CHECK_LAUNCH("debug_cell_activations");
     return GNNPN_OK;
 }
+
+// ---- a gate a stream waits behind until the HOST opens it ---------------------------------------------------------------
+// One wavefront polls a 32-bit word in pinned host memory (system-scope loads, a sleep between them) until it holds `expect`
+// or `timeout_us` have passed, and ends; what is enqueued behind it on the stream starts then.  PipelinedRunner holds the
+// first replays of a burst behind one such gate and opens it when both are in their queues (pipeline.py: the two slots then
+// start at the same moment, however long the host took to enqueue them — bounded by the time-out).
+namespace {
+__global__ void gate_wait_kernel(const unsigned* __restrict__ flag, unsigned expect, unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != expect &&
+           __builtin_amdgcn_s_memrealtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(20);
+}
+}  // namespace
+
+extern "C" int gnnpn_gate_wait(const void* flag, uint32_t expect, int32_t timeout_us, void* stream) {
+    GNNPN_REQUIRE(flag && timeout_us >= 0 && timeout_us <= 100000, "gate_wait: a flag in pinned host (or device) memory, a time-out of at most 0.1 s");
+    GNNPN_REQUIRE(gnnpn_aligned(flag, 4), "gate_wait: the flag must be 4-byte aligned");
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned*>(flag), expect,
+                       (unsigned long long)timeout_us * 100ull);
+    GNNPN_CHECK_LAUNCH("gate_wait");
+    return GNNPN_OK;
+}

@@ -10,13 +10,14 @@ the stages:
 Inputs are ``DeviceBatch``/``DeviceServices`` (packed once from the host structures of synth.py /
 loadData.py); outputs stay on the device.
 """
+import ctypes
 import os
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
-from . import custom_ops, graph, ops   # noqa: F401  (custom_ops registers torch.ops.gnnpn.*)
+from . import _lib, custom_ops, graph, ops   # noqa: F401  (custom_ops registers torch.ops.gnnpn.*)
 from .modelPN import two_level_greedy
 
 
@@ -89,23 +90,7 @@ class DeviceBatch:
 # round 4: DESIGN.md section 11.
 DEFAULT_WRITE_THROUGH = False
 HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
-COMMON_START_US = 150.0     # PipelinedRunner: how long the first replays of a burst are held so that both slots start together (0: off)
-_SPIN_CYCLES_PER_US = {}    # device index -> cycles of torch.cuda._sleep per microsecond (measured once)
-
-
-def _spin_cycles_per_us(device):
-    """torch.cuda._sleep counts device clock cycles; their rate is measured once per device (two timed spins of ~0.3 ms)."""
-    idx = torch.device(device).index or 0
-    if idx not in _SPIN_CYCLES_PER_US:
-        with torch.cuda.device(idx):
-            torch.cuda._sleep(100_000)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            torch.cuda._sleep(1_000_000)
-            e1.record()
-            e1.synchronize()
-            _SPIN_CYCLES_PER_US[idx] = 1_000_000 / max(e0.elapsed_time(e1) * 1e3, 1.0)
-    return _SPIN_CYCLES_PER_US[idx]
+COMMON_START_US = 400.0     # PipelinedRunner: the first replays of a burst are held until both are enqueued — at most this long (0: off)
 
 
 def half_batch_split(n_problems):
@@ -313,17 +298,19 @@ class PipelinedRunner:
         # — one slot's step takes 1.7 instead of 1.2 ms at the QWS shape — which costs a 20-step burst 0.5 ms (4 %); slots
         # released TOGETHER stay in step (tools/probes/stagger_probe.py: 11.50 against 12.01 ms per 20 steps, the hold included;
         # 30 and 60 us are too short, 90 and more work).  So the first replay after the runner has been idle is held behind a
-        # gate on a third stream that opens COMMON_START_US later, and so is the other slot's first one; later replays are not.
+        # gate on another stream, and so is the other slot's first one; later replays are not.  The gate (gnnpn_gate_wait: one
+        # wavefront polling a word in pinned host memory) is opened by the HOST the moment the second replay is in its queue —
+        # or by synchronize / poll, or after COMMON_START_US at the latest (a burst of one replay that is waited for some other way).
         # "Idle" = since the last synchronize() / poll() of this runner: a caller that works in bursts waits for them that way.
         self.common_start_us = float(os.environ.get("GNNPN_PIPE_COMMON_START_US", COMMON_START_US)) \
-            if (self.n_slots == 2 and self.n_streams == 2 and not self.lockstep and hasattr(torch.cuda, "_sleep")) else 0.0
+            if (self.n_slots == 2 and self.n_streams == 2 and not self.lockstep) else 0.0
         self._gate = None                        # [event, slots still to be held behind it]
+        self._gate_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if self.common_start_us > 0 else None   # the word the gate polls
+        self._gate_seq = 0                       # value that opens the current gate (one more per burst)
         self._drained = True                     # nothing in flight: set by synchronize / poll, cleared by the next replay
         # (the gate's spin runs on slot 0's transfer stream, idle whenever the batches are resident: one more stream of its own
         # changed which streams share a hardware queue and cost the pinned-host path 1.7 %)
         self._gate_stream = self._copy_streams[0] if self.common_start_us > 0 else None
-        if self.common_start_us > 0:
-            _spin_cycles_per_us(torch.cuda.current_device())     # measured here, not inside somebody's timed region
         # gnnpn_launch_opts_t.paired_start: half-batches (set inside ML2PNPipeline.run) and slots started in pairs begin together
         self.batches = [self._clone(example_batch) for _ in range(self.n_slots)]   # never alias caller tensors
         self.workspaces = [ops.new_workspaces(example_batch.x.device) for _ in range(2 if self.halves else self.n_slots)]
@@ -459,9 +446,10 @@ class PipelinedRunner:
                         st.wait_event(self._last_done[1 - s])
                     started = torch.cuda.Event()
                     started.record(st)
-            if self.common_start_us > 0:
-                self._hold_for_common_start(s, st)
+            last_held = self.common_start_us > 0 and self._hold_for_common_start(s, st)
             out = self.graphs[s]()
+            if last_held:
+                self._open_gate()                   # both held replays are in their queues: they start now, together
             done = torch.cuda.Event()
             done.record(st)
             self._slot_done[s] = done               # what the next transfer into this slot's static inputs waits for
@@ -474,24 +462,30 @@ class PipelinedRunner:
         return out
 
     def _hold_for_common_start(self, s, st):
-        """First replay after an idle period: open a gate COMMON_START_US from now (a spin kernel on a third stream) and hold this
-        replay and the other slot's next one behind it (see __init__)."""
+        """First replay after the runner was waited for: a gate (see __init__) in front of this replay and the other slot's next
+        one.  Returns True if this replay completes the pair — the caller opens the gate once the replay is enqueued."""
         if self._gate is None and self._drained:
-            # the first replay after the pipeline was waited for (synchronize / poll, or the very first one): a burst begins.
             # (Deliberately NOT "whenever the streams happen to be empty": a host-paced caller whose device catches up now and
             # then would pay the hold every time — measured with the pinned-host batches of tools/bench_pcie.py: -2.7 %.)
+            self._gate_seq = (self._gate_seq + 1) & 0x7fffffff
             ev = torch.cuda.Event()
             with torch.cuda.stream(self._gate_stream):
-                torch.cuda._sleep(int(self.common_start_us * _spin_cycles_per_us(st.device)))
+                _lib.check(_lib.load().gnnpn_gate_wait(ctypes.c_void_p(self._gate_flag.data_ptr()), self._gate_seq, int(self.common_start_us),
+                                                       _lib.stream_ptr()), "gnnpn_gate_wait")
                 ev.record(self._gate_stream)
             self._gate = [ev, set(range(self.n_slots))]
         self._drained = False
+        if self._gate is not None and s in self._gate[1]:
+            st.wait_event(self._gate[0])
+            self._gate[1].discard(s)
+            return not self._gate[1]
+        return False
+
+    def _open_gate(self):
+        """The host opens the pending gate (both replays are enqueued, or the caller is about to wait)."""
         if self._gate is not None:
-            if s in self._gate[1]:
-                st.wait_event(self._gate[0])
-                self._gate[1].discard(s)
-            if not self._gate[1] or s not in self._gate[1] and self._gate[0].query():
-                self._gate = None                    # both held, or the gate has opened long ago (a one-slot burst)
+            self._gate_flag[0] = self._gate_seq
+            self._gate = None
 
     def _replay_pair(self, lead, after_lead, s, after):
         """Leader and partner enqueued together: each replay behind BOTH transfers, the leader behind whatever the partner's slot
@@ -529,7 +523,7 @@ class PipelinedRunner:
         """The HIP stream slot ``slot``'s replays run on (half-batch mode: every slot's, there is one step in flight).  A leader
         that is waiting for its partner (``submit``) is enqueued first: work a caller puts on the stream comes behind the replay."""
         self._flush_deferred()
-        return self._stream(slot)
+        return self._stream(slot)                  # (a pending common-start gate stays: it opens with the partner's replay, or by its time-out)
 
     def reference_run(self, slot=0):
         """The same kernels on ONE stream, nothing overlapped (used to check an overlapped result)."""
@@ -539,6 +533,7 @@ class PipelinedRunner:
         """Wait for every slot's stream; the OR of the slots' sticky status words since the last poll / check, cleared — 0: no
         launch reported a failed hand-off.  The non-raising form of ``synchronize(check=True)``."""
         self._flush_deferred()
+        self._open_gate()
         for st in self.streams:
             st.synchronize()
         self._drained = True
@@ -551,6 +546,7 @@ class PipelinedRunner:
         """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a
         failed inter-workgroup hand-off (its outputs would be garbage) — the sticky status words of the slots."""
         self._flush_deferred()
+        self._open_gate()
         for st in self.streams:
             st.synchronize()
         self._drained = True

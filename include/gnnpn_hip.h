@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 5   /* 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 6   /* 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -545,6 +545,12 @@ int gnnpn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
 /* Test hook: the sigmoid / tanh the LSTM cells use (hardware exp2/rcp based, |error| ~1e-7),
  * evaluated on an array so that tests can measure them against the CPU's libm-grade functions. */
 int gnnpn_debug_cell_activations(const float* x, float* sig, float* th, int64_t n, void* stream);
+
+/* A gate for a stream that the HOST opens: one wavefront polls the 32-bit word `flag` (pinned host memory, or device memory) until
+ * it holds `expect` or `timeout_us` (<= 100000) have passed; work enqueued behind it on `stream` starts then.  No counterpart in
+ * the reference (its training loop runs one batch at a time, trainPNHigh.py:134-139): PipelinedRunner holds the first replays of a
+ * burst of two free-running slots behind one gate and opens it when both replays are enqueued, so that the slots start together. */
+int gnnpn_gate_wait(const void* flag, uint32_t expect, int32_t timeout_us, void* stream);
 
 /* Test hook: a stand-in for a collective's kernel beside the cooperative launches — n_workgroups workgroups of 256 threads hold
  * lds_bytes of LDS each for hold_us microseconds (sleeping spin, no memory traffic) on `stream`.  What an 8-rank RCCL ring kernel

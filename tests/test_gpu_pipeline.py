@@ -256,7 +256,8 @@ def test_pipelined_runner_matches_single_stream(dev):
 
 def test_first_replays_of_a_burst_start_together(dev):
     """Two free-running slots: the first replay after the runner was waited for (synchronize / poll, or the first ever) and the
-    other slot's first one are held behind ONE gate (pipeline.COMMON_START_US, a spin on slot 0's transfer stream) — the later
+    other slot's first one are held behind ONE gate (gnnpn_gate_wait on slot 0's transfer stream, opened by the host when the second
+    replay is enqueued, by synchronize / poll, or after pipeline.COMMON_START_US) — the later
     ones are not, batches from host memory are not, a runner without the option is not; the results are what a single stream
     gives.  (What the common start is worth is a measurement: tools/probes/stagger_probe.py)"""
     import gnnpn_sc_amd.synth as synth
