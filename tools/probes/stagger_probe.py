@@ -43,7 +43,7 @@ print(f"{a.workload} B={B}: spin kernel {cyc_per_us:.1f} cycles/us", flush=True)
 gate_stream = torch.cuda.Stream()
 
 
-def one_round(delay_us):
+def one_round(delay_us, extra_us=0):
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
@@ -61,6 +61,9 @@ def one_round(delay_us):
     if delay_us > 0:
         with torch.cuda.stream(runner.stream(1)):
             torch.cuda._sleep(int(delay_us * cyc_per_us))
+    if extra_us > 0:                                    # behind the common gate: slot 1 a little later than slot 0
+        with torch.cuda.stream(runner.stream(1)):
+            torch.cuda._sleep(int(extra_us * cyc_per_us))
     for _ in range(a.steps):
         runner.submit()
     cur = torch.cuda.current_stream()
@@ -71,10 +74,12 @@ def one_round(delay_us):
     return t0.elapsed_time(t1)
 
 
-for d in [int(x) for x in a.delays.split(",")] * 2:
-    one_round(d)
-    ms = [one_round(d) for _ in range(a.rounds)]
+for spec in a.delays.split(",") * 2:
+    d, _, x = spec.partition(":")                      # "d" or "d:x": x = extra microseconds for slot 1 behind a common gate (d < 0)
+    d, x = int(d), int(x or 0)
+    one_round(d, x)
+    ms = [one_round(d, x) for _ in range(a.rounds)]
     med = statistics.median(ms)
-    print(f"delay {d:4d} us: round median {med:.3f} ms  min {min(ms):.3f}  p90 {sorted(ms)[int(0.9 * len(ms))]:.3f}  -> "
-          f"{B * a.steps / med:.0f} k problems/s", flush=True)
+    print(f"delay {d:4d} us extra {x:3d}: round median {med:.3f} ms  min {min(ms):.3f}  p90 {sorted(ms)[int(0.9 * len(ms))]:.3f}  "
+          f"slow rounds (> 1.02 x median) {sum(1 for v in ms if v > 1.02 * med)} of {len(ms)}  -> {B * a.steps / med:.0f} k problems/s", flush=True)
 runner.synchronize(check=True)
