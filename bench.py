@@ -612,7 +612,7 @@ def main():
     if share:       # ranks sharing ONE GPU (launch-path rehearsal): a CU holds two cooperative workgroups in all, so every rank
         n_slots = 1  # runs one launch at a time — four launches of two processes would wait on each other past the spin bound
     with gpu_turn(share):
-        runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None,
+        runner = PipelinedRunner(pipe, svc, batch, slots=n_slots, halves=False if share else None, auto_degrade=False,   # the degraded form is this file's own (below)
                                  write_through=None if args.write_through < 0 else bool(args.write_through)) if args.graph else None
     if runner is not None:
         batches = [runner.pack(b) for b in batches]             # the slots' layout: one device-to-device copy per step instead of seven
@@ -713,12 +713,17 @@ def main():
         the hold is inside the timed region)."""
         rounds, total, i0, res = [], 0.0, args.warmup, None
         timed_rounds.local = []
+        timed_rounds.bad = 0              # OR of the status every round's poll returned (failure codes | shortfall of finished tiles)
+        timed_rounds.polls = 0
 
         def one_round():
             nonlocal i0, res
             rn = runner if runner is not None else cur["runner"]
             if rn is not None:
-                rn.synchronize(check=False)
+                # between two rounds (outside the timed region): wait for the runner AND check the previous round — failure
+                # codes and the proof of work (workgroup-tiles finished == expected == the host's own count, ops.Workspaces)
+                timed_rounds.bad |= rn.poll()
+                timed_rounds.polls += 1
             torch.cuda.synchronize()
             gdist.barrier(world)
             torch.cuda.synchronize()
@@ -785,7 +790,7 @@ def main():
         for d in (stages, gathers, last):
             d.clear()
         with gpu_turn(share):
-            cur["runner"] = PipelinedRunner(pipe, svc, batch, slots=1, halves=False, write_through=True)
+            cur["runner"] = PipelinedRunner(pipe, svc, batch, slots=1, halves=False, write_through=True, auto_degrade=False)
 
     force_fail = os.environ.get("GNNPN_BENCH_FORCE_DEGRADE")           # test hook: pretend the first status poll of that phase failed
     if force_fail and int(os.environ.get("GNNPN_BENCH_FORCE_DEGRADE_RANK", rank)) != rank:   # ... on that rank only
@@ -807,7 +812,7 @@ def main():
         timers.enabled = not args.graph
         rounds, (idx, R) = timed_rounds(step)
         timers.enabled = False
-        bad = cur["runner"].poll() if cur["runner"] is not None else 0
+        bad = (cur["runner"].poll() | timed_rounds.bad) if cur["runner"] is not None else 0
         if force_fail == "timed" and attempt == 0 and cur["runner"] is not None:
             bad |= 0x40
         if any_rank(bad):
@@ -826,6 +831,8 @@ def main():
     lr = sorted(timed_rounds.local)
     mine = {"rank": rank, "ms_per_step_local": round(lr[len(lr) // 2] / args.steps * 1e3, 4) if lr else None,
             "degraded": cur["degraded"], "placement_last_launch": [w.placement() for w in runner.workspaces] if runner is not None else None,
+            # proof of work at the last poll of the timed rounds (one poll per round; counters are cumulative since the last failure)
+            "progress": {"polls": getattr(timed_rounds, "polls", 0), "workspaces": runner.progress()} if runner is not None else None,
             "gpu": gpu_identity(0 if share else local_rank)}
     per_rank = [mine]
     if world > 1:

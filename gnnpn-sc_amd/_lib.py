@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
 LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -51,6 +51,7 @@ _SIGNATURES = {
     "gnnpn_set_option": (c_int, [c_char_p, c_int]),
     "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
     "gnnpn_coop_reset_staffing": (c_int, []),
+    "gnnpn_last_launch_units": (c_int64, []),
     "gnnpn_coop_staffing_count": (c_int, []),
     "gnnpn_bn_train_forward_f32": (c_int, [_P, c_int64, c_int32, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "gnnpn_bn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int, _P, _P, _P, _P]),

@@ -7,6 +7,12 @@
 
 thread_local char g_gnnpn_err[256] = "";
 
+// proof of work, host side: the workgroup-tiles the LAST recurrent entry point called on this thread booked as expected in the
+// caller's status block (0: it took a streaming form, or had no status block) — so that a caller's own count of the work it asked
+// for follows the launcher's choice of form instead of guessing it
+thread_local int64_t g_gnnpn_last_units = 0;
+extern "C" int64_t gnnpn_last_launch_units(void) { return g_gnnpn_last_units; }
+
 extern "C" int gnnpn_abi_version(void) { return GNNPN_ABI_VERSION; }
 extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 

@@ -203,17 +203,32 @@ namespace {   // one copy per translation unit
 // work on), not left dirty in the L2 of whichever XCD ran the block: the words of the status area are modified by device-scope
 // atomics of the next kernel, and a failure record of round 4 showed a launch that started on seat counters of 32 + 3 and 32 + 20
 // on two XCDs — the previous launch's totals, i.e. zeros that had not arrived.
-__global__ __launch_bounds__(256) void coop_zero_kernel(unsigned long long* __restrict__ p, size_t n8) {
+// The same kernel books the work the launch behind it is EXPECTED to do (`expected` workgroup-tiles, added to word `word` of the
+// caller's status block: gnnpn_launch_opts_t.sticky_status, GNNPN_STATUS_*): every seated workgroup of the cooperative kernel adds
+// the tiles it FINISHED to the word next to it when it leaves (coop_note_finished), and the host compares the two after a
+// synchronisation — a launch whose workgroups all left without working (stale seat counters: section "robustness" of DESIGN.md)
+// raises nothing and times nothing out, but it cannot make finished == expected.
+__global__ __launch_bounds__(256) void coop_zero_kernel(unsigned long long* __restrict__ p, size_t n8, unsigned* __restrict__ sticky,
+                                                        int word, unsigned expected, int skip_zeroing) {
+    if (sticky && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(sticky + word, expected);
+    if (skip_zeroing) return;                              // test hook (lstm_ablate bit 13): the workspace stays as the test prepared it
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x)
         __hip_atomic_store(p + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
-inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t s) {   // bytes: a multiple of 16
+// bytes: a multiple of 16.  sticky / word / expected: see coop_zero_kernel (sticky may be NULL: nothing is booked).
+inline hipError_t coop_zero_workspace(void* workspace, size_t bytes, hipStream_t s, unsigned* sticky, int word, unsigned expected,
+                                      bool skip_zeroing = false) {
     const size_t n8 = bytes / 8;
-    unsigned blocks = (unsigned)((n8 + 255) / 256);
+    unsigned blocks = skip_zeroing ? 1u : (unsigned)((n8 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(coop_zero_kernel, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long*>(workspace), n8);
+    hipLaunchKernelGGL(coop_zero_kernel, dim3(blocks), dim3(256), 0, s, static_cast<unsigned long long*>(workspace), n8, sticky, word,
+                       expected, skip_zeroing ? 1 : 0);
     return hipGetLastError();
+}
+// one thread of a seated workgroup, when it leaves the kernel: the tiles it took to the end (an aborted tile is not one)
+__device__ __forceinline__ void coop_note_finished(unsigned* sticky, int word, unsigned tiles_done) {
+    if (sticky && tiles_done) atomicAdd(sticky + word, tiles_done);
 }
 
 // Called by every thread of the workgroup.  false: surplus workgroup (leave at once).  `slot` is two ints of LDS.

@@ -182,11 +182,12 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
                                         float tanh_c, int use_tanh, int32_t B, int32_t T, int32_t n_per, int32_t H,
                                         int32_t precision, const gnnpn_launch_opts_t* opts_in, void* workspace,
                                         int64_t workspace_bytes, void* stream) {
+    g_gnnpn_last_units = 0;
     GNNPN_REQUIRE(B >= 0 && T > 0, "pointer_decode: bad shape");
     if (B == 0) return GNNPN_OK;                    // empty batch: its buffers may be NULL
     GNNPN_REQUIRE(nets && inputs, "pointer_decode: null input");
     const CoopOpts opts = coop_opts(opts_in);
-    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 4, "pointer_decode: opts.impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups), 3 (16-CU groups) or 4 (8-CU groups, 256-register build)");
+    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 4 && opts.impl != 3, "pointer_decode: opts.impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-CU groups) or 4 (8-CU groups, 256-register build) — the 16-CU-group form (3) was removed in ABI version 7");
     GNNPN_REQUIRE(opts.lds_kb >= 0 && opts.lds_kb <= 160, "pointer_decode: opts.lds_kb must be 0..160");
     GNNPN_REQUIRE(precision == GNNPN_PREC_F32 || precision == GNNPN_PREC_SPLIT, "pointer_decode: precision must be GNNPN_PREC_F32 or GNNPN_PREC_SPLIT, got %d", precision);
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_DECODE_NETS, "pointer_decode: n_nets must be 1..%d",
@@ -224,24 +225,14 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
     hipStream_t s = (hipStream_t)stream;
     bool any_sample = false;
     for (int n = 0; n < n_nets; ++n) any_sample |= nets[n].sample != 0;
-    if (any_sample && (precision != GNNPN_PREC_F32 || opts.impl >= 3))
+    if (any_sample && (precision != GNNPN_PREC_F32 || opts.impl > 2))
         GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: sampling is built in the streaming and the 8-CU-group fp32 forms (impl 0-2, "
                    "GNNPN_PREC_F32)");
-    const int impl = opts.impl;   // 0 auto, 1 streaming, 2 8-CU groups, 3 16-CU groups, 4 8-CU groups sized for 2 per CU
+    const int impl = opts.impl;   // 0 auto, 1 streaming, 2 8-CU groups, 4 8-CU groups sized for 2 per CU
     if (impl != 1 && gnnpn_decode_coop_supported(H, n_per) && (workspace != nullptr || impl >= 2)) {
-        // auto / 2: 8-member groups — fastest when the launch has the GPU to itself (0.32 ms at QWS B=256).
-        // 3: 16-member groups — 0.52 ms alone, but 256 registers, i.e. it shares every SIMD with a wave of the
-        // cooperative encoder of ANOTHER batch in flight on a second stream (bench.py turns it on when it
-        // pipelines two steps: 1.345 -> 1.313 ms/step).
-        int rc;
-        if (impl == 3) {
-            rc = gnnpn_launch_decode_coop2(args, n_nets, precision, opts, workspace, workspace_bytes, s);
-            if (rc == GNNPN_E_UNSUP) rc = gnnpn_launch_decode_coop(args, n_nets, precision, false, opts, workspace, workspace_bytes, s);
-        } else {
-            rc = gnnpn_launch_decode_coop(args, n_nets, precision, impl == 4, opts, workspace, workspace_bytes, s);
-            if (rc == GNNPN_E_UNSUP && impl == 4)   // K > 8: the 16-member form is the other build that shares a CU
-                rc = gnnpn_launch_decode_coop2(args, n_nets, precision, opts, workspace, workspace_bytes, s);
-        }
+        // auto / 2: fastest when the launch has the GPU to itself; 4: the 256-register build that shares every SIMD with a wave of
+        // ANOTHER cooperative launch in flight on a second stream (what PipelinedRunner selects)
+        const int rc = gnnpn_launch_decode_coop(args, n_nets, precision, impl == 4, opts, workspace, workspace_bytes, s);
         // auto mode: a device the cooperative forms are not built for (fewer than 8 XCDs x 32 CUs, a net the
         // cooperative sampling build does not cover) is served by the streaming form below instead of an error
         const bool fall_through = rc == GNNPN_E_UNSUP && impl == 0 && precision == GNNPN_PREC_F32;

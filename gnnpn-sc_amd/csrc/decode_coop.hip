@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
 
     const int n_tiles = (B + ROWS - 1) / ROWS;
     unsigned step = 0;   // publish counter: tag = step+1, parity = step&1
+    unsigned tiles_done = 0;   // proof of work (coop_note_finished)
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
         const int b0 = tile * ROWS;
         // cell state / output of the two rows this lane finishes: rows kq*4 + {0,1} (c < 8) or kq*4 + {2,3} (c >= 8)
@@ -524,8 +525,12 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
             if (tid == 0) decode_diag_record(group, member, tile, err, gpx);
             break;
         }
+        ++tiles_done;
     }
-    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u, seats);
+    if (tid == 0) {
+        if (abort_flag) coop_raise(err, sticky, 2u, seats);
+        coop_note_finished(sticky, GNNPN_STATUS_DEC_FINISHED, tiles_done);
+    }
 }
 
 extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, int32_t n_per) {
@@ -533,10 +538,8 @@ extern "C" int64_t gnnpn_pointer_decode_workspace_bytes(int32_t B, int32_t T, in
     const int64_t groups = 64, tiles = (B + ROWS - 1) / ROWS;
     const int64_t a8 = COOP_STATUS_BYTES + groups * 2 * ROWS * H * 8 + groups * 2 * G * ROWS * (int64_t)n_per * 8 +
                        tiles * T * ROWS * (int64_t)n_per * 8 + COOP_OVERREAD_BYTES;
-    const int64_t a16 = gnnpn_decode_coop2_workspace_bytes(B, T, n_per);
     const int64_t lean = gnnpn_decode_lean_workspace_bytes(B, T, n_per);
-    const int64_t m = a8 > a16 ? a8 : a16;
-    return m > lean ? m : lean;
+    return a8 > lean ? a8 : lean;
 }
 
 // device address of the failure record, for the kernels of other translation units (decode_lean.hip)
@@ -593,8 +596,10 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes + COOP_OVERREAD_BYTES;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
-    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
+    if (coop_zero_workspace(workspace, (size_t)need, s, opts.sticky, GNNPN_STATUS_DEC_EXPECTED, (unsigned)(G * n_nets * n_tiles),
+                            (gnnpn_option_lstm_ablate() & 0x2000) != 0) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
+    g_gnnpn_last_units = opts.sticky ? (int64_t)G * n_nets * n_tiles : 0;
     unsigned* p_seats = gnnpn_cu_seat_table();
     if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "%s: cannot allocate the seat table", "pointer_decode");
     char* base = static_cast<char*>(workspace);
@@ -602,7 +607,7 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800)) | (opts.write_through ? 128 : 0);
+    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000 | 0x2000)) | (opts.write_through ? 128 : 0);   // bit 13: the launch's zeroing (above)
     unsigned* p_s = opts.sticky;
     const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
     if (split && (!fold || (abl & 32)))

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
 
     const int n_tiles = (B + ROWS - 1) / ROWS;
     unsigned step = 0;   // publish counter: tag = step+1, parity = step&1
+    unsigned tiles_done = 0;   // proof of work (coop_note_finished)
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
         const int b0 = tile * ROWS;
         const int rows_here = min(ROWS, B - b0);
@@ -491,8 +492,12 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
             ++step;
         }
         if (abort_flag) break;
+        ++tiles_done;
     }
-    if (abort_flag && tid == 0) coop_raise(err, sticky, 2u, seats);
+    if (tid == 0) {
+        if (abort_flag) coop_raise(err, sticky, 2u, seats);
+        coop_note_finished(sticky, GNNPN_STATUS_DEC_FINISHED, tiles_done);
+    }
 }
 
 // pick_prob[b][t] = softmax of the step's window logits (+ the latent logits) at the pick = 1 / sum_j exp(v_j - v_pick):
@@ -571,8 +576,10 @@ int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, 
     const int64_t need = COOP_STATUS_BYTES + h_bytes + p_bytes + l_bytes + COOP_OVERREAD_BYTES;
     if (!workspace || workspace_bytes < need || !gnnpn_aligned(workspace, 256))
         GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: workspace of %lld B (256-B aligned) required", (long long)need);
-    if (coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
+    if (coop_zero_workspace(workspace, (size_t)need, s, opts.sticky, GNNPN_STATUS_DEC_EXPECTED, (unsigned)(G * n_nets * n_tiles),
+                            (gnnpn_option_lstm_ablate() & 0x2000) != 0) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: workspace memset failed");
+    g_gnnpn_last_units = opts.sticky ? (int64_t)G * n_nets * n_tiles : 0;
     unsigned* p_seats = gnnpn_cu_seat_table();
     if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "pointer_decode: cannot allocate the seat table");
     char* base = static_cast<char*>(workspace);

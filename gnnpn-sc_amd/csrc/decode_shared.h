@@ -44,9 +44,6 @@ struct DecodeArgs {
 bool gnnpn_decode_coop_supported(int32_t H, int32_t n_per);
 int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, const CoopOpts& opts,
                              void* workspace, int64_t workspace_bytes, hipStream_t s);
-int gnnpn_launch_decode_coop2(const DecodeArgs& args, int n_nets, int precision, const CoopOpts& opts, void* workspace,
-                              int64_t workspace_bytes, hipStream_t s);
-int64_t gnnpn_decode_coop2_workspace_bytes(int32_t B, int32_t T, int32_t n_per);
 // decode_lean.hip: the production build of the cooperative form (folded input side, greedy picks; fp32 and exact split)
 int gnnpn_launch_decode_lean(const DecodeArgs& args, int n_nets, int precision, bool shared_cu, const CoopOpts& opts,
                              void* workspace, int64_t workspace_bytes, hipStream_t s);

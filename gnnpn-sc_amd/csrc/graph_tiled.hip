@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void tile_plan_fill_kernel(
 // while the PREVIOUS unit was being consumed — and the first four quads of the next unit (nb) on exit: one pair of loads
 // is always in flight under the adds, across the units, passes and source tiles of a wavefront.  (Measured before this:
 // every unit began with a header load and a stream load whose L2 round trips nothing covered — 28 % of the kernel for
-// the stream loads alone, tools/ablate_aggregate.py.)  Quads beyond nq are loaded — the stream ends with three quads of
-// slack — and never used.
+// the stream loads alone, tools/ablate_aggregate.py.)  Quads beyond nq are loaded — the stream ends with FOUR quads of
+// slack (an empty last unit starts AT the stream's end and still requests four) — and never used.
 __device__ __forceinline__ void tiled_unit(const char* __restrict__ bp, const char* __restrict__ nb, unsigned lane_boff, int nq,
                                            uint4& co, uint4& wv, const char* __restrict__ tile_b, int lane_off, f32x2& a01,
                                            f32x2& a23) {

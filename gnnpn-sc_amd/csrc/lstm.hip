@@ -90,6 +90,7 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     GNNPN_REQUIRE(n_nets >= 1 && n_nets <= GNNPN_MAX_NETS, "lstm_encode: n_nets must be 1..%d", GNNPN_MAX_NETS);
     GNNPN_REQUIRE(in, "lstm_encode: null net array");
     GNNPN_REQUIRE(B >= 0 && L > 0, "lstm_encode: bad shape");
+    g_gnnpn_last_units = 0;
     if (B == 0) return GNNPN_OK;                    // empty batch: its buffers may be NULL
     GNNPN_REQUIRE(precision >= GNNPN_PREC_F32 && precision <= GNNPN_PREC_SPLIT, "lstm_encode: unknown precision %d", precision);
     if (H != 256 && H != 32) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: hidden size %d not built (256, 32)", H);
@@ -116,7 +117,7 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
     if (B == 0) return GNNPN_OK;
     hipStream_t s = (hipStream_t)stream;
     const CoopOpts opts = coop_opts(opts_in);
-    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 3, "lstm_encode: opts.impl must be 0 (auto), 1 (streaming), 2 (cooperative, 8-member groups) or 3 (cooperative, 16-member groups)");
+    GNNPN_REQUIRE(opts.impl >= 0 && opts.impl <= 2, "lstm_encode: opts.impl must be 0 (auto), 1 (streaming) or 2 (cooperative, 8-member groups) — the 16-member form (3) was removed in ABI version 7");
     GNNPN_REQUIRE(opts.lds_kb >= 0 && opts.lds_kb <= 160, "lstm_encode: opts.lds_kb must be 0..160");
     const int impl = opts.impl;
     const bool coop = H == 256 && impl != 1 && (workspace != nullptr || impl >= 2);

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     }
     const int n_tiles = (B + ROWS - 1) / ROWS;
     unsigned step = 0;                                     // running step counter: tag = step+1, parity = step&1
+    unsigned tiles_done = 0;                               // proof of work (coop_note_finished)
     bool first_tile = true;
     for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
         const int b0 = tile * ROWS;
@@ -374,185 +375,12 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             }
         }
         first_tile = false;
+        ++tiles_done;
     }
-    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u, seats);
-}
-
-// ---- 16-member form (opts.impl = 3): groups of 16 workgroups of 16 hidden units ------------------------------------
-// 64 weight registers per wave instead of 128 (162 registers in all: THREE workgroups fit a CU).  Per wave ONE 16-column
-// tile = 4 units x 4 gates (column c: gate c & 3, unit c >> 2), a single k-ordered chain of 64 MFMAs — the same chain per
-// column as the 8-member form, so results are bit-identical; the four gates of a (row, unit) sit in one quad of lanes and
-// are brought together by a 4x4 quad transpose (DPP quad_perm), after which lane (kq, c) finishes row 4kq + (c & 3) of
-// unit c >> 2.  fp32 operands, folded input side only.  Alone it is SLOWER than the 8-member form (a single dependent
-// chain issues a v_mfma_f32_16x16x4_f32 every 57 cycles, not 32: DESIGN.md section 11); it exists as the building block
-// of the next design step — more than two workgroups per CU — and is measured as such by tools/bench_encode_occupancy.py.
-namespace {
-constexpr int G16 = 16;
-constexpr int UNITS16 = H / G16;   // 16
-constexpr int GROUP_GRANULES16 = 2 * ROWS * H + 64;
-}  // namespace
-
-__device__ __forceinline__ float quad_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float quad_xor2(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
-}
-// lane l of a quad holds a[0..3]; afterwards out[j] = a_{lane j}[l]
-__device__ __forceinline__ void quad_transpose(const float (&a)[4], int l, float (&out)[4]) {
-    const bool lo = l & 1, hi = l & 2;
-    const float r0 = quad_xor1(lo ? a[0] : a[1]), r1 = quad_xor1(lo ? a[2] : a[3]);
-    const float p0 = lo ? r0 : a[0], p1 = lo ? a[1] : r0;      // row lo of lanes (l & ~1, l | 1)
-    const float q0 = lo ? r1 : a[2], q1 = lo ? a[3] : r1;      // row lo + 2
-    const float u0 = quad_xor2(hi ? p0 : q0), u1 = quad_xor2(hi ? p1 : q1);
-    out[0] = hi ? u0 : p0;
-    out[1] = hi ? u1 : p1;
-    out[2] = hi ? q0 : u0;
-    out[3] = hi ? q1 : u1;
-}
-// {tanh(x.x), sigmoid(x.y)}: the packed exp/reciprocal core of cell_act2, the tanh-only part on one component —
-// operation for operation the scalar cell_act
-__device__ __forceinline__ f32x2 cell_act_tanh_sigmoid(f32x2 x) {
-    const float ax = fminf(fabsf(x.x), 43.0f);
-    const f32x2 u = {__fmul_rn(2.0f, ax), fminf(fmaxf(-x.y, -87.0f), 87.0f)};
-    const f32x2 r = cell_rcp2v(pk_set(1.0f) + cell_exp2v(u));
-    const float big = __fsub_rn(1.0f, __fmul_rn(2.0f, r.x));
-    const float x2 = __fmul_rn(ax, ax);
-    float p = fmaf(x2, 2.18694885e-02f, -5.39682540e-02f);
-    p = fmaf(x2, p, 1.33333333e-01f);
-    p = fmaf(x2, p, -3.33333333e-01f);
-    const float small = fmaf(__fmul_rn(ax, x2), p, ax);
-    return f32x2{copysignf(ax < 0.25f ? small : big, x.x), r.y};
-}
-// one k-ordered fp32 MFMA chain over K = 256 against the k-quarter-major h tile (A-fragments prefetched CH k-steps ahead,
-// as mfma_chain_pair)
-template <int LD, int CH = 16>
-__device__ __forceinline__ void mfma_chain_single(const float* src, int c, int kq, const float (&w)[64], f32x4& acc) {
-    const float4* base4 = reinterpret_cast<const float4*>(src + c * LD + kq * 64);
-    float a[2][CH];
-    auto fetch = [&](int ch, float (&dst)[CH]) {
-#pragma unroll
-        for (int q = 0; q < CH / 4; ++q) {
-            const float4 v = base4[(CH / 4) * ch + q];
-            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
-        }
-    };
-    fetch(0, a[0]);
-#pragma unroll
-    for (int ch = 0; ch < 64 / CH; ++ch) {
-        if (ch < 64 / CH - 1) fetch(ch + 1, a[(ch + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ch & 1][i], w[CH * ch + i], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) {
+        if (abort_flag) coop_raise(err, sticky, 1u, seats);
+        coop_note_finished(sticky, GNNPN_STATUS_ENC_FINISHED, tiles_done);
     }
-}
-
-__global__ __launch_bounds__(256, 3) void lstm_encode_coop16_kernel(LstmNets nets, u64* __restrict__ xchg,
-                                                                    unsigned* __restrict__ err, unsigned* __restrict__ sticky,
-                                                                    int32_t B, int32_t L, int n_nets, int groups_per_net,
-                                                                    int gpx, int write_through, unsigned* __restrict__ seats) {
-    __shared__ __attribute__((aligned(16))) float hs[ROWS * LDT];      // k-quarter-major (coop_common.h)
-    __shared__ __attribute__((aligned(16))) float hst[ROWS][UNITS16];   // own h slice, staged for 64-B row stores
-    __shared__ int abort_flag;
-    __shared__ int place[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kq = lane >> 4, c = lane & 15;
-    int group, member;
-    if (!coop_place<G16>(err, gpx, place, group, member, seats, false, sticky)) return;
-    const int net = group / groups_per_net, gi = group % groups_per_net;
-    if (net >= n_nets) return;
-    if (threadIdx.x == 0) abort_flag = 0;
-    __syncthreads();
-    const bool same_xcd = !write_through;
-    if (threadIdx.x == 0 && same_xcd) atomicAdd(err + 1, 1u);
-
-    const float* __restrict__ xin = nets.inputs[net];
-    const float* __restrict__ Wp = nets.whh[net];
-    float* __restrict__ enc = nets.enc_out[net];
-    u64* xg = xchg + (size_t)group * GROUP_GRANULES16;
-
-    const int gate = c & 3, ul = wave * 4 + (c >> 2), unit = member * UNITS16 + ul;
-    const int wrow = gate * H + unit;
-    float wB[64];
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) wB[kk] = Wp[((size_t)(kk * 4 + gate) * H + unit) * 4 + kq];
-    const float bh = nets.bhh[net][wrow], bx = nets.b_in[net][wrow];
-    const float wX0 = nets.w_in[net][wrow * 8 + kq], wX1 = nets.w_in[net][wrow * 8 + 4 + kq];
-
-    const int n_tiles = (B + ROWS - 1) / ROWS;
-    const int my_row = kq * 4 + gate;                      // the row this lane finishes (of unit `unit`)
-    unsigned step = 0;
-    bool first_tile = true;
-    for (int tile = gi; tile < n_tiles; tile += groups_per_net) {
-        const int b0 = tile * ROWS;
-        float cst = 0.0f, hlast = 0.0f;
-        float ax[2] = {0.f, 0.f}, ax_next[2] = {0.f, 0.f};
-        auto load_input = [&](int t, float (&axv)[2]) {
-            if (b0 + c < B) {
-                const float* row = xin + ((int64_t)(b0 + c) * L + t) * 8;
-                axv[0] = row[kq];
-                axv[1] = row[4 + kq];
-            }
-        };
-        load_input(0, ax_next);
-        for (int t = 0; t < L; ++t, ++step) {
-            ax[0] = ax_next[0];
-            ax[1] = ax_next[1];
-            f32x4 px = {0.f, 0.f, 0.f, 0.f};
-            px = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0], wX0, px, 0, 0, 0);
-            px = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1], wX1, px, 0, 0, 0);
-            bool ok = true;
-            if (t == 0) {
-                for (int i = threadIdx.x; i < ROWS * LDT; i += 256) hs[i] = 0.0f;
-                if (!first_tile) ok = sweep_quarter<0>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, false);
-            } else {
-                ok = sweep_quarter<0>(xg + ((step - 1) & 1) * (ROWS * H), step, hs, wave, lane, true);
-            }
-            if (!ok) abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0) mfma_chain_single<LDT, 8>(hs, c, kq, wB, acc);
-            if (t + 1 < L) load_input(t + 1, ax_next);
-            if (t > 0 && threadIdx.x < ROWS * 4) {       // enc_out of the previous step: 64 B per problem row
-                const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-                if (b0 + row < B)
-                    *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (t - 1)) * H + member * UNITS16 + 4 * q) =
-                        *reinterpret_cast<const float4*>(&hst[row][4 * q]);
-            }
-            __syncthreads();   // everyone is done reading hs before the next step's sweep rewrites it
-
-            // gate sums of this lane's column for its four rows, then the quad transpose: all four gates of one row
-            float gs[4], gt[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gs[r] = __fadd_rn(__fadd_rn(acc[r], bh), __fadd_rn(px[r], bx));
-            quad_transpose(gs, gate, gt);                  // gt = (i, f, g, o) of row my_row
-            const f32x2 sif = cell_act2(f32x2{gt[0], gt[1]}, false);
-            const f32x2 sgo = cell_act_tanh_sigmoid(f32x2{gt[2], gt[3]});
-            cst = __fadd_rn(__fmul_rn(sif.y, cst), __fmul_rn(sif.x, sgo.x));
-            hlast = __fmul_rn(sgo.y, cell_act(cst, true));
-
-            u64* dst = xg + (step & 1) * (ROWS * H) + my_row * H + unit;
-            if (same_xcd) granule_store_l2(dst, step + 1, hlast);
-            else granule_store(dst, step + 1, hlast);
-            hst[my_row][ul] = hlast;
-        }
-        if (abort_flag) break;
-        __syncthreads();
-        if (threadIdx.x < ROWS * 4) {
-            const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-            if (b0 + row < B)
-                *reinterpret_cast<float4*>(enc + ((int64_t)(b0 + row) * L + (L - 1)) * H + member * UNITS16 + 4 * q) =
-                    *reinterpret_cast<const float4*>(&hst[row][4 * q]);
-        }
-        if (b0 + my_row < B) {
-            nets.h_n[net][(int64_t)(b0 + my_row) * H + unit] = hlast;
-            nets.c_n[net][(int64_t)(b0 + my_row) * H + unit] = cst;
-        }
-        first_tile = false;
-    }
-    if (abort_flag && threadIdx.x == 0) coop_raise(err, sticky, 1u, seats);
 }
 
 
@@ -570,30 +398,6 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: cannot query the device");
     const int n_tiles = (B + ROWS - 1) / ROWS;
-    if (opts.impl == 3) {   // 16-member groups (one workgroup per CU from this launch; three such launches fit a CU)
-        if (precision != 0 || (gnnpn_option_lstm_ablate() & ~(128 | 64 | 0x800)) != 0)
-            GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the 16-member form is built for fp32 operands, no diagnostics");
-        for (int n = 0; n < n_nets; ++n)
-            if (nets.pregates[n] != nullptr) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: the 16-member form is built for the folded input side");
-        int gpx16 = n_cu / (8 * G16);
-        if (gpx16 > 8) gpx16 = 8;
-        while (gpx16 > 1 && (gpx16 - 1) * 8 >= n_nets * n_tiles) --gpx16;
-        if (gpx16 < 1 || n_cu < 256) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: device has %d CUs, the 16-member form is built for 8 XCDs x 32 CUs", n_cu);
-        const int groups16 = gpx16 * 8;
-        if (groups16 < n_nets) GNNPN_FAIL(GNNPN_E_UNSUP, "lstm_encode: %d groups for %d nets", groups16, n_nets);
-        const int64_t need16 = COOP_STATUS_BYTES + (int64_t)groups16 * GROUP_GRANULES16 * sizeof(u64);
-        if (!workspace || workspace_bytes < need16 || !gnnpn_aligned(workspace, 256))
-            GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need16);
-        if (coop_zero_workspace(workspace, (size_t)need16, s) != hipSuccess)
-            GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
-        unsigned* seats16 = gnnpn_cu_seat_table();
-        if (!seats16) GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: cannot allocate the seat table");
-        hipLaunchKernelGGL(lstm_encode_coop16_kernel, dim3(COOP_OVERSUB * groups16 * G16), dim3(256), 0, s, nets,
-                           reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES),
-                           reinterpret_cast<unsigned*>(workspace), opts.sticky, B, L, n_nets, groups16 / n_nets, gpx16,
-                           opts.write_through ? 1 : 0, seats16);
-        return GNNPN_OK;
-    }
     // groups per XCD: every workgroup must be resident at once (one per CU), grid = 8 * G * gpx
     int gpx = n_cu / (8 * G);
     if (gpx > 8) gpx = 8;
@@ -609,8 +413,10 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: workspace of %lld B (256-B aligned) required", (long long)need);
     // zero the status word and every tag before each launch (tags start at 1).  Test hook (lstm_ablate bit 13, tests only): leave
     // the workspace as the previous launch left it — every workgroup must then notice (status code 8) instead of running on it
-    if (!(gnnpn_option_lstm_ablate() & 0x2000) && coop_zero_workspace(workspace, (size_t)need, s) != hipSuccess)
+    if (coop_zero_workspace(workspace, (size_t)need, s, opts.sticky, GNNPN_STATUS_ENC_EXPECTED, (unsigned)(G * n_nets * n_tiles),
+                            (gnnpn_option_lstm_ablate() & 0x2000) != 0) != hipSuccess)
         GNNPN_FAIL(GNNPN_E_LAUNCH, "lstm_encode: workspace memset failed");
+    g_gnnpn_last_units = opts.sticky ? (int64_t)G * n_nets * n_tiles : 0;
     unsigned* p_seats = gnnpn_cu_seat_table();
     if (!p_seats) GNNPN_FAIL(GNNPN_E_LAUNCH, "%s: cannot allocate the seat table", "lstm_encode");
     u64* p_x = reinterpret_cast<u64*>(static_cast<char*>(workspace) + COOP_STATUS_BYTES);

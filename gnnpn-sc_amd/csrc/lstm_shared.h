@@ -39,4 +39,5 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
                              void* workspace, int64_t workspace_bytes, hipStream_t s);
 constexpr int COOP_SEAT_TABLE_WORDS = 8 * 256 + 8 + 8;   // CU seats, per-XCD hand-out counters, [8*256+8] = launches staffing right now
 unsigned* gnnpn_cu_seat_table();   // api.hip: the device's canonical CU -> seat table (nullptr: allocation failed)
+extern thread_local int64_t g_gnnpn_last_units;   // api.hip: gnnpn_last_launch_units
 int gnnpn_option_lstm_ablate();   // timing experiments only: results are wrong when non-zero

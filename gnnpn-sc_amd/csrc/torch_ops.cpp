@@ -265,6 +265,8 @@ bool coop_supported(int64_t H, int64_t n_per, int64_t impl) { return H == 256 &&
 gnnpn_launch_opts_t launch_opts(int64_t impl, int64_t lds_kb, bool write_through, bool paired_start, const OptTensor& status) {
     gnnpn_launch_opts_t o{};
     o.impl = (int32_t)impl, o.lds_kb = (int32_t)lds_kb, o.write_through = write_through ? 1 : 0, o.paired_start = paired_start ? 1 : 0;
+    TORCH_CHECK(!(status.has_value() && status->defined()) || status->numel() >= GNNPN_STATUS_WORDS,
+                "status: a block of ", GNNPN_STATUS_WORDS, " int32 words (ops.Workspaces.status)");
     o.sticky_status = (status.has_value() && status->defined())
                           ? const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(cptr<int32_t>(*status, at::kInt, "status")))
                           : nullptr;

@@ -82,6 +82,8 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
     wsp = _coop_ws(first.device, nets[0]["bhh"].numel() // 4, 1, impl, ws)
     out = torch.ops.gnnpn.lstm_encode(flat, len(nets), precision, impl, lds_kb, bool(write_through),
                                       None if wsp is None else wsp.encode(), None if wsp is None else wsp.status, bool(paired_start))
+    if wsp is not None:
+        wsp.note_launch(0, _lib.load().gnnpn_last_launch_units())     # the host's count of the work the launcher asked for
     n = len(nets)
     return out[:n], out[n:2 * n], out[2 * n:]
 
@@ -99,6 +101,8 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
                                          precision, impl, lds_kb, bool(write_through),
                                          None if wsp is None else wsp.decode(B, n_cat, n_per), None if wsp is None else wsp.status,
                                          seeds, bool(paired_start))
+    if wsp is not None:
+        wsp.note_launch(1, _lib.load().gnnpn_last_launch_units())
     m = len(DECODE_OUTS)
     res = []
     for i in range(len(nets)):

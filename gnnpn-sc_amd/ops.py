@@ -117,7 +117,7 @@ class TilePlan:
                       "mean_run": (sum(i * h for i, h in enumerate(hist)) / max(1, sum(hist)))}
         if m[0] != 0:
             return
-        self.batches = torch.zeros((m[1] + 3) * 512, dtype=U8, device=dev)      # + three quads of slack for the fixed-shape loads
+        self.batches = torch.zeros((m[1] + 4) * 512, dtype=U8, device=dev)      # + FOUR quads of slack: every unit's first four quads are requested, also an empty last unit's (first == quads)
         check(lib.gnnpn_csr_tile_plan_fill(dev_ptr(col, I32, "col"), dev_ptr(w, F32, "w", True), n, int(block_rows),
                                            dev_ptr(self.header, I32, "header"), dev_ptr(self.order, I32, "order"),
                                            dev_ptr(tstart, I32, "tstart"), dev_ptr(self.batches, U8, "batches"), m[1], stream_ptr()),
@@ -403,14 +403,25 @@ class Workspaces:
     buffers: each gets its own ``Workspaces`` (``PipelinedRunner`` owns one per slot).  A buffer is never freed or
     replaced once handed out — a captured HIP graph may have baked its address in — so growing keeps the old tensor
     alive; while ``frozen`` (set by whoever captured a graph over it) growing raises instead.
-    ``status`` is gnnpn_launch_opts_t.sticky_status: every cooperative launch ORs its failure code (a bounded
-    inter-workgroup wait timed out: outputs invalid) into it and nothing but ``check()`` clears it, so one host read
-    covers every launch since the last check."""
+    ``status`` is gnnpn_launch_opts_t.sticky_status (include/gnnpn_hip.h, GNNPN_STATUS_*): word 0 — every cooperative launch ORs
+    its failure code (a bounded inter-workgroup wait timed out: outputs invalid) into it and nothing but ``check()`` / ``poll()``
+    clears it, so one host read covers every launch since the last check; words 4..7 — the proof of work: workgroup-tiles the
+    launches were expected to finish and workgroup-tiles their workgroups did finish (encoder, decoder), which must be equal after
+    a synchronisation.  ``launched`` is the HOST's own count of the same quantity (what the wrappers and the graph replays of this
+    process asked for): ``check`` / ``poll`` compare all three and report a difference as code 16 (GNNPN_COOP_SHORTFALL) — a
+    launch that did nothing raises no code by itself."""
+
+    WORDS = 8                             # GNNPN_STATUS_WORDS
+    SHORTFALL = 16                        # GNNPN_COOP_SHORTFALL
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.id = -1                      # index in the process-wide registry (custom_ops pass it as an int)
-        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(self.WORDS, dtype=torch.int32, device=self.device)
+        self.launched = [0, 0]            # workgroup-tiles asked of the encoder / decoder launches on this object (host count)
+        self._captured = [0, 0]           # ... of the launches recorded into a HIP graph that nobody has claimed yet (take_captured)
+        self._untracked = False           # a captured graph replays these launches without telling: the host count is unknown
+        self.last_progress = None         # the counters the last poll / check read (diagnosis; bench.py's per_rank)
         self._encode = None
         self._decode = None
         self._retired = []
@@ -434,15 +445,53 @@ class Workspaces:
             ws = self._decode = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return ws
 
-    def poll(self):
-        """Synchronise the device, return the sticky status word and clear it (0: every launch since the last poll / check was
-        fine) — the non-raising form of ``check`` for callers that have a degraded mode to fall back to (bench.py at N > 1)."""
+    @staticmethod
+    def coop_units(n_nets, n_problems):
+        """Workgroup-tiles of one cooperative launch: 8 members x nets x tiles of 16 problems (what the launch books as expected)."""
+        return 8 * int(n_nets) * ((int(n_problems) + 15) // 16)
+
+    def note_launch(self, which, units):
+        """Host-side bookkeeping of one cooperative launch (``which``: 0 encoder, 1 decoder) — called by the wrappers that make
+        the launch and, per replay, by whoever captured them into a HIP graph."""
+        if torch.cuda.is_current_stream_capturing():
+            # recorded, not run: whoever captures claims the tally (take_captured) and books it per replay (graph_replay);
+            # until then the replays are invisible to the host count, which _read then leaves out of the comparison
+            self._captured[which] += int(units)
+            self._untracked = True
+            return
+        self.launched[which] = (self.launched[which] + int(units)) & 0xFFFFFFFF
+
+    def take_captured(self):
+        """[encoder, decoder] workgroup-tiles of the launches recorded on this object since the last call — what ONE replay of
+        the graph just captured will ask for (ops.graph_replay books it per replay)."""
+        out, self._captured, self._untracked = self._captured, [0, 0], False
+        return out
+
+    def _read(self):
+        """Synchronise, read the status block once.  -> (code incl. SHORTFALL, progress dict)"""
         torch.cuda.synchronize(self.device)
-        word = int(self.status[0].item())
+        w = [v & 0xFFFFFFFF for v in self.status.tolist()]
+        prog = {"encoder": {"expected": w[4], "finished": w[5], "host_expected": self.launched[0]},
+                "decoder": {"expected": w[6], "finished": w[7], "host_expected": self.launched[1]}}
+        word = w[0]
+        if any(p["finished"] != p["expected"] or (not self._untracked and p["expected"] != p["host_expected"]) for p in prog.values()):
+            word |= self.SHORTFALL
+        self.last_progress = prog
+        return word, prog
+
+    def _clear(self):
+        self.status.zero_()
+        self.launched = [0, 0]
+        with torch.cuda.device(self.device):
+            return _lib.load().gnnpn_coop_reset_staffing()
+
+    def poll(self):
+        """Synchronise the device, return the status code and clear it (0: every launch since the last poll / check raised
+        nothing AND finished every workgroup-tile it was expected to) — the non-raising form of ``check`` for callers that have a
+        degraded mode to fall back to (PipelinedRunner, bench.py)."""
+        word, _ = self._read()
         if word != 0:
-            self.status.zero_()
-            with torch.cuda.device(self.device):
-                _lib.load().gnnpn_coop_reset_staffing()
+            self._clear()
         return word
 
     def placement(self):
@@ -457,14 +506,11 @@ class Workspaces:
 
     def check(self, what="cooperative kernel"):
         """Synchronise the device and raise if any launch since the last check reported a failed hand-off."""
-        torch.cuda.synchronize(self.device)
-        word = int(self.status[0].item())
+        word, prog = self._read()
         if word != 0:
-            self.status.zero_()
             # a launch that timed out leaves the count of staffing launches by itself (coop_raise); this reset is the belt to
             # those braces — on THIS object's device, and a failure of the reset is reported with the status it hides behind
-            with torch.cuda.device(self.device):
-                rc = _lib.load().gnnpn_coop_reset_staffing()
+            rc = self._clear()
             if rc != 0:
                 what = f"{what} (and gnnpn_coop_reset_staffing failed: {_lib.load().gnnpn_last_error().decode('utf-8', 'replace')})"
             last = [int(b[:4].view(torch.int32).item()) if b is not None else None for b in (self._encode, self._decode)]
@@ -472,10 +518,24 @@ class Workspaces:
             if word & 2:
                 rec = decode_failure_record()
                 detail = f"; decoder failure record: {rec['failures']} sweeps, first: {rec['records'][:4]}"
-            raise GnnpnError(f"{what}: status {word:#x} — an inter-workgroup hand-off timed out in at least one launch "
-                             f"since the last check (its outputs are invalid); bits: 1 encoder sweep, 2 decoder sweep, 4 a "
-                             f"group member never showed up, 8 the workspace was not clean when a launch began; last launches' own words "
-                             f"(encoder, decoder) = {last}{detail}")
+            raise GnnpnError(f"{what}: status {word:#x} — at least one cooperative launch since the last check failed (its outputs "
+                             f"are invalid); bits: 1 encoder sweep timed out, 2 decoder sweep timed out, 4 a group member never "
+                             f"showed up, 8 the workspace was not clean when a launch began, 16 workgroup-tiles finished != expected "
+                             f"(a launch did not do its work): {prog}; last launches' own words (encoder, decoder) = {last}{detail}")
+
+
+def graph_replay(graph, all_ws):
+    """Call right after capturing ``graph`` (torch.cuda.CUDAGraph) over launches on the ``Workspaces`` in ``all_ws``: returns
+    ``replay()`` = ``graph.replay()`` + the host-side booking of the cooperative launches one replay makes (proof of work:
+    ``Workspaces.launched`` against the device's expected / finished counters)."""
+    per = [(w, w.take_captured()) for w in all_ws]
+
+    def replay():
+        graph.replay()
+        for w, (enc, dec) in per:
+            w.note_launch(0, enc)
+            w.note_launch(1, dec)
+    return replay
 
 
 def decode_failure_record(clear=True):
@@ -622,6 +682,8 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
     check(_lib.load().gnnpn_lstm_encode_f32(n, arr, B, L, H, 8, _PRECISIONS[precision], _lib.ctypes.byref(opts),
                                             dev_ptr(buf, torch.uint8, "workspace", True),
                                             0 if buf is None else buf.numel(), stream_ptr()), "gnnpn_lstm_encode_f32")
+    if coop:
+        wsp.note_launch(0, _lib.load().gnnpn_last_launch_units())
     return enc, h_n, c_n
 
 
@@ -690,6 +752,8 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         _PRECISIONS["split"] if precision == "split" else 0, _lib.ctypes.byref(opts),
         dev_ptr(buf, torch.uint8, "workspace", True), 0 if buf is None else buf.numel(), stream_ptr()),
         "gnnpn_pointer_decode_f32")
+    if coop:
+        wsp.note_launch(1, _lib.load().gnnpn_last_launch_units())
     return outs
 
 

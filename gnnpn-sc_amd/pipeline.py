@@ -86,9 +86,12 @@ class DeviceBatch:
 
 # Hand-off form of the cooperative kernels in the runner's launches (gnnpn_launch_opts_t.write_through): False = granule stores
 # that stay in the group's XCD L2 (faster; correct by this toolchain's lowering and by the run-time XCD placement of a group),
-# True = agent-scope write-through stores (valid by the HIP memory model, placement independent).  Settled by measurement in
-# round 4: DESIGN.md section 11.
-DEFAULT_WRITE_THROUGH = False
+# True = agent-scope write-through stores (valid by the HIP memory model, placement independent).  What can go wrong with the
+# fast form is liveness, not data: a granule is ONE 8-byte store carrying its own tag, so a reader sees an old granule or a new
+# one, never a mixture — a store that does not become visible ends in a bounded-spin time-out (status 1 / 2), and a launch that
+# did not run at all in a shortfall of finished workgroup-tiles (status 16): both are loud at the next poll / synchronize, and
+# the runner then switches ITSELF to the write-through form for the rest of its life (``auto_degrade``).  DESIGN.md section 5.
+DEFAULT_WRITE_THROUGH = os.environ.get("GNNPN_PIPE_WRITE_THROUGH", "0") == "1"
 HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
 COMMON_START_US = 400.0     # PipelinedRunner: the first replays of a burst are held until both are enqueued — at most this long (0: off)
 
@@ -205,9 +208,10 @@ class ML2PNPipeline:
             out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start, write_through)
         for w in all_ws:
             w.frozen = True
+        booked_replay = ops.graph_replay(graph, all_ws)      # graph.replay() + the host's count of the cooperative launches it makes
 
         def replay():
-            graph.replay()
+            booked_replay()
             return out
         replay.graph, replay.outputs, replay.workspaces = graph, out, ws
         return replay
@@ -242,7 +246,7 @@ class PipelinedRunner:
     tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
     """
 
-    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=None):
+    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=None, auto_degrade=True):
         # Batches of 512 problems and more: ONE batch in flight, its recurrent part as two half-batches side by side
         # (ML2PNPipeline.run with a pair of workspaces).  A cooperative launch has one workgroup per CU and two of them
         # fill a CU's registers, so nothing else runs beside a co-resident pair; with two WHOLE batches in flight on two
@@ -320,10 +324,30 @@ class PipelinedRunner:
         # write_through: the placement-independent hand-off form (agent-scope write-through granule stores) in every cooperative
         # launch of this runner — the degraded mode bench.py falls back to when a launch reported a failed hand-off
         self.write_through = DEFAULT_WRITE_THROUGH if write_through is None else bool(write_through)
-        self.graphs = [pipe.capture(services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                    ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
-                                    write_through=self.write_through)
+        # auto_degrade: the first poll / synchronize that finds a failed launch (any status code, the shortfall of finished
+        # workgroup-tiles included) re-captures every slot with the write-through hand-off; ``degraded`` keeps the status that
+        # caused it.  The batches since the previous poll are invalid either way and the caller submits them again.
+        self.auto_degrade, self.degraded = bool(auto_degrade), None
+        self._capture_graphs()
+
+    def _capture_graphs(self):
+        self.graphs = [self.pipe.capture(self.services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
+                                         ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
+                                         write_through=self.write_through)
                        for s in range(self.n_slots)]
+
+    def _degrade(self, word):
+        """A launch of this runner failed (status ``word``): from now on every cooperative launch uses the placement-independent
+        write-through hand-off (new graphs over the same static inputs and workspaces; the old ones are dropped)."""
+        if not self.auto_degrade or self.write_through:
+            return
+        import warnings
+        warnings.warn(f"gnnpn: PipelinedRunner: cooperative launches reported status {word:#x}; switching this runner to the "
+                      f"write-through hand-off (the batches since the last poll / synchronize must be submitted again)", RuntimeWarning)
+        self.write_through, self.degraded = True, word
+        self._open_leader, self._last_done = None, [None, None]
+        self._slot_done = [None] * self.n_slots
+        self._capture_graphs()
 
     @staticmethod
     def _fields(b):
@@ -540,7 +564,13 @@ class PipelinedRunner:
         word = 0
         for w in self.workspaces:
             word |= w.poll()
+        if word:
+            self._degrade(word)
         return word
+
+    def progress(self):
+        """The proof-of-work counters the last poll / synchronize read, per workspace (ops.Workspaces.last_progress)."""
+        return [w.last_progress for w in self.workspaces]
 
     def synchronize(self, check=True):
         """Wait for every slot's stream; with ``check`` raise if any launch of any slot since the last call reported a
@@ -551,5 +581,12 @@ class PipelinedRunner:
             st.synchronize()
         self._drained = True
         if check:
+            err = None
             for w in self.workspaces:
-                w.check("PipelinedRunner")
+                try:
+                    w.check("PipelinedRunner")
+                except ops.GnnpnError as e:      # every workspace is read (and cleared) before the first failure is raised
+                    err = err or e
+            if err is not None:
+                self._degrade(int(str(err).split("status ")[1].split(" ")[0], 16) if "status " in str(err) else 0xffff)
+                raise err

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 6   /* 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 7   /* 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -110,8 +110,8 @@ int gnnpn_csr_block_row_order(const int32_t* rowptr, int32_t n_rows, int32_t blo
  *   1. gnnpn_csr_tile_plan_geometry: tile counts and the byte sizes of the plan's arrays (host only).
  *   2. gnnpn_csr_tile_plan_rows: fills header / order / tstart / selfw / meta (device).  Read meta back (stream-ordered):
  *        meta[0] = rows that break the rule above (0: the graph qualifies; otherwise use gnnpn_csr_aggregate_f32),
- *        meta[1] = quads in the stream (allocate (meta[1] + 3) * 512 bytes: the kernel's fixed-shape loads read up to three
- *        quads past the last one), meta[2] = edges in the stream, meta[3] = (row, edge) slots the stream holds = 64 * meta[1]
+ *        meta[1] = quads in the stream (allocate (meta[1] + 4) * 512 bytes: the kernel's fixed-shape loads read up to four
+ *        quads past the last one — an empty unit at the end of the scan order starts there), meta[2] = edges in the stream, meta[3] = (row, edge) slots the stream holds = 64 * meta[1]
  *        (efficiency = meta[2] / meta[3]), meta[4] = rows, meta[8..72) = histogram of the per-(row, source tile) run lengths
  *        (last bin: >= 63).
  *   3. gnnpn_csr_tile_plan_fill: writes the stream (w == NULL: weight 1).
@@ -299,10 +299,10 @@ typedef struct {
 
 /* Per-call launch options of the two recurrent entry points (NULL = all defaults).  They select among
  * implementations of the SAME arithmetic; nothing here is process-wide state.
- *   impl            encoder: 0 auto, 1 per-workgroup streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups: 168
- *                   registers per thread, three workgroups per CU; fp32, folded input side; measured slower, opt-in)
- *                   decoder: 0 auto, 1 streaming, 2 cooperative (8-CU groups), 3 cooperative (16-CU groups),
+ *   impl            encoder: 0 auto, 1 per-workgroup streaming, 2 cooperative (8-CU groups)
+ *                   decoder: 0 auto, 1 streaming, 2 cooperative (8-CU groups),
  *                            4 cooperative (8-CU groups, 256-register build that shares a CU with another launch)
+ *                   (3, the 16-CU-group forms of ABI versions <= 6, measured slower everywhere and were removed: GNNPN_E_ARG)
  *   lds_kb          LDS footprint (KB per workgroup, padded with unused dynamic LDS) of the cooperative kernel, 0 = none:
  *                   placement control for two launches sharing the CUs (100 on one stream + 56 on the other: a CU
  *                   takes one workgroup of each, never two of one)
@@ -315,10 +315,31 @@ typedef struct {
  *                   do that to each other both stay short of members and end in hand-off time-outs.  With the flag, a
  *                   workgroup in such a position does not take its seat (a later arrival of the over-subscribed launch does);
  *                   without it that happens only while another launch of the process is staffing at the same moment.
- *   sticky_status   device uint32 or NULL: every failure code a cooperative kernel raises (bounded inter-workgroup
- *                   wait timed out: outputs invalid) is OR-ed into it as well as into word 0 of the workspace.  The
- *                   library never clears it — word 0 of the workspace is zeroed by every launch — so one host read
- *                   after any number of launches tells whether ANY of them failed. */
+ *   sticky_status   device uint32[GNNPN_STATUS_WORDS] or NULL — the caller's status block, which the library only ever ADDS to:
+ *                   word GNNPN_STATUS_CODE: every failure code a cooperative kernel raises (GNNPN_COOP_*: a bounded
+ *                   inter-workgroup wait timed out, the workspace was not clean: outputs invalid) is OR-ed into it as well as
+ *                   into word 0 of the workspace.  The library never clears it — word 0 of the workspace is zeroed by every
+ *                   launch — so one host read after any number of launches tells whether ANY of them failed.
+ *                   Proof of work (ABI version 7): every cooperative launch adds the workgroup-tiles it is EXPECTED to finish
+ *                   (8 members x nets x ceil(B / 16)) to word GNNPN_STATUS_ENC_EXPECTED / _DEC_EXPECTED before it starts, and
+ *                   every seated workgroup adds the tiles it really took to the end to GNNPN_STATUS_ENC_FINISHED / _DEC_FINISHED
+ *                   when it leaves.  After the stream has been synchronised finished == expected (modulo 2^32) for every launch
+ *                   that did its work; a shortfall means that a launch left outputs it never wrote — whatever the failure codes
+ *                   say (a launch whose workgroups all leave as surplus raises none).  The host reports it as
+ *                   GNNPN_COOP_SHORTFALL (ops.Workspaces.check / poll, which also hold their own count of the launches they
+ *                   made against the expected words). */
+#define GNNPN_STATUS_WORDS 8
+#define GNNPN_STATUS_CODE 0
+#define GNNPN_STATUS_ENC_EXPECTED 4
+#define GNNPN_STATUS_ENC_FINISHED 5
+#define GNNPN_STATUS_DEC_EXPECTED 6
+#define GNNPN_STATUS_DEC_FINISHED 7
+/* failure codes (bits) of the cooperative kernels, in word 0 of a workspace and in sticky_status[GNNPN_STATUS_CODE] */
+#define GNNPN_COOP_ENC_TIMEOUT 1     /* an encoder hand-off sweep gave up (~0.3 s) */
+#define GNNPN_COOP_DEC_TIMEOUT 2     /* a decoder hand-off sweep gave up */
+#define GNNPN_COOP_MEMBER_MISSING 4  /* a group member never showed up */
+#define GNNPN_COOP_DIRTY 8           /* the status area of the workspace was not clean when the launch began */
+#define GNNPN_COOP_SHORTFALL 16      /* host-side: finished != expected after a synchronisation (never set by a kernel) */
 typedef struct {
     int32_t impl;
     int32_t lds_kb;
@@ -337,6 +358,13 @@ int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B,
  * bounded inter-workgroup wait of the LAST launch on it timed out (outputs are then invalid);
  * gnnpn_launch_opts_t.sticky_status accumulates over launches. */
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
+
+/* Proof of work, host side (ABI version 7): the workgroup-tiles the LAST call of gnnpn_lstm_encode_f32 / gnnpn_pointer_decode_f32
+ * on THIS thread booked as expected in the caller's status block (gnnpn_launch_opts_t.sticky_status) — 0 if the call took a
+ * streaming form, had no status block or failed before launching.  A caller adds it to its own count of the work it asked for
+ * and compares that with the device's GNNPN_STATUS_*_EXPECTED / _FINISHED words after a synchronisation.  Replaces nothing in the
+ * reference (PyTorch launches are not cooperative: /root/reference/src/models/modelPN.py:191,204-239 cannot half-run). */
+int64_t gnnpn_last_launch_units(void);
 
 /* Diagnostics switch (process-wide; tools/ only):
  *   "lstm_ablate"    phase stamps / ablations of the cooperative kernels; results are WRONG when non-zero.

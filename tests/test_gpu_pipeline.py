@@ -254,6 +254,54 @@ def test_pipelined_runner_matches_single_stream(dev):
         runner.submit(DeviceBatch.from_problems(synth.make_problem_batch(table, B + 1, seed=3, tasks_per_problem=10), dev))
 
 
+def test_runner_counts_its_work_and_degrades_itself(dev):
+    """Proof of work through graph replays, and the runner's own degraded mode (round 5): every replay books the workgroup-tiles
+    its cooperative launches are expected to finish (device) and the host books the same per replay (ops.graph_replay); poll()
+    finds finished == expected == host count.  A status raised in any slot — here planted by hand: a failure code in one slot, a
+    missing tile in the other — makes poll() return it and switches the runner to the write-through hand-off for good (new
+    graphs over the same static buffers); the batches submitted afterwards are right."""
+    import warnings
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 48
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=70 + i, tasks_per_problem=10), dev) for i in range(4)]
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2, write_through=False)
+    assert runner.poll() == 0
+    for b in batches:
+        runner.submit(b)
+    assert runner.poll() == 0
+    units = ops.Workspaces.coop_units(2, B)                       # two nets, three tiles of 16 problems, eight members
+    for p in runner.progress():                                   # per slot: the capture's two warm-up passes + two replays
+        for part in ("encoder", "decoder"):
+            assert p[part]["finished"] == p[part]["expected"] == p[part]["host_expected"] == 4 * units, p
+    # slot 0: a failure code as a kernel would raise it; slot 1: one workgroup-tile short
+    runner.workspaces[0].status[0] = 2
+    runner.workspaces[1].status[7] -= 1
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        word = runner.poll()
+    assert word == (2 | ops.Workspaces.SHORTFALL) and runner.write_through and runner.degraded == word
+    assert any("write-through" in str(w.message) for w in caught)
+    got = []
+    for b in batches:
+        out, slot = runner.submit(b)
+        with torch.cuda.stream(runner.stream(slot)):
+            got.append((out["idx_high"].clone(), out["R"].clone()))
+    assert runner.poll() == 0                                     # counters restarted after the failure, and agree again
+    for b, (idx, R) in zip(batches, got):
+        ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)
+        assert torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"])
+    runner.workspaces[0].status[0] = 1                            # synchronize(check=True) raises instead
+    with pytest.raises(ops.GnnpnError, match="status 0x1"):
+        runner.synchronize()
+
+
 def test_first_replays_of_a_burst_start_together(dev):
     """Two free-running slots: the first replay after the runner was waited for (synchronize / poll, or the first ever) and the
     other slot's first one are held behind ONE gate (gnnpn_gate_wait on slot 0's transfer stream, opened by the host when the second

@@ -295,10 +295,10 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     x = x.to(dev)
     ref = two_level_greedy(low, high, x, decode_impl=1)
     out8 = two_level_greedy(low, high, x, decode_impl=2)    # 8-CU groups
-    out4 = two_level_greedy(low, high, x, decode_impl=4)    # 8-CU groups, 256-register build (K > 8: falls back to the 16-CU form)
-    out = two_level_greedy(low, high, x, decode_impl=3)     # 16-CU groups (256 registers: co-resident with an encoder wave)
-    out2 = two_level_greedy(low, high, x, decode_impl=3)
-    out3 = two_level_greedy(low, high, x, decode_impl=3, write_through=True)   # the placement-independent hand-off
+    out4 = two_level_greedy(low, high, x, decode_impl=4)    # 8-CU groups, 256-register build (co-resident with another cooperative launch)
+    out = out8
+    out2 = two_level_greedy(low, high, x, decode_impl=2)
+    out3 = two_level_greedy(low, high, x, decode_impl=2, write_through=True)   # the placement-independent hand-off
     ops.check_status(dev)
     for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions", "action_probs"):
         assert torch.equal(out[k], out2[k]), k                    # deterministic across launches
@@ -321,10 +321,10 @@ def test_decode_cooperative_vs_streaming(dev, B, T, K):
     # the pick's probability: the 256-register build forms it in a kernel of its own (pick_prob_kernel, one lane per (problem,
     # step)), the other builds inside the decoder (lane 0 of a 16-lane DPP reduction) — the same tree of sums, so wherever the
     # logits and picks of two builds are the same bits, so are the probabilities
-    for other in (out8, out):
+    for other in (out8, out3):
         eq = (out4["idx_high"] == other["idx_high"]).all(1) & (out4["win_high_raw"] == other["win_high_raw"]).flatten(1).all(1) & \
             (out4["win_low"] == other["win_low"]).flatten(1).all(1)
-        if K <= 8:                                                # (K > 8: impl 4 IS the 16-CU form)
+        if K <= 8:
             assert bool(eq.any())
         assert torch.equal(out4["action_probs"][eq], other["action_probs"][eq])
     s4 = (assert_index_parity(out4["idx_low"], ref["idx_low"], robust, "coop8x2/low", 0.8, x.cpu()) &
@@ -374,7 +374,7 @@ def test_saturated_logits_first_max_wins(dev):
         nets.append(m.to(dev).eval())
     x = torch.from_numpy(fx["inputs"]).to(dev)
     ties_checked = 0
-    for impl in (1, 2, 3):
+    for impl in (1, 2):
         out = two_level_greedy(nets[0], nets[1], x, fold=False, decode_impl=impl)   # literal two-stage order: closest to the fixture
         got_low, win = out["idx_low"].cpu().numpy(), out["win_low"].cpu().numpy()
         for b in range(x.shape[0]):
@@ -481,14 +481,14 @@ def test_split_precision_ragged_shapes(dev, B, T, K):
     x[:, K:, 4:] = 0
     x = x.to(dev)
     ref = two_level_greedy(low, high, x)
-    outs = [two_level_greedy(low, high, x, precision="split", decode_impl=impl) for impl in (2, 3, 3, 4)]
+    outs = [two_level_greedy(low, high, x, precision="split", decode_impl=impl) for impl in (2, 2, 2, 4)]
     ops.check_status(dev)
     for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions"):
         assert torch.equal(outs[1][k], outs[2][k]), k
     win_ref = torch.stack([ref["win_low"], ref["win_high_raw"] + ref["win_low"]]).cpu()
     m = opn.decision_margin(win_ref[0], x.cpu()), opn.decision_margin(win_ref[1], x.cpu())
     robust = (m[0] > 1e-4).all(1) & (m[1] > 1e-4).all(1)
-    for tag, out in (("split8", outs[0]), ("split16", outs[1]), ("split8x2", outs[3])):
+    for tag, out in (("split8", outs[0]), ("split8x2", outs[3])):
         same = assert_index_parity(out["idx_low"], ref["idx_low"], robust, tag + "/low", 0.8, x.cpu()) & \
             assert_index_parity(out["idx_high"], ref["idx_high"], robust, tag + "/high", 0.8, x.cpu())
         s = same.to(dev)
@@ -533,6 +533,118 @@ def test_a_launch_on_a_dirty_workspace_is_loud(dev):
     finally:
         ops.set_option("lstm_ablate", 0)
     assert torch.equal(custom_ops.lstm_encode([args], ws=ws)[0][0], enc0)       # and the next ordinary launch is fine again
+    ws.check()
+
+
+# ---- proof of work (round 5): a cooperative launch that did not do its work cannot pass a check ------------------------------
+# layout of a workspace's status area in 32-bit words (csrc/coop_common.h): 0 the launch's error word, 4 staffing state, 5 seats
+# taken in all, 256.. seats taken per XCD, 288.. arrivals per XCD, 512..2559 CU claim statistics, 2560.. seat flags (64 per XCD)
+def _poison(kind, words, gen):
+    """Patterns for the status area of a workspace that the launch then does NOT zero (test hook).  The first two are what the
+    failure record of round 4 showed (profiles/r04_handoff_timeouts_on_some_boxes.jsonl): the PREVIOUS launch's totals."""
+    p = torch.zeros(words, dtype=torch.int32)
+    if kind in ("previous_totals", "previous_totals_some_xcds"):
+        xcds = range(8) if kind == "previous_totals" else (1, 4, 6)
+        for x in xcds:
+            p[256 + x] = 32                       # the XCD's 32 seats taken
+            p[288 + x] = 96                       # every workgroup of the 3 x over-subscribed launch arrived
+            p[2560 + 64 * x:2560 + 64 * x + 32] = 1
+        p[4], p[5] = 2, 32 * len(list(xcds))     # "staffed", seats in all
+    elif kind == "seat_counters_only":
+        p[256:264] = 32
+    elif kind == "seat_flags_only":
+        p[2560:2560 + 512:3] = 1                 # every third seat looks taken: those members can never be seated
+    elif kind == "staffing_word":
+        p[4] = 1
+    elif kind == "random_dense":
+        p = torch.randint(-2**31, 2**31 - 1, (words,), generator=gen, dtype=torch.int64).to(torch.int32)
+    elif kind == "random_sparse":
+        idx = torch.randint(0, words, (40,), generator=gen)
+        p[idx] = torch.randint(1, 200, (40,), generator=gen, dtype=torch.int64).to(torch.int32)
+    else:
+        raise KeyError(kind)
+    return p
+
+
+POISONS = ["previous_totals", "previous_totals_some_xcds", "seat_counters_only", "seat_flags_only", "staffing_word", "random_dense",
+           "random_sparse"]
+
+
+@pytest.mark.parametrize("kind", POISONS)
+@pytest.mark.parametrize("which", ["encoder", "decoder"])
+def test_poisoned_status_area_ends_loud_or_correct(dev, which, kind):
+    """The silent failure of round 4: a launch that began on the previous launch's seat counters — every workgroup left as
+    surplus, nothing ran, nothing timed out, status 0, outputs garbage.  Now every seated workgroup adds the tiles it FINISHED to
+    the caller's status block and the launch books the tiles it is EXPECTED to finish (include/gnnpn_hip.h, GNNPN_STATUS_*);
+    ``Workspaces.poll`` compares them (and the host's own count of the launches it made).  Whatever the status area holds when
+    a launch begins — the previous launch's totals, on all XCDs or some; stale flags; random words — the launch ends in a
+    CORRECT result or a NON-ZERO status, never in silence.  QWS-sized batch (32 seats per XCD, as in the failure record)."""
+    from gnnpn_sc_amd import _lib, custom_ops, ops
+    T, K, B = 6, 4, 256
+    cfg = {"hidden": 256, "n_cat": T, "n_per": K, "seed_low": 1, "seed_high": 2}
+    low, high = build(cfg, dev)
+    x = torch.rand(B, T * K, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+    ws = ops.new_workspaces(dev)
+    gen = torch.Generator().manual_seed(hash((which, kind)) % 1000)
+
+    def launch():
+        args = [m.actor.encode_args(x, None)[0] for m in (low, high)]
+        if which == "encoder":
+            return torch.stack(custom_ops.lstm_encode(args, ws=ws)[0])
+        from gnnpn_sc_amd.modelPN import two_level_greedy
+        out = two_level_greedy(low, high, x, precision="f32", ws=ws)
+        return torch.cat([out["idx_low"], out["idx_high"]]).float()
+    ref = launch().clone()
+    assert ws.poll() == 0 and all(p["finished"] == p["expected"] == p["host_expected"] for p in ws.last_progress.values())
+    assert ws.last_progress[which]["expected"] == ops.Workspaces.coop_units(2, B)
+    buf = ws._encode if which == "encoder" else ws._decode
+    try:
+        # the workspaces as a per-launch zeroing would leave them, then the poison; the test hook (lstm_ablate bit 13) makes the
+        # launches skip their own zeroing (the decode call's encoder launch included: its workspace is clean)
+        ws._encode.zero_()
+        if ws._decode is not None:
+            ws._decode.zero_()
+        buf[:16384].view(torch.int32).copy_(_poison(kind, 16384 // 4, gen))
+        torch.cuda.synchronize()
+        ops.set_option("lstm_ablate", 0x2000)
+        got = launch()
+        torch.cuda.synchronize()
+        ops.set_option("lstm_ablate", 0)
+        word = ws.poll()
+        assert word != 0 or torch.equal(got, ref), f"{which}/{kind}: status 0 and a wrong result: {ws.last_progress}"
+        if kind in ("previous_totals", "seat_counters_only", "random_dense"):
+            assert word != 0                        # these cannot run: every workgroup finds the launch "staffed"
+    finally:
+        ops.set_option("lstm_ablate", 0)
+        assert _lib.load().gnnpn_coop_reset_staffing() == 0
+    again = launch()                               # and the next ordinary launch on the same workspace is fine
+    assert ws.poll() == 0 and torch.equal(again, ref)
+
+
+def test_a_launch_that_does_nothing_is_a_shortfall(dev):
+    """The bare mechanism: seat counters that say "staffed" and arrival counters of a FINISHED launch are what no failure code
+    catches from inside (every workgroup is surplus) unless a workgroup happens to look — with code 8 masked out of the
+    comparison the shortfall alone must raise: finished 0 of 256 expected."""
+    from gnnpn_sc_amd import custom_ops, ops
+    cfg = {"hidden": 256, "n_cat": 6, "n_per": 4, "seed_low": 1, "seed_high": 2}
+    low, high = build(cfg, dev)
+    x = torch.rand(256, 24, 8).to(dev)
+    ws = ops.new_workspaces(dev)
+    args = [m.actor.encode_args(x, None)[0] for m in (low, high)]
+    custom_ops.lstm_encode(args, ws=ws)
+    ws.check()
+    try:
+        ops.set_option("lstm_ablate", 0x2000)
+        custom_ops.lstm_encode(args, ws=ws)         # on the counters the first launch left behind
+        word, prog = ws._read()
+        assert prog["encoder"]["expected"] == 2 * ops.Workspaces.coop_units(2, 256) == prog["encoder"]["host_expected"]
+        assert prog["encoder"]["finished"] == ops.Workspaces.coop_units(2, 256)          # the second launch finished nothing
+        assert word & ops.Workspaces.SHORTFALL
+        with pytest.raises(ops.GnnpnError, match="finished != expected"):
+            ws.check()
+    finally:
+        ops.set_option("lstm_ablate", 0)
+    custom_ops.lstm_encode(args, ws=ws)
     ws.check()
 
 
