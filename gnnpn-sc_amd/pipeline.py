@@ -204,7 +204,12 @@ class ML2PNPipeline:
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=pool):
+        # thread_local: only THIS thread's calls are policed during the capture.  In the default ("global") mode an event query
+        # made by another thread while the capture is open is an error that invalidates it — and the watchdog thread of
+        # torch.distributed's RCCL process group queries the events of its collectives whenever one is outstanding: a runner
+        # captured while collectives are in flight (bench.py's degraded form at N > 1 is built mid-run) died that way in one
+        # of this round's GPU runs (ProcessGroupNCCL watchdog: HIP error from hipEventQuery, the process aborted)
+        with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
             out = self.run(services, batch, decode_impl, lds_kb, ws, paired_start, write_through)
         for w in all_ws:
             w.frozen = True

@@ -104,7 +104,7 @@ def build(rowptr, col, w, n_rows, block_rows):
            "stats": stats}
     if invalid:
         return out
-    batches = np.zeros(((quads + 3) * 128,), np.uint32)      # 512 bytes per quad: [16 rows][4] offsets, then [16 rows][4] weights
+    batches = np.zeros(((quads + 4) * 128,), np.uint32)      # 512 bytes per quad: [16 rows][4] offsets, then [16 rows][4] weights; four quads of slack
     zero_off = TR * 64
     item = 0
     for bd in range(n_bd):
