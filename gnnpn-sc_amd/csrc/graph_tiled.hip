@@ -525,29 +525,50 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         rl[p] = in ? ob[p * RPP + ((p & 1) ? pos_odd : pos_even)] : -1;
         swl[p] = in ? swb[p * RPP + ((p & 1) ? pos_odd : pos_even)] : 0.0f;
     }
+    // The rows' own features (trailing self loop outside the last source tile, GIN self term) come from global memory: requested
+    // for EPI_CHUNK passes at once, unconditionally (rows that need nothing read row 0 of the block and ignore it), then used —
+    // one round trip per chunk.  (Round 4: one load per pass inside `if (has_loop)`, each behind a wait for the previous pass's
+    // STORE as well: ten dependent HBM round trips per workgroup, 0.29 ms of the 0.775 ms launch at 5000 rows x 128 copies —
+    // profiles/r05_aggregate_skeleton.json.)  A workgroup whose rows all lie in the last source tile (wave-uniform test) skips it.
+    constexpr int EPI_CHUNK = PASSES < 5 ? PASSES : 5;
+    const bool needs_own = self_coef != nullptr || d * g.DR < (g.NT - 1) * g.TR;
+#pragma unroll
+    for (int p0 = 0; p0 < PASSES; p0 += EPI_CHUNK) {
+        float4 own[EPI_CHUNK];
+#pragma unroll
+        for (int k = 0; k < EPI_CHUNK; ++k) {
+            own[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + k < PASSES && needs_own) own[k] = *reinterpret_cast<const float4*>(x + (r0 + max(rl[p0 + k < PASSES ? p0 + k : 0], 0)) * ldx + c);
+        }
+#pragma unroll
+        for (int k = 0; k < EPI_CHUNK; ++k) {
+            const int p = p0 + k;
+            if (p >= PASSES) break;
+            if (rl[p] < 0) continue;
+            const float sw = swl[p];
+            const bool has_loop = sw == sw;
+            const float o4[4] = {own[k].x, own[k].y, own[k].z, own[k].w};
+            float acc[4] = {a01[p].x, a01[p].y, a23[p].x, a23[p].y};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float tv = acc[v];
+                if (has_loop) tv = __fadd_rn(tv, __fmul_rn(sw, o4[v]));
+                if (self_coef) tv = __fadd_rn(tv, __fmul_rn(one_plus_eps, o4[v]));
+                if (bias) tv = __fadd_rn(tv, bv[v]);
+                if (scale) tv = __fadd_rn(__fmul_rn(tv, sc[v]), sh[v]);
+                acc[v] = apply_act(tv, act);
+            }
+            a01[p] = f32x2{acc[0], acc[1]};                 // the results stay in the accumulators' registers ...
+            a23[p] = f32x2{acc[2], acc[3]};
+        }
+    }
+    // ... and leave in one burst of stores at the very end: a store reads its data registers after it has been issued, so a store
+    // between two chunks made the compiler wait for its completion (vmcnt(0)) before it reused them — two more round trips
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         if (rl[p] < 0) continue;
-        const int64_t r = r0 + rl[p];
-        const float sw = swl[p];
-        const bool has_loop = sw == sw;
-        float o4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (has_loop || self_coef) {                                      // (rows of the last source tile took their loop from LDS)
-            const float4 own = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            o4[0] = own.x, o4[1] = own.y, o4[2] = own.z, o4[3] = own.w;
-        }
-        float acc[4] = {a01[p].x, a01[p].y, a23[p].x, a23[p].y};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float tv = acc[v];
-            if (has_loop) tv = __fadd_rn(tv, __fmul_rn(sw, o4[v]));
-            if (self_coef) tv = __fadd_rn(tv, __fmul_rn(one_plus_eps, o4[v]));
-            if (bias) tv = __fadd_rn(tv, bv[v]);
-            if (scale) tv = __fadd_rn(__fmul_rn(tv, sc[v]), sh[v]);
-            acc[v] = apply_act(tv, act);
-        }
-        if (!(GNNPN_AGG_ABLATE & 8) || acc[0] == 1.2345e30f)
-            *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (!(GNNPN_AGG_ABLATE & 8) || a01[p].x == 1.2345e30f)
+            *reinterpret_cast<float4*>(y + (r0 + rl[p]) * ldy + c) = make_float4(a01[p].x, a01[p].y, a23[p].x, a23[p].y);
     }
     }   // item
 }
