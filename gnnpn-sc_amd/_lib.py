@@ -52,6 +52,7 @@ _SIGNATURES = {
     "gnnpn_decode_diag": (c_int, [_P, c_int32, c_int32]),
     "gnnpn_coop_reset_staffing": (c_int, []),
     "gnnpn_last_launch_units": (c_int64, []),
+    "gnnpn_lds_footprint_kb": (c_int, [c_int]),
     "gnnpn_coop_staffing_count": (c_int, []),
     "gnnpn_bn_train_forward_f32": (c_int, [_P, c_int64, c_int32, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "gnnpn_bn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int, _P, _P, _P, _P]),

@@ -13,6 +13,25 @@ thread_local char g_gnnpn_err[256] = "";
 thread_local int64_t g_gnnpn_last_units = 0;
 extern "C" int64_t gnnpn_last_launch_units(void) { return g_gnnpn_last_units; }
 
+// ---- LDS footprint of the ordinary kernels in front of a cooperative launch (gnnpn_lds_footprint_kb, include/gnnpn_hip.h) -----
+thread_local int g_gnnpn_lds_footprint_kb = 0;
+extern "C" int gnnpn_lds_footprint_kb(int kb) {
+    const int prev = g_gnnpn_lds_footprint_kb;
+    if (kb >= 0 && kb <= 160) g_gnnpn_lds_footprint_kb = kb;
+    return prev;
+}
+// dynamic LDS bytes that bring `func`'s footprint to the calling thread's setting (0: none asked for, or the kernel is larger)
+unsigned gnnpn_front_lds_pad(const void* func) {
+    const int kb = g_gnnpn_lds_footprint_kb;
+    if (kb <= 0) return 0;
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, func) != hipSuccess) return 0;
+    const long dyn = (long)kb * 1024 - (long)a.sharedSizeBytes;
+    if (dyn <= 0) return 0;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return 0;
+    return (unsigned)dyn;
+}
+
 extern "C" int gnnpn_abi_version(void) { return GNNPN_ABI_VERSION; }
 extern "C" const char* gnnpn_last_error(void) { return g_gnnpn_err; }
 

@@ -29,6 +29,7 @@ extern thread_local char g_gnnpn_err[256];
     } while (0)
 
 static inline bool gnnpn_aligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
+unsigned gnnpn_front_lds_pad(const void* func);   // api.hip: dynamic LDS bytes up to the thread's gnnpn_lds_footprint_kb (0: none)
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

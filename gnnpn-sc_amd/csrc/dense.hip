@@ -158,15 +158,15 @@ extern "C" int gnnpn_linear_f32(const float* A, int64_t lda, const float* W, int
     if (blocks128 >= 256 && K >= 512 && N >= 256) {
         dim3 grid((N + 127) / 128, (unsigned)((M + 127) / 128));
         GNNPN_REQUIRE(grid.y < 65536u * 32768u, "linear: M too large");
-        hipLaunchKernelGGL((linear_f32_kernel<128, 128>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, scale,
+        hipLaunchKernelGGL((linear_f32_kernel<128, 128>), grid, dim3(256), gnnpn_front_lds_pad((const void*)linear_f32_kernel<128, 128>), s, A, lda, W, ldw, bias, scale,
                            shift, act, C, ldc, M, N, K, vec_a, vec_w);
     } else if (N % 128 == 0 && M >= 64 * 512) {   // full-width 64x128 tiles: A is read once per 128 columns (5-15 % over 64x64)
         dim3 grid(N / 128, (unsigned)((M + 63) / 64));
-        hipLaunchKernelGGL((linear_f32_kernel<64, 128>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, scale,
+        hipLaunchKernelGGL((linear_f32_kernel<64, 128>), grid, dim3(256), gnnpn_front_lds_pad((const void*)linear_f32_kernel<64, 128>), s, A, lda, W, ldw, bias, scale,
                            shift, act, C, ldc, M, N, K, vec_a, vec_w);
     } else {
         dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
-        hipLaunchKernelGGL((linear_f32_kernel<64, 64>), grid, dim3(256), 0, s, A, lda, W, ldw, bias, scale,
+        hipLaunchKernelGGL((linear_f32_kernel<64, 64>), grid, dim3(256), gnnpn_front_lds_pad((const void*)linear_f32_kernel<64, 64>), s, A, lda, W, ldw, bias, scale,
                            shift, act, C, ldc, M, N, K, vec_a, vec_w);
     }
     GNNPN_CHECK_LAUNCH("linear_f32");

@@ -274,10 +274,10 @@ extern "C" int gnnpn_request_branch_f32(const float* x, int32_t nfeat, const flo
     a.emb = emb;
     hipStream_t st = (hipStream_t)stream;
     switch (n_layers) {
-        case 1: hipLaunchKernelGGL(gin_request_branch_kernel<1>, dim3(n_graphs), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(gin_request_branch_kernel<2>, dim3(n_graphs), dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(gin_request_branch_kernel<3>, dim3(n_graphs), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(gin_request_branch_kernel<4>, dim3(n_graphs), dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(gin_request_branch_kernel<1>, dim3(n_graphs), dim3(256), gnnpn_front_lds_pad((const void*)gin_request_branch_kernel<1>), st, a); break;
+        case 2: hipLaunchKernelGGL(gin_request_branch_kernel<2>, dim3(n_graphs), dim3(256), gnnpn_front_lds_pad((const void*)gin_request_branch_kernel<2>), st, a); break;
+        case 3: hipLaunchKernelGGL(gin_request_branch_kernel<3>, dim3(n_graphs), dim3(256), gnnpn_front_lds_pad((const void*)gin_request_branch_kernel<3>), st, a); break;
+        default: hipLaunchKernelGGL(gin_request_branch_kernel<4>, dim3(n_graphs), dim3(256), gnnpn_front_lds_pad((const void*)gin_request_branch_kernel<4>), st, a); break;
     }
     GNNPN_CHECK_LAUNCH("request_branch_f32");
     return GNNPN_OK;

@@ -524,6 +524,24 @@ class Workspaces:
                              f"(a launch did not do its work): {prog}; last launches' own words (encoder, decoder) = {last}{detail}")
 
 
+class lds_footprint:
+    """``with ops.lds_footprint(kb):`` — the ordinary LDS-using kernels this thread launches inside the block (gnnpn_linear_f32,
+    gnnpn_request_branch_f32) are padded to ``kb`` KB of LDS per workgroup (gnnpn_lds_footprint_kb): PipelinedRunner captures
+    its free-running slots' graphs that way, so that a small kernel's LDS range is exactly what the other slot's cooperative
+    workgroup needs when it is freed (include/gnnpn_hip.h)."""
+
+    def __init__(self, kb):
+        self.kb, self.prev = int(kb), 0
+
+    def __enter__(self):
+        self.prev = _lib.load().gnnpn_lds_footprint_kb(self.kb)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().gnnpn_lds_footprint_kb(self.prev)
+        return False
+
+
 def graph_replay(graph, all_ws):
     """Call right after capturing ``graph`` (torch.cuda.CUDAGraph) over launches on the ``Workspaces`` in ``all_ws``: returns
     ``replay()`` = ``graph.replay()`` + the host-side booking of the cooperative launches one replay makes (proof of work:

@@ -93,7 +93,9 @@ class DeviceBatch:
 # the runner then switches ITSELF to the write-through form for the rest of its life (``auto_degrade``).  DESIGN.md section 5.
 DEFAULT_WRITE_THROUGH = os.environ.get("GNNPN_PIPE_WRITE_THROUGH", "0") == "1"
 HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
-COMMON_START_US = 400.0     # PipelinedRunner: the first replays of a burst are held until both are enqueued — at most this long (0: off)
+COMMON_START_US = 0.0       # PipelinedRunner: > 0 holds the first replays of a burst until both are enqueued, at most this long.  OPT-IN since
+#                             round 5 (GNNPN_PIPE_COMMON_START_US=400 is what round 4 ran): the slots no longer slip apart once the front-half
+#                             kernels share the cooperative kernels' LDS footprint (FRONT_LDS_KB below), which is also 1 % faster than the gate
 
 
 def half_batch_split(n_problems):
@@ -286,6 +288,15 @@ class PipelinedRunner:
         env = os.environ.get("GNNPN_SLOT_LDS_KB")
         equal = 78 if (getattr(pipe, "precision", "f32") == "split" and paired) else 0
         self.lds_kb = [int(v) for v in env.split(",")] if env else [equal] * self.n_slots
+        # ... and so are the ORDINARY kernels of a step that use LDS in front of the encoder (the one-launch GIN branch, the score
+        # product: ops.lds_footprint / gnnpn_lds_footprint_kb).  A cooperative workgroup that lands above such a kernel's few KB
+        # keeps its 78 KB in the middle of the CU when the small kernel has gone, and the OTHER slot's encoder workgroup for that
+        # CU finds no contiguous 78 KB until this encoder has finished: the two free-running slots slipped apart by 0.5 ms in
+        # every 20-step round (round 4 held the slots of a burst behind a common-start gate against it: 455 k problems/s with 4-8
+        # slow rounds of 89; with the front half at the same footprint 460 k and no slow round in 270, gate off —
+        # profiles/r05_slip_front_lds.jsonl).  Two free-running slots only: the half-batch mode runs its front half alone.
+        env = os.environ.get("GNNPN_PIPE_FRONT_LDS_KB")
+        self.front_lds_kb = int(env) if env is not None else (equal if (self.n_streams == 2 and not self.halves) else 0)
         self.count = 0
         # Two slots, long recurrent kernels: start the two replays of a pair TOGETHER (a submission joins the leader that is
         # still waiting for a partner, else it leads).  Free-running slots drift apart by the difference of their step
@@ -336,10 +347,11 @@ class PipelinedRunner:
         self._capture_graphs()
 
     def _capture_graphs(self):
-        self.graphs = [self.pipe.capture(self.services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
-                                         ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
-                                         write_through=self.write_through)
-                       for s in range(self.n_slots)]
+        with ops.lds_footprint(self.front_lds_kb):            # captured launches keep the footprint (a per-launch attribute)
+            self.graphs = [self.pipe.capture(self.services, self.batches[s], decode_impl=self.decode_impl, lds_kb=self.lds_kb[s],
+                                             ws=tuple(self.workspaces) if self.halves else self.workspaces[s], paired_start=self.lockstep,
+                                             write_through=self.write_through)
+                           for s in range(self.n_slots)]
 
     def _degrade(self, word):
         """A launch of this runner failed (status ``word``): from now on every cooperative launch uses the placement-independent

@@ -359,6 +359,18 @@ int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B,
  * gnnpn_launch_opts_t.sticky_status accumulates over launches. */
 int64_t gnnpn_lstm_encode_workspace_bytes(void);
 
+/* LDS footprint of the ORDINARY kernels of this library that use LDS and run in front of a cooperative launch in a pipelined step
+ * (gnnpn_linear_f32, gnnpn_request_branch_f32): every such kernel launched by the CALLING THREAD from now on is padded with unused
+ * dynamic LDS to `kb` KB per workgroup (0 = no padding, the default; kernels that already use more are left alone).  Returns the
+ * previous setting.  Why: LDS is handed out in contiguous ranges.  A cooperative workgroup (78 KB in the exact-split precision) that
+ * lands ABOVE a small kernel's few KB keeps its range in the middle of the CU after the small kernel has gone, and the other
+ * pipeline slot's cooperative workgroup for that CU then has no contiguous 78 KB until this whole launch has finished (0.5 ms at the
+ * QWS shape: the "slip" of two slots out of step, measured in every 20-step round without a common start).  With the small kernels
+ * at the SAME footprint their range is exactly what the next cooperative workgroup needs (profiles/r05_slip_front_lds.jsonl:
+ * 436 k -> 460 k problems/s, no slow round in 270).  A placement setting like gnnpn_launch_opts_t.lds_kb — it selects no kernel
+ * build and changes no result; capture a HIP graph with it set and the captured launches keep it.  New in ABI version 7. */
+int gnnpn_lds_footprint_kb(int kb);
+
 /* Proof of work, host side (ABI version 7): the workgroup-tiles the LAST call of gnnpn_lstm_encode_f32 / gnnpn_pointer_decode_f32
  * on THIS thread booked as expected in the caller's status block (gnnpn_launch_opts_t.sticky_status) — 0 if the call took a
  * streaming form, had no status block or failed before launching.  A caller adds it to its own count of the work it asked for

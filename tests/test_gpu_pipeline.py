@@ -303,7 +303,9 @@ def test_runner_counts_its_work_and_degrades_itself(dev):
 
 
 def test_first_replays_of_a_burst_start_together(dev):
-    """Two free-running slots: the first replay after the runner was waited for (synchronize / poll, or the first ever) and the
+    """(The common start is OPT-IN since round 5 — GNNPN_PIPE_COMMON_START_US — the slots no longer slip apart once the front
+    half shares the encoders' LDS footprint: test_front_half_shares_the_cooperative_footprint.)
+    Two free-running slots: the first replay after the runner was waited for (synchronize / poll, or the first ever) and the
     other slot's first one are held behind ONE gate (gnnpn_gate_wait on slot 0's transfer stream, opened by the host when the second
     replay is enqueued, by synchronize / poll, or after pipeline.COMMON_START_US) — the later
     ones are not, batches from host memory are not, a runner without the option is not; the results are what a single stream
@@ -318,8 +320,13 @@ def test_first_replays_of_a_burst_start_together(dev):
     pipe = ML2PNPipeline(net, low, high, K)
     svc = DeviceServices.from_table(table, dev)
     batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=40 + i, tasks_per_problem=10), dev) for i in range(3)]
-    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
-    assert runner.common_start_us == pipeline.COMMON_START_US and runner._drained and runner._gate is None
+    assert pipeline.COMMON_START_US == 0 and PipelinedRunner(pipe, svc, batches[0], slots=2).common_start_us == 0    # the default: off
+    os.environ["GNNPN_PIPE_COMMON_START_US"] = "400"
+    try:
+        runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    finally:
+        del os.environ["GNNPN_PIPE_COMMON_START_US"]
+    assert runner.common_start_us == 400 and runner._drained and runner._gate is None
 
     def burst(n, source):
         starts, outs = [], []
@@ -352,16 +359,50 @@ def test_first_replays_of_a_burst_start_together(dev):
     runner.submit(host[1])
     runner.synchronize()
     ops.check_status(dev)
-    # the option off
-    os.environ["GNNPN_PIPE_COMMON_START_US"] = "0"
-    try:
-        plain = PipelinedRunner(pipe, svc, batches[0], slots=2)
-    finally:
-        del os.environ["GNNPN_PIPE_COMMON_START_US"]
+    # the option off (the default)
+    plain = PipelinedRunner(pipe, svc, batches[0], slots=2)
     assert plain.common_start_us == 0
     plain.submit(batches[0])
     assert plain._gate is None
     plain.synchronize()
+
+
+def test_front_half_shares_the_cooperative_footprint(dev):
+    """Round 5: the ordinary LDS-using kernels in front of the encoder (one-launch GIN branch, score product) are captured with
+    the cooperative kernels' LDS footprint in a runner of two free-running slots in the exact-split precision (78 KB: a freed
+    range then fits the other slot's encoder workgroup — what made the slots slip apart, profiles/r05_slip_front_lds.jsonl);
+    the setting is the calling thread's and is restored; f32 runners and the half-batch mode pad nothing; results unchanged."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import _lib, ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 48
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=90 + i, tasks_per_problem=10), dev) for i in range(3)]
+    lib = _lib.load()
+    assert lib.gnnpn_lds_footprint_kb(-1) == 0                        # (out of range: a query)
+    with ops.lds_footprint(78):
+        assert lib.gnnpn_lds_footprint_kb(-1) == 78
+        with ops.lds_footprint(0):
+            assert lib.gnnpn_lds_footprint_kb(-1) == 0
+        assert lib.gnnpn_lds_footprint_kb(-1) == 78
+    assert lib.gnnpn_lds_footprint_kb(-1) == 0
+    pipe = ML2PNPipeline(net, low, high, K)                           # exact split by default
+    runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+    assert runner.front_lds_kb == 78 == runner.lds_kb[0] and lib.gnnpn_lds_footprint_kb(-1) == 0
+    assert PipelinedRunner(ML2PNPipeline(net, low, high, K, precision="f32"), svc, batches[0], slots=2).front_lds_kb == 0
+    assert PipelinedRunner(pipe, svc, batches[0], slots=2, halves=True).front_lds_kb == 0
+    got = []
+    for b in batches:
+        out, slot = runner.submit(b)
+        with torch.cuda.stream(runner.stream(slot)):
+            got.append((out["idx_high"].clone(), out["R"].clone(), out["scores"].clone()))
+    runner.synchronize()
+    for b, (idx, R, sc) in zip(batches, got):
+        ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)          # eager: no padding
+        assert torch.equal(idx, ref["idx_high"]) and torch.equal(R, ref["R"]) and torch.equal(sc, ref["scores"])
 
 
 @pytest.mark.parametrize("B,precision", [(88, "f32"), (88, "split"), (50, "split"), (33, "f32")])
