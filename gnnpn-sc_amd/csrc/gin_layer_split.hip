@@ -22,30 +22,17 @@
 #include "common.h"
 #include "coop_common.h"
 
-// Timing-only builds (tools/ablate_gin_layer.py; results wrong by design): -DGNNPN_GIN_ABLATE=bits — 1: every k-block reads the
-// layer's FIRST weight record (no weight stream from L2), 2: no matrix instructions, 4: no aggregate (no gathers), 8: no piece
-// split in the epilogues (piece 0 only).
-#ifndef GNNPN_GIN_ABLATE
-#define GNNPN_GIN_ABLATE 0
-#endif
+// (The timing-only builds and the tile / depth / occupancy / piece-form variants that were measured and not kept live in
+// tools/experiments/gin_layer_split_switches.patch, applied by tools/ablate_gin_layer.py; profiles/LOG_r04.md has the numbers.)
 
 namespace {
 
 constexpr int H1 = 256, H2 = 128, H3 = 128;
-#ifndef GNNPN_GIN_RT
-#define GNNPN_GIN_RT 3
-#endif
-#ifndef GNNPN_GIN_NCT
-#define GNNPN_GIN_NCT 2
-#endif
-constexpr int NCT = GNNPN_GIN_NCT;                          // column tiles of 16 a wave works on at a time (accumulators: 12-16 registers per (row tile, column tile))
-constexpr int RT = GNNPN_GIN_RT, BM = 16 * RT;               // row tiles of 16 per workgroup: a weight fragment is used RT times
+constexpr int NCT = 2;                                      // column tiles of 16 a wave works on at a time (accumulators: 12-16 registers per (row tile, column tile))
+constexpr int RT = 3, BM = 16 * RT;                           // row tiles of 16 per workgroup: a weight fragment is used RT times
 constexpr int REC = 2560;                                  // bytes per (column tile, k-block) weight record
 constexpr int NCH_MAX = 4;                                 // aggregate: float4 chunks per lane (128 channels / 8 lanes / 4)
-#ifndef GNNPN_GIN_DEPTH
-#define GNNPN_GIN_DEPTH 2
-#endif
-constexpr int DEPTH = GNNPN_GIN_DEPTH;                       // k-blocks of weights a wave keeps in flight (registers: 20 per k-block)
+constexpr int DEPTH = 2;                                     // k-blocks of weights a wave keeps in flight (registers: 20 per k-block)
 
 struct BFrag {
     f16x8 w0, w1;
@@ -96,10 +83,6 @@ __device__ __forceinline__ void kblock(const _Float16* a_lane, int lda, int piec
 #pragma unroll
         for (int n = 0; n < NCT; ++n) {
             Acc& c = acc[rt][n];
-#if GNNPN_GIN_ABLATE & 2
-            c.a0[0] += (float)h0[rt][0] + (float)h1[rt][1] + (float)h2[rt][2] + (float)b[n].w0[0] + (float)b[n].w1[1] + (float)e[n][2];
-            continue;
-#endif
             c.a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[n].w1, h1[rt], c.a2, 0, 0, 0);
             c.a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[n].w0, h1[rt], c.a1, 0, 0, 0);
             c.a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(e[n], h0[rt], c.a2, 0, 0, 0);
@@ -117,10 +100,10 @@ __device__ __forceinline__ void kblock(const _Float16* a_lane, int lda, int piec
 __device__ __forceinline__ void prefetch_b(const unsigned char* w, int ct0, int kb_n, int lane, BFrag (&q)[DEPTH][NCT]) {
 #pragma unroll
     for (int n = 0; n < NCT; ++n) {
-        const unsigned char* wl = w + ((GNNPN_GIN_ABLATE & 1) ? 0 : (size_t)(ct0 + n) * kb_n * REC);
+        const unsigned char* wl = w + (size_t)(ct0 + n) * kb_n * REC;
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (d < kb_n) q[d][n] = load_b(wl + ((GNNPN_GIN_ABLATE & 1) ? 0 : d * REC), lane);
+            if (d < kb_n) q[d][n] = load_b(wl + d * REC, lane);
     }
 }
 
@@ -134,7 +117,7 @@ __device__ __forceinline__ void split_gemm(const _Float16* a_lane, int lda, int 
         for (int n = 0; n < NCT; ++n) acc[rt][n].a0 = acc[rt][n].a0b = acc[rt][n].a1 = acc[rt][n].a2 = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned char* wl[NCT];
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) wl[n] = w + ((GNNPN_GIN_ABLATE & 1) ? 0 : (size_t)(ct0 + n) * kb_n * REC);
+    for (int n = 0; n < NCT; ++n) wl[n] = w + (size_t)(ct0 + n) * kb_n * REC;
     for (int kk0 = 0; kk0 < kb_n; kk0 += DEPTH) {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) {
@@ -145,7 +128,7 @@ __device__ __forceinline__ void split_gemm(const _Float16* a_lane, int lda, int 
                 for (int n = 0; n < NCT; ++n) b[n] = q[i][n];
                 if (kk + DEPTH < kb_n) {
 #pragma unroll
-                    for (int n = 0; n < NCT; ++n) q[i][n] = load_b(wl[n] + ((GNNPN_GIN_ABLATE & 1) ? 0 : (size_t)(kk + DEPTH) * REC), lane);
+                    for (int n = 0; n < NCT; ++n) q[i][n] = load_b(wl[n] + (size_t)(kk + DEPTH) * REC, lane);
                 }
                 if (!LONGK || kk < 4) kblock<true>(a_lane, lda, piece, kk, b, acc);
                 else kblock<false>(a_lane, lda, piece, kk, b, acc);
@@ -201,40 +184,10 @@ __device__ __forceinline__ void store_global(const f32x4 (&v)[RT][NCT], float* _
     }
 }
 
-// xs (already times the row's power-of-two factor) -> its three fp16 pieces, four features at a time.  Three forms of the residual
-// (x - p) 2^11, all exact and therefore the same bits: 0 = convert the piece back, subtract, multiply (10 instructions per four
-// features); 1 = fma(p, -2^11, x 2^11) written in C (the compiler packs it behind the conversions: 8); 2 = the same fma as
-// v_fma_mix_f32, which reads the fp16 piece itself (6).  Measured on one box, layer 0 / layer 1 (tools/ablate_gin_layer.py
-// F0..F2): 0.408 / 0.624-0.629, 0.411-0.416 / 0.628-0.631, 0.410 / 0.614-0.622 ms — the ~190 vector instructions per wave the
-// third form saves are not what binds the layer (section 13.2), so the plain form stays the default.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#ifndef GNNPN_GIN_SPLIT_FORM
-#define GNNPN_GIN_SPLIT_FORM 0
-#endif
-// fma(half `hi` of the fp16 pair `pair`, neg_scale, c) with the piece read as fp16 by the instruction itself
-template <int HI>
-__device__ __forceinline__ float fma_mix_f16(unsigned pair, float neg_scale, float c) {
-    float d;
-    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "s"(neg_scale), "v"(c));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "s"(neg_scale), "v"(c));
-    return d;
-}
+// xs (already times the row's power-of-two factor) -> its three fp16 pieces, four features at a time; every residual (x - p) 2^11 is
+// exact: convert the piece back, subtract, multiply.
 __device__ __forceinline__ f32x4 residual_x4(const f32x4 x, const f16x4 p) {
-#if GNNPN_GIN_SPLIT_FORM == 0
     return (x - __builtin_convertvector(p, f32x4)) * SPLIT_SCALE;
-#elif GNNPN_GIN_SPLIT_FORM == 1
-    const f32x4 up = x * SPLIT_SCALE;
-    f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fmaf((float)p[i], -SPLIT_SCALE, up[i]);
-    return r;
-#else
-    const f32x4 up = x * SPLIT_SCALE;
-    const u32x2 pp = __builtin_bit_cast(u32x2, p);
-    const float ns = -SPLIT_SCALE;
-    return f32x4{fma_mix_f16<0>(pp[0], ns, up[0]), fma_mix_f16<1>(pp[0], ns, up[1]), fma_mix_f16<0>(pp[1], ns, up[2]),
-                 fma_mix_f16<1>(pp[1], ns, up[3])};
-#endif
 }
 __device__ __forceinline__ void split3x4(const f32x4 xs, f16x4& p0, f16x4& p1, f16x4& p2) {
     p0 = __builtin_convertvector(xs, f16x4);
@@ -278,19 +231,14 @@ __device__ __forceinline__ void split_rows_to_lds(const f32x4 (&v)[NP][RT][NCT],
                 split3x4(v[p][rt][n] * up, p0, p1, p2);
                 _Float16* at = dst + row * ld + 16 * (ct0[p] + n) + 4 * kq;
                 *reinterpret_cast<f16x4*>(at) = p0;
-#if !(GNNPN_GIN_ABLATE & 8)
                 *reinterpret_cast<f16x4*>(at + piece) = p1;
                 *reinterpret_cast<f16x4*>(at + 2 * piece) = p2;
-#endif
             }
     }
 }
 
 template <bool LIN3>
-#ifndef GNNPN_GIN_WGS
-#define GNNPN_GIN_WGS 2
-#endif
-__global__ __launch_bounds__(256, GNNPN_GIN_WGS) void gin_layer_split_kernel(
+__global__ __launch_bounds__(256, 2) void gin_layer_split_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ x, int64_t ldx, int32_t c_in,
     const float* __restrict__ eps, const unsigned char* __restrict__ w1, const float* __restrict__ i1, const float* __restrict__ b1,
     const float* __restrict__ a1, const float* __restrict__ s1, const unsigned char* __restrict__ w2, const float* __restrict__ i2,
@@ -319,9 +267,6 @@ __global__ __launch_bounds__(256, GNNPN_GIN_WGS) void gin_layer_split_kernel(
             e0 = rowptr[row];
             e1 = rowptr[row + 1];
         }
-#if GNNPN_GIN_ABLATE & 4
-        e0 = e1;
-#endif
         if (r < 32) prefetch_b(w1, 4 * wave, k1a / 32, lane, q);   // the first product's first weights travel under the aggregate's gathers
         float4 acc[NCH_MAX];
 #pragma unroll

@@ -5,17 +5,6 @@
 #pragma once
 #include "common.h"
 
-// Diagnostic builds only (tools/ablate_aggregate.py compiles a second library with -DGNNPN_AGG_ABLATE=<bits> and times it;
-// the results of such a build are WRONG by design and it is never the library the package loads by default):
-//   1 no LDS reads (the address arithmetic stays), 2 one add instead of the two multiplies and two adds per (edge, lane),
-//   4 no tile fill, 8 no result stores, 16 no stream loads (graph_tiled.hip).
-#ifndef GNNPN_AGG_ABLATE
-#define GNNPN_AGG_ABLATE 0
-#endif
-#ifndef GNNPN_LDS_W_AT_USE
-#define GNNPN_LDS_W_AT_USE 0
-#endif
-
 // value of lane L of the own group of LPR (4, 2 or 1) consecutive lanes, as a DPP quad permute (no LDS round trip)
 template <int LPR, int L>
 __device__ __forceinline__ int quad_from(int v) {
@@ -35,34 +24,16 @@ __device__ __forceinline__ void lds_agg_read4(const char* __restrict__ tile, con
                                               int lane_off, float4 (&xv)[4], float (&wq)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-#if GNNPN_AGG_ABLATE & 1
-        const float av = __int_as_float(quad_from<LPR, P>(cc[k]) + lane_off);
-        xv[k] = make_float4(av, av, av, av);
-#else
         xv[k] = *reinterpret_cast<const float4*>(tile + (quad_from<LPR, P>(cc[k]) + lane_off));
-#endif
-#if !GNNPN_LDS_W_AT_USE
         if (HAS_W) wq[k] = __int_as_float(quad_from<LPR, P>(__float_as_int(ww[k])));
-#endif
     }
 }
 
-// ... and adds them in edge order.  (GNNPN_LDS_W_AT_USE, an experiment of graph_tiled.hip: the weight's quad permute right before
-// its multiply instead of beside the read — four registers per read group live for a shorter time)
+// ... and adds them in edge order
 template <bool HAS_W, int LPR = 4, int P = 0>
-__device__ __forceinline__ void lds_agg_add4(const float4 (&xv)[4], const float (&wq_in)[4], f32x2& a01, f32x2& a23) {
+__device__ __forceinline__ void lds_agg_add4(const float4 (&xv)[4], const float (&wq)[4], f32x2& a01, f32x2& a23) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-#if GNNPN_LDS_W_AT_USE
-        float wq[4];
-        wq[k] = HAS_W ? __int_as_float(quad_from<LPR, P>(__float_as_int(wq_in[k]))) : 0.0f;
-#else
-        const float (&wq)[4] = wq_in;
-#endif
-#if GNNPN_AGG_ABLATE & 2
-        a01 = a01 + f32x2{xv[k].x, HAS_W ? wq[k] : xv[k].y};
-        continue;
-#endif
         f32x2 lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
         if (HAS_W) {
             const f32x2 w2 = {wq[k], wq[k]};
@@ -80,16 +51,6 @@ __device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, c
                                                 int lane_off, f32x2& a01, f32x2& a23) {
     float4 xa[4], xb[4];
     float wa[4], wb[4];
-#if GNNPN_LDS_W_AT_USE
-    lds_agg_read4<LPR, HAS_W, 0>(tile, cc, ww, lane_off, xa, wa);
-    if (NP > 1) lds_agg_read4<LPR, HAS_W, 1 % LPR>(tile, cc, ww, lane_off, xb, wb);
-    lds_agg_add4<HAS_W, LPR, 0>(xa, ww, a01, a23);
-    if (NP > 2) lds_agg_read4<LPR, HAS_W, 2 % LPR>(tile, cc, ww, lane_off, xa, wa);
-    if (NP > 1) lds_agg_add4<HAS_W, LPR, 1 % LPR>(xb, ww, a01, a23);
-    if (NP > 3) lds_agg_read4<LPR, HAS_W, 3 % LPR>(tile, cc, ww, lane_off, xb, wb);
-    if (NP > 2) lds_agg_add4<HAS_W, LPR, 2 % LPR>(xa, ww, a01, a23);
-    if (NP > 3) lds_agg_add4<HAS_W, LPR, 3 % LPR>(xb, ww, a01, a23);
-#else
     lds_agg_read4<LPR, HAS_W, 0>(tile, cc, ww, lane_off, xa, wa);
     if (NP > 1) lds_agg_read4<LPR, HAS_W, 1 % LPR>(tile, cc, ww, lane_off, xb, wb);
     lds_agg_add4<HAS_W>(xa, wa, a01, a23);
@@ -98,6 +59,5 @@ __device__ __forceinline__ void lds_agg_consume(const char* __restrict__ tile, c
     if (NP > 3) lds_agg_read4<LPR, HAS_W, 3 % LPR>(tile, cc, ww, lane_off, xb, wb);
     if (NP > 2) lds_agg_add4<HAS_W>(xa, wa, a01, a23);
     if (NP > 3) lds_agg_add4<HAS_W>(xb, wb, a01, a23);
-#endif
 }
 

@@ -43,33 +43,12 @@ constexpr int META_WORDS = 128;
 constexpr int PASSES_MAX = 10;            // destination rows per lane group: 10 x 4 accumulator registers
 constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, META_STREAM_ROWS = 4, META_HIST = 8, HIST_BINS = 64;
 
-// (experiment switches: 8 waves with 1279-row tiles = two workgroups per CU; measured slower, see the notes below / DESIGN.md 13.1)
-#ifndef GNNPN_TILED_WAVES
-#define GNNPN_TILED_WAVES 16
-#endif
-#ifndef GNNPN_TILED_TILE_ROWS
-#define GNNPN_TILED_TILE_ROWS 2559
-#endif
-// (experiment switch: 1 = one workgroup per CU that walks its XCD's items in a loop, the register-staged fill of the next item's
-// first tile right behind this item's stores — 0.665 / 0.841 / 0.496 ms against 0.645 / 0.787 / 0.452 at 2507 x 256 / 5000 x 128 /
-// 20000 x 8 (tools/ablate_aggregate.py build+run P0= P1=-DGNNPN_TILED_PERSISTENT=1): the hardware's dispatch of 4096 workgroups
-// balances the CUs better than a static walk, and a workgroup launch costs less than the imbalance)
-#ifndef GNNPN_TILED_FILL_LATER
-#define GNNPN_TILED_FILL_LATER 5                        // rows in flight per lane when a later source tile is filled (the accumulators are live)
-#endif
-#ifndef GNNPN_TILED_SHARED_PLAN
-#define GNNPN_TILED_SHARED_PLAN 0
-#endif
-#ifndef GNNPN_TILED_PERSISTENT
-#define GNNPN_TILED_PERSISTENT 0
-#endif
-#if GNNPN_TILED_PERSISTENT
-#define GNNPN_TILED_NEXT continue
-#else
-#define GNNPN_TILED_NEXT return
-#endif
-constexpr int WAVES = GNNPN_TILED_WAVES;  // wavefronts per workgroup: 16 = one workgroup per CU
-constexpr int TILE_ROWS_MAX = GNNPN_TILED_TILE_ROWS;   // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
+// (The variants that were measured and not kept — 8 waves with half-size tiles, a persistent walk, a shared plan, eight quads of
+// stream look-ahead, deeper fills — and the timing-only ablation builds live in tools/experiments/aggregate_switches.patch, applied by
+// tools/ablate_aggregate.py; profiles/LOG_r04.md has the numbers.)
+constexpr int WAVES = 16;                 // wavefronts per workgroup: one workgroup per CU
+constexpr int TILE_ROWS_MAX = 2559;       // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
+constexpr int FILL_LATER = 5;             // rows in flight per lane when a later source tile is filled (the accumulators are live)
 constexpr int DST_ROWS_MAX = WAVES * 16 * PASSES_MAX;   // destination rows per workgroup: 10 passes of 256 rows (1024 lanes, 4 per row)
 
 struct Geom {
@@ -285,62 +264,15 @@ __device__ __forceinline__ void tiled_unit(const char* __restrict__ bp, const ch
         const int cc[4] = {(int)co.x, (int)co.y, (int)co.z, (int)co.w};
         const float ww[4] = {__uint_as_float(wv.x), __uint_as_float(wv.y), __uint_as_float(wv.z), __uint_as_float(wv.w)};
         bp += 2048;                                   // four quads
-#if !(GNNPN_AGG_ABLATE & 16)
         const char* src = nq > 4 ? bp : nb;           // this unit's next four quads, or the next unit's first four (wave-uniform)
         co = *reinterpret_cast<const uint4*>(src + lane_boff);            // scalar base + 32-bit lane offset
         wv = *reinterpret_cast<const uint4*>(src + lane_boff + 256);
-#endif
         if (nq >= 4) lds_agg_consume<4, true, 4>(tile_b, cc, ww, lane_off, a01, a23);
         else if (nq == 3) lds_agg_consume<4, true, 3>(tile_b, cc, ww, lane_off, a01, a23);
         else if (nq == 2) lds_agg_consume<4, true, 2>(tile_b, cc, ww, lane_off, a01, a23);
         else lds_agg_consume<4, true, 1>(tile_b, cc, ww, lane_off, a01, a23);
         nq -= 4;
         if (nq <= 0) break;
-    }
-}
-
-#ifndef GNNPN_TILED_DEEP
-#define GNNPN_TILED_DEEP 0
-#endif
-// (experiment, GNNPN_TILED_DEEP=1) The same walk with EIGHT quads of look-ahead: (c0, w0) hold quads 0..3 and (c1, w1) quads 4..7
-// of the unit on entry (the second pair only if the unit has more than four), and of the next unit — nq_next quads at nb — on
-// exit; each pair is re-requested right after it has been copied out, so a unit's stream is on its way a whole unit earlier.
-__device__ __forceinline__ void load_pair(const char* __restrict__ at, unsigned lane_boff, uint4& c, uint4& w) {
-    c = *reinterpret_cast<const uint4*>(at + lane_boff);
-    w = *reinterpret_cast<const uint4*>(at + lane_boff + 256);
-}
-template <int NQ>
-__device__ __forceinline__ void consume_upto4(int nq, const char* __restrict__ tile_b, const int (&cc)[4], const float (&ww)[4], int lane_off,
-                                              f32x2& a01, f32x2& a23) {
-    if (nq >= 4) lds_agg_consume<4, true, 4>(tile_b, cc, ww, lane_off, a01, a23);
-    else if (nq == 3) lds_agg_consume<4, true, 3>(tile_b, cc, ww, lane_off, a01, a23);
-    else if (nq == 2) lds_agg_consume<4, true, 2>(tile_b, cc, ww, lane_off, a01, a23);
-    else lds_agg_consume<4, true, 1>(tile_b, cc, ww, lane_off, a01, a23);
-}
-__device__ __forceinline__ void tiled_unit_deep(const char* __restrict__ bp, const char* __restrict__ nb, int nq_next, unsigned lane_boff,
-                                                int nq, uint4& c0, uint4& w0, uint4& c1, uint4& w1, const char* __restrict__ tile_b,
-                                                int lane_off, f32x2& a01, f32x2& a23) {
-    for (;;) {
-        const bool more = nq > 8;                                         // this unit goes on after these eight quads
-        const char* nx = more ? bp + 4096 : nb;                           // where the following eight quads are
-        const int nq_nx = more ? nq - 8 : nq_next;
-        {
-            const int cc[4] = {(int)c0.x, (int)c0.y, (int)c0.z, (int)c0.w};
-            const float ww[4] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
-            load_pair(nx, lane_boff, c0, w0);
-            consume_upto4<0>(nq, tile_b, cc, ww, lane_off, a01, a23);
-        }
-        if (nq > 4) {
-            const int cc[4] = {(int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
-            const float ww[4] = {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w)};
-            if (nq_nx > 4) load_pair(nx + 2048, lane_boff, c1, w1);
-            consume_upto4<1>(nq - 4, tile_b, cc, ww, lane_off, a01, a23);
-        } else if (nq_nx > 4) {
-            load_pair(nx + 2048, lane_boff, c1, w1);
-        }
-        if (!more) break;
-        nq -= 8;
-        bp += 4096;
     }
 }
 
@@ -354,7 +286,7 @@ __device__ __forceinline__ int unit_of(int p, int wave) { return p * WAVES + ((p
 template <int DEPTH>
 __device__ __forceinline__ void fill_tile(float* __restrict__ tile, const float* __restrict__ src, int64_t ldx, int srows, int tid, int sub) {
     constexpr int RPP = WAVES * 16;
-    for (int rr = (GNNPN_AGG_ABLATE & 4) ? srows : (tid >> 2); rr < srows; rr += DEPTH * RPP) {
+    for (int rr = tid >> 2; rr < srows; rr += DEPTH * RPP) {
         float4 v[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
@@ -386,7 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int2* __restrict__ header, const int32_t* __restrict__ order, const float* __restrict__ selfw,
     const uint4* __restrict__ batches, const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef,
     const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ y, int64_t ldy, int32_t n_rows, Geom g, int32_t n_slices, int32_t n_jj) {
+    float* __restrict__ y, int64_t ldy, int32_t n_rows, Geom g, int32_t n_slices) {
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [TR + 1][16]: the source tile's slice and one all-zero row
     constexpr int RPP = WAVES * 16;                                       // rows per pass of the workgroup (4 lanes per row)
     // placement (speed only): the (destination tile, slice) workgroups of one block get equal blockIdx % 8 — one XCD — so
@@ -394,33 +326,18 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int xcd = blockIdx.x & 7;
     const int per_block = g.ND * n_slices;
     const int tid = threadIdx.x, sub = tid & 3, lane = tid & 63, wave = tid >> 6;
-#if GNNPN_TILED_PERSISTENT
-    // one workgroup per CU walks its XCD's items: the next item's first fill is requested right behind this item's stores
-    // (no drain of the stores, no workgroup launch, between two items)
-    bool first_item = true;
-    for (int jj = blockIdx.x >> 3; jj < n_jj; jj += (int)(gridDim.x >> 3)) {
-    if (!first_item) __syncthreads();                                     // every gather from the previous item's last tile is done
-    first_item = false;
-#else
     const int jj = blockIdx.x >> 3;
-    (void)n_jj;
-    {
-#endif
     const int b = (jj / per_block) * 8 + xcd;
-    if (b >= g.n_blocks) GNNPN_TILED_NEXT;
+    if (b >= g.n_blocks) return;
     const int d = (jj % per_block) / n_slices, s = (jj % per_block) % n_slices;
     const int r0 = b * g.R, Rb = min(g.R, n_rows - r0);
-    if (Rb - d * g.DR <= 0) GNNPN_TILED_NEXT;                             // ragged last block: no rows in this destination tile
+    if (Rb - d * g.DR <= 0) return;                             // ragged last block: no rows in this destination tile
     const int c = s * 16 + 4 * sub;
     const char* tile_b = reinterpret_cast<const char*>(tile);
     const int lane_off = 16 * sub;
     const unsigned lane_boff = (unsigned)(sub * 512 + (lane >> 2) * 16);  // this lane's 16 bytes of quad `sub` of a unit, from the unit's first byte
     const char* stream_b = reinterpret_cast<const char*>(batches);
-#if GNNPN_TILED_SHARED_PLAN
-    const int64_t bd = d;                                                 // (experiment: every block walks block 0's plan — right only for identical blocks)
-#else
     const int64_t bd = (int64_t)b * g.ND + d;
-#endif
     if (tid < 16) tile[g.TR * 16 + tid] = 0.0f;                          // the all-zero row: no fill writes it
     // the headers {first quad, quads} of this wavefront's units in EVERY source tile, fetched once: entry e = t * PASSES + p
     // sits in lane e % 64 of register e / 64 and is read back into scalar registers where it is needed
@@ -453,26 +370,15 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         a23[p] = f32x2{0.f, 0.f};
     }
     uint4 co, wv;                                                         // the pair of loads in flight (tiled_unit)
-#if GNNPN_TILED_DEEP
-    uint4 co1 = make_uint4(0, 0, 0, 0), wv1 = make_uint4(0, 0, 0, 0);     // ... and the second pair (tiled_unit_deep)
-#endif
-#if GNNPN_AGG_ABLATE & 16
-    co = make_uint4(lane_off * 64u, lane_off * 128u, lane_off * 192u, lane_off * 256u);
-    wv = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);
-#else
     {
         const char* b0 = stream_b + (int64_t)first_of(0) * 512;
         co = *reinterpret_cast<const uint4*>(b0 + lane_boff);
         wv = *reinterpret_cast<const uint4*>(b0 + lane_boff + 256);
-#if GNNPN_TILED_DEEP
-        if (quads_of(0) > 4) load_pair(b0 + 2048, lane_boff, co1, wv1);
-#endif
     }
-#endif
     for (int t = 0; t < g.NT; ++t) {
         if (t) {
             __syncthreads();                                              // every gather from the previous tile is done
-            fill_tile<GNNPN_TILED_FILL_LATER>(tile, x + (int64_t)(r0 + t * g.TR) * ldx + c, ldx, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
+            fill_tile<FILL_LATER>(tile, x + (int64_t)(r0 + t * g.TR) * ldx + c, ldx, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
         }
         __syncthreads();
 #pragma unroll
@@ -482,25 +388,12 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
             // the unit after this one (the next pass, or the first pass of the next source tile; after the last: any valid address)
             const int e_next = e + 1 < g.NT * PASSES ? e + 1 : 0;
             const char* nb = stream_b + (int64_t)first_of(e_next) * 512;
-#if GNNPN_TILED_DEEP
-            const int nq_next = e + 1 < g.NT * PASSES ? quads_of(e_next) : 0;
-            if (nq > 0) {
-                tiled_unit_deep(stream_b + (int64_t)first_of(e) * 512, nb, nq_next, lane_boff, nq, co, wv, co1, wv1, tile_b, lane_off,
-                                a01[p], a23[p]);
-            } else {
-                load_pair(nb, lane_boff, co, wv);
-                if (nq_next > 4) load_pair(nb + 2048, lane_boff, co1, wv1);
-            }
-#else
             if (nq > 0) {
                 tiled_unit(stream_b + (int64_t)first_of(e) * 512, nb, lane_boff, nq, co, wv, tile_b, lane_off, a01[p], a23[p]);
             } else {                                  // no edges into this tile: the pair in flight was this unit's — replace it
-#if !(GNNPN_AGG_ABLATE & 16)
                 co = *reinterpret_cast<const uint4*>(nb + lane_boff);
                 wv = *reinterpret_cast<const uint4*>(nb + lane_boff + 256);
-#endif
             }
-#endif
         }
     }
     // ---- epilogue: the trailing self loop of rows outside the last source tile, then what the gather form's epilogue does
@@ -567,10 +460,8 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         if (rl[p] < 0) continue;
-        if (!(GNNPN_AGG_ABLATE & 8) || a01[p].x == 1.2345e30f)
-            *reinterpret_cast<float4*>(y + (r0 + rl[p]) * ldy + c) = make_float4(a01[p].x, a01[p].y, a23[p].x, a23[p].y);
+        *reinterpret_cast<float4*>(y + (r0 + rl[p]) * ldy + c) = make_float4(a01[p].x, a01[p].y, a23[p].x, a23[p].y);
     }
-    }   // item
 }
 
 }  // namespace
@@ -654,15 +545,6 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
     const unsigned lds = (unsigned)(g.TR + 1) * 64u;
     const int n_jj = ((g.n_blocks + 7) / 8) * g.ND * n_slices;
     dim3 grid((unsigned)(n_jj * 8)), block(WAVES * 64);
-#if GNNPN_TILED_PERSISTENT
-    {
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8)
-            GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot query the device");
-        const unsigned per_xcd = (unsigned)(n_cu / 8) * (unsigned)(16 / WAVES > 0 ? 16 / WAVES : 1);
-        if (grid.x > per_xcd * 8) grid.x = per_xcd * 8;
-    }
-#endif
     hipStream_t st = (hipStream_t)stream;
 #define GNNPN_AGG_TILED(P_, H_)                                                                                             \
     do {                                                                                                                  \
@@ -671,7 +553,7 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
             GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot reserve %u B of LDS", lds);                           \
         hipLaunchKernelGGL((csr_aggregate_tiled_kernel<P_, H_>), grid, block, lds, st, reinterpret_cast<const int2*>(header), \
                            order, selfw, static_cast<const uint4*>(batches), x, ldx, self_coef, bias, scale, shift, act, \
-                           y, ldy, n_rows, g, n_slices, n_jj);                                                            \
+                           y, ldy, n_rows, g, n_slices);                                                            \
     } while (0)
     // more than 64 (source tile, pass) headers per wavefront only occur with 7 or 8 source tiles, i.e. full destination tiles
     switch (g.passes) {

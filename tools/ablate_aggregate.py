@@ -4,7 +4,8 @@ kernel removed each — compiled here (no GPU needed), timed on the GPU box.
     python tools/ablate_aggregate.py build                 # compiles gnnpn-sc_amd/build/ablate/libgnnpn_hip_abl<bits>.so
     python tools/ablate_aggregate.py run [S:copies ...]    # on the GPU: times every build on the tiled form
 
-bits (csrc/graph_lds.h): 1 no LDS reads, 2 one add instead of 2 multiplies + 2 adds per (edge, lane), 4 no tile fill,
+The switches are NOT in the product sources (round 5): tools/experiments/aggregate_switches.patch adds them to a copy of csrc/.
+bits: 1 no LDS reads, 2 one add instead of 2 multiplies + 2 adds per (edge, lane), 4 no tile fill,
 8 no result stores, 16 no stream loads.
 """
 import json, os, subprocess, sys
@@ -13,6 +14,18 @@ PKG = os.path.join(ROOT, "gnnpn-sc_amd")
 OUT = os.path.join(PKG, "build", "ablate")
 VARIANTS = [0, 1, 2, 3, 4, 8, 12, 16, 19, 31]
 EXTRA = {}            # name -> -D flags of an experiment build: python tools/ablate_aggregate.py build P1=-DGNNPN_TILED_PERSISTENT=1 ...
+
+
+def patched_csrc(patch):
+    """A copy of csrc/ (+ include/) with tools/experiments/<patch> applied: the product sources carry no experiment switch, the
+    timing-only builds are compiled from this copy."""
+    import shutil
+    dst = os.path.join(OUT, "src_" + patch.replace(".patch", ""))
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(os.path.join(dst, "gnnpn-sc_amd"), exist_ok=True)
+    shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(dst, "gnnpn-sc_amd", "csrc"))
+    subprocess.run(["git", "apply", "--unsafe-paths", "--directory=" + dst, os.path.join(ROOT, "tools", "experiments", patch)], check=True, cwd=ROOT)
+    return os.path.join(dst, "gnnpn-sc_amd", "csrc")
 
 
 def build():
@@ -25,11 +38,13 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     objs = [os.path.join(PKG, "build", s.replace(".hip", ".o")) for s in b.SOURCES]
     todo = {v: [f"-DGNNPN_AGG_ABLATE={v}"] for v in VARIANTS} if not EXTRA else EXTRA
+    csrc = patched_csrc("aggregate_switches.patch")
+    flags0 = [f for f in b.FLAGS if f != "-I" + b.CSRC] + ["-I" + csrc]
     for v, flags in todo.items():
         mine = []
         for src in ("graph.hip", "graph_tiled.hip"):
             o = os.path.join(OUT, f"{src[:-4]}_abl{v}.o")
-            subprocess.run(["hipcc"] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", o], check=True)
+            subprocess.run(["hipcc"] + flags0 + flags + ["-c", os.path.join(csrc, src), "-o", o], check=True)
             mine.append(o)
         rest = [o for o in objs if os.path.basename(o) not in ("graph.o", "graph_tiled.o")]
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(OUT, f"libgnnpn_hip_abl{v}.so")] + rest + mine, check=True)

@@ -4,7 +4,7 @@ O=gpurun_out/r05_slip; mkdir -p $O
 for i in 1 2 3; do
   for cfg in "0:0" "0:78" "400:0"; do
     us=${cfg%%:*}; kb=${cfg#*:}
-    GNNPN_PIPE_COMMON_START_US=$us GNNPN_EXP_FRONT_LDS_KB=$kb timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision --no-kernel-timers > $O/run_${us}_${kb}_$i.json 2> $O/run_${us}_${kb}_$i.err
+    GNNPN_PIPE_COMMON_START_US=$us GNNPN_PIPE_FRONT_LDS_KB=$kb timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision --no-kernel-timers > $O/run_${us}_${kb}_$i.json 2> $O/run_${us}_${kb}_$i.err
     python - <<PY
 import json
 d=json.loads([l for l in open("$O/run_${us}_${kb}_$i.json") if l.startswith("{")][-1])

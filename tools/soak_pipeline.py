@@ -1,6 +1,11 @@
 """Soak test of the two-slot pipeline: N steps with a different batch every step, every output compared with a
 single-stream run of the same batch (bit for bit), hand-off status checked at the end.
-Usage: soak_pipeline.py [N] [precision] [workload] [batch]   (batches of 512 and more exercise the half-batch pairing)"""
+Usage: soak_pipeline.py [N] [precision] [workload] [batch]   (batches of 512 and more exercise the half-batch pairing)
+Environment: SOAK_POLL_EVERY=n  the runner's poll() every n steps (default 500): status 0 and the proof of work — workgroup-tiles
+                                finished == expected == the host's count — at EVERY poll, or the soak fails;
+             SOAK_DIST=1        a real RCCL process group of world size 1 and the path's single collective, the asynchronous
+                                all-gather of the selected indices, behind every step on the group's own stream (what a rank of
+                                `bench.py --gpus N` does)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnpn_sc_amd import ops, synth
@@ -19,7 +24,13 @@ svc = DeviceServices.from_table(table, dev)
 n_var = 12
 batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, w["B"], seed=100 + i, tasks_per_problem=w["n_t"]), dev)
            for i in range(n_var)]
-runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+runner = PipelinedRunner(pipe, svc, batches[0], slots=2, auto_degrade=False)
+poll_every = int(os.environ.get("SOAK_POLL_EVERY", 500))
+use_dist = os.environ.get("SOAK_DIST") == "1"
+if use_dist:
+    from gnnpn_sc_amd import dist as gdist
+    gdist.init_process_group("nccl", dev)
+gathers, polls, bad_polls = {}, 0, 0
 refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]           # single stream, same kernels
 torch.cuda.synchronize()
 keys = ("idx_low", "idx_high", "R", "actions", "win_low", "win_high_raw")
@@ -27,7 +38,13 @@ bad, t0 = 0, time.time()
 pending = []                                          # (step, slot, variant, event)
 for i in range(N):
     v = (i * 7 + i // 5) % n_var
+    if use_dist and gathers.get(runner.count % runner.n_slots, (None, None))[1] is not None:
+        with torch.cuda.stream(runner.stream(runner.count % runner.n_slots)):
+            gathers[runner.count % runner.n_slots][1].wait()          # the previous gather out of this slot's index buffer is done
     out, s = runner.submit(batches[v])
+    if use_dist:
+        with torch.cuda.stream(runner.stream(s)):
+            gathers[s] = gdist.all_gather_indices_async(out["idx_high"], gathers.get(s, (None, None))[0])
     ev = torch.cuda.Event(); ev.record(runner.stream(s))
     snap = None
     pending.append((i, s, v, ev, out))
@@ -42,6 +59,22 @@ for i in range(N):
                       f"[error word, same-XCD workgroups, off-canonical seats, -]: enc {wsj.encode()[:16].view(torch.int32).tolist()} "
                       f"dec {wsj._decode[:16].view(torch.int32).tolist()}; sticky {[int(x.status[0]) for x in runner.workspaces]}", flush=True)
                 break
+    if poll_every and (i + 1) % poll_every == 0:
+        for g_, w_ in gathers.values():
+            if w_ is not None:
+                w_.wait()
+        word = runner.poll()
+        polls += 1
+        prog = runner.progress()
+        ok = word == 0 and all(p[part]["finished"] == p[part]["expected"] == p[part]["host_expected"] for p in prog for part in ("encoder", "decoder"))
+        if not ok:
+            bad_polls += 1
+            print(f"poll after step {i}: status {word:#x}, progress {prog}", flush=True)
+        for j, sj, vj, evj, oj in pending:            # everything submitted so far has finished: compare it before the slots are reused
+            for k in keys:
+                if not torch.equal(oj[k], refs[vj][k]):
+                    bad += 1; print(f"step {j}: {k} differs", flush=True); break
+        pending = []
 for j, sj, vj, evj, oj in pending:
     evj.synchronize()
     for k in keys:
@@ -50,5 +83,10 @@ for j, sj, vj, evj, oj in pending:
 if bad:
     print("failure record (first entries):", ops.decode_failure_record(clear=False))
 ops.check_status(dev)
-print(f"{N} steps ({prec}), {bad} mismatching, {time.time() - t0:.1f} s")
-sys.exit(1 if bad else 0)
+import json
+print(json.dumps({"steps": N, "precision": prec, "workload": sys.argv[3] if len(sys.argv) > 3 else "qws", "batch": w["B"], "rccl_world1_all_gather_per_step": use_dist,
+                  "mismatching_steps": bad, "polls": polls, "polls_with_status_or_shortfall": bad_polls, "progress_at_end": runner.progress() if polls else None,
+                  "write_through": runner.write_through, "front_lds_kb": runner.front_lds_kb, "seconds": round(time.time() - t0, 1)}))
+if use_dist:
+    gdist.destroy(2)
+sys.exit(1 if (bad or bad_polls) else 0)
