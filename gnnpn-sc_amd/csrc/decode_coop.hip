@@ -573,11 +573,11 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     for (int n = 0; n < n_nets; ++n)
         if ((args.net[n].xw_fold != nullptr) != fold)
             GNNPN_FAIL(GNNPN_E_ARG, "pointer_decode: all nets of a call must use the same input-side form");
-    {   // the shipped configuration (folded input side, greedy picks) runs on the production build, decode_lean.hip;
-        // lstm_ablate bit 6 keeps it on this kernel (A/B runs of tools/ and the both-kernels test)
+    {   // the shipped configuration (folded input side, greedy picks) runs on the production build, decode_lean.hip; this file
+        // keeps the two builds that one does not cover: the literal two-stage input side and the sampling decoder
         bool any_sample0 = false;
         for (int n = 0; n < n_nets; ++n) any_sample0 |= args.net[n].sample != 0;
-        if (fold && !any_sample0 && !(gnnpn_option_lstm_ablate() & 64) && args.K <= 16)
+        if (fold && !any_sample0 && args.K <= 16)
             return gnnpn_launch_decode_lean(args, n_nets, precision, shared_cu, opts, workspace, workspace_bytes, s);
     }
     const int n_tiles = (args.B + ROWS - 1) / ROWS;
@@ -607,39 +607,23 @@ int gnnpn_launch_decode_coop(const DecodeArgs& args, int n_nets, int precision, 
     u64* p_p = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes);
     u64* p_l = reinterpret_cast<u64*>(base + COOP_STATUS_BYTES + h_bytes + p_bytes);
     unsigned* p_err = reinterpret_cast<unsigned*>(base);
-    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000 | 0x2000)) | (opts.write_through ? 128 : 0);   // bit 13: the launch's zeroing (above)
+    const int abl = opts.write_through ? 128 : 0;
     unsigned* p_s = opts.sticky;
-    const bool split = precision == GNNPN_PREC_SPLIT;   // "split" precision: fp16 hi+lo operands in W_hh.h
-    if (split && (!fold || (abl & 32)))
-        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the split-operand form is built for the folded input side only");
+    if (precision == GNNPN_PREC_SPLIT)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the exact-split arithmetic is built for the folded input side with greedy picks (decode_lean.hip)");
+    if (shared_cu)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side with greedy picks only");
     const int lds_kb = opts.lds_kb;
-#define GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, EVH_)                                                                   \
-    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>), dim3(COOP_OVERSUB * groups * G), dim3(256),     \
-                       coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, DIAG_, SPLIT_, OCC_, EVH_>, lds_kb), \
-                       s, args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl, p_seats)
-#define GNNPN_DEC8(FOLD_, DIAG_, SPLIT_, OCC_) GNNPN_DEC8X(FOLD_, DIAG_, SPLIT_, OCC_, (OCC_ == 2 ? 2 : 1))
     bool any_sample = false;
     for (int n = 0; n < n_nets; ++n) any_sample |= args.net[n].sample != 0;
-    if (any_sample) {
-        if (!fold || split || (abl & 32))
-            GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the sampling build exists for the folded fp32 input side only");
-        hipLaunchKernelGGL((pointer_decode_coop_kernel<true, false, false, 1, 1, true>), dim3(COOP_OVERSUB * groups * G), dim3(256),
-                           coop_lds_padding((const void*)pointer_decode_coop_kernel<true, false, false, 1, 1, true>, lds_kb), s,
-                           args, p_h, p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl, p_seats);
-        return GNNPN_OK;
-    }
-    if (shared_cu && (!fold || (abl & 32)))
-        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the 2-per-CU build exists for the folded input side only");
-    const bool wide_k = args.K > 8;                       // two threads per (row, candidate) need 2*16*K <= 256
-    if (split && shared_cu && wide_k) GNNPN_DEC8X(true, false, true, 2, 1);
-    else if (split && shared_cu) GNNPN_DEC8(true, false, true, 2);
-    else if (split) GNNPN_DEC8(true, false, true, 1);
-    else if (shared_cu && wide_k) GNNPN_DEC8X(true, false, false, 2, 1);
-    else if (shared_cu) GNNPN_DEC8(true, false, false, 2);
-    else if (fold && (abl & 32)) GNNPN_DEC8(true, true, false, 1);
-    else if (fold) GNNPN_DEC8(true, false, false, 1);
-    else GNNPN_DEC8(false, false, false, 1);
+    if (any_sample && !fold)
+        GNNPN_FAIL(GNNPN_E_UNSUP, "pointer_decode: the sampling build exists for the folded fp32 input side only");
+#define GNNPN_DEC8(FOLD_, SAMPLE_)                                                                                                       \
+    hipLaunchKernelGGL((pointer_decode_coop_kernel<FOLD_, false, false, 1, 1, SAMPLE_>), dim3(COOP_OVERSUB * groups * G), dim3(256),          \
+                       coop_lds_padding((const void*)pointer_decode_coop_kernel<FOLD_, false, false, 1, 1, SAMPLE_>, lds_kb), s, args, p_h, \
+                       p_p, p_l, p_err, p_s, n_nets, groups_per_net, gpx, abl, p_seats)
+    if (any_sample) GNNPN_DEC8(true, true);       // folded input side, every pick drawn from the window softmax
+    else GNNPN_DEC8(false, false);                // the literal two-stage input side (embedding2, then W_ih), greedy
 #undef GNNPN_DEC8
-#undef GNNPN_DEC8X
     return GNNPN_OK;
 }

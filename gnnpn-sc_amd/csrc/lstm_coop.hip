@@ -426,7 +426,7 @@ int gnnpn_launch_encode_coop(const LstmNets& nets, int n_nets, int32_t B, int32_
         if ((nets.pregates[n] != nullptr) != pre)
             GNNPN_FAIL(GNNPN_E_ARG, "lstm_encode: all nets of a call must use the same input-side form");
     const int prec = precision;   // GNNPN_PREC_*: 0 fp32, 1 fp16 operands, 2 fp16-split operands
-    const int abl = (gnnpn_option_lstm_ablate() & ~(64 | 0x800 | 0x1000 | 0x2000)) | (opts.write_through ? 128 : 0);   // bits 6 and 11 belong to the decoder, 13 to the launch (above)
+    const int abl = (gnnpn_option_lstm_ablate() & ~(0x800 | 0x1000 | 0x2000)) | (opts.write_through ? 128 : 0);   // bit 11 belongs to the decoder (phase stamps), 13 to the launch (above)
     const int abl_arg = abl | (opts.paired_start ? 0x1000 : 0);   // bit 12 rides the kernel argument only (placement, coop_place)
     const int lds_kb = opts.lds_kb;
     unsigned* p_s = opts.sticky;

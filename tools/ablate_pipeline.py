@@ -11,7 +11,7 @@ table = synth.make_service_table(w["T"], w["S"], seed=0, degree=32)
 net, low, high = bench.build_models(w["T"], w["S"], w["K"], dev, w["n_gcn"])
 svc = DeviceServices.from_table(table, dev)
 batch = DeviceBatch.from_problems(synth.make_problem_batch(table, w["B"], seed=1, tasks_per_problem=w["n_t"]), dev)
-for label, abl in (("production build", 0), ("diagnostic build, nothing ablated", 64), ("no MFMA", 1), ("no transcendentals", 2),
+for label, abl in (("production build", 0), ("no MFMA", 1), ("no transcendentals", 2),
                    ("no tag wait", 4), ("no sweep", 8), ("no sweep, no publish", 24), ("no enc_out flush, no input prefetch", 0x600)):
     ops.set_option("lstm_ablate", abl)
     pipe = ML2PNPipeline(net, low, high, w["K"])
