@@ -505,6 +505,8 @@ def main():
                     "(default: the workload's G, else its per-GPU batch)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps rotate over")
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step timed region until this many seconds")
+    ap.add_argument("--settle", type=int, default=24, help="at most this many UNTIMED rounds of K steps behind the warm-up, until three in a row "
+                    "agree within 2 %% (0: none — the first timed round follows the W warm-up steps directly); they are listed in timing.settling_round_us")
     ap.add_argument("--write-through", type=int, default=-1, help="hand-off form of the cooperative kernels: 1 = agent-scope write-through "
                     "granule stores (placement independent), 0 = stores that stay in the XCD's L2 (same-XCD groups), -1 = the library's default")
     ap.add_argument("--precision", default="split", choices=["f32", "f16", "split"],
@@ -744,11 +746,12 @@ def main():
         # whose other 86 rounds lay within 1 % (p10 .. p90).  Rounds are discarded until two in a row agree within 2 % with
         # the one before (at most 24; every rank sees the same maxima and stops settling together).
         settle = []
-        while args.min_time > 0 and len(settle) < 24:
+        while args.min_time > 0 and len(settle) < args.settle:
             settle.append(one_round())
             if len(settle) >= 3 and all(abs(settle[-k] - settle[-k - 1]) <= 0.02 * settle[-k] for k in (1, 2)):
                 break
         timed_rounds.settle = len(settle)
+        timed_rounds.settle_rounds = list(settle)     # reported in `timing` (what `value` leaves out is in the line)
         timed_rounds.local = []
         while True:
             dt = one_round()
@@ -766,6 +769,11 @@ def main():
                                   "p90": round(qt(0.9) * 1e3, 4), "max": round(r[-1] * 1e3, 4)},
                      "spread_pct": round((r[-1] - r[0]) / med * 100, 2), "p10_p90_spread_pct": round((qt(0.9) - qt(0.1)) / med * 100, 2),
                      "untimed_settling_rounds": getattr(timed_rounds, "settle", 0),
+                     # the discarded rounds themselves, in time order (--settle 0 times from the first round on): the first one is
+                     # the K steps right behind the W warm-up steps, as the bare contract would have timed them
+                     "settling_round_us": [int(v * 1e6) for v in getattr(timed_rounds, "settle_rounds", [])],
+                     "first_round_after_warmup_ms": (round(getattr(timed_rounds, "settle_rounds", [None])[0] * 1e3, 4)
+                                                     if getattr(timed_rounds, "settle_rounds", []) else round(rounds[0] * 1e3, 4)),
                      "round_us": [int(v * 1e6) for v in rounds[:128]]}        # in time order (regimes, drifts)
 
     gc.collect()
@@ -952,22 +960,40 @@ def main():
     value = world * B * args.steps / elapsed
     kernels = kernel_table(summary, n_timed, args.precision)
     # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
-    # profiles/r04_pmc_traffic.json (tools/r04_profiles.sh + tools/collect_profiles.py), FETCH_SIZE doubled as the gfx950 guide
+    # profiles/r05_pmc_traffic.json (tools/r05_profiles.sh + tools/collect_profiles.py; r04's while that one is absent), FETCH_SIZE doubled as the gfx950 guide
     # prescribes; only quoted when this run is a workload / batch / precision those passes measured.
     def pmc_traffic(precision):
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
+            name = next(n for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
             return {k: v["traffic"] for k, v in pmc.get(f"{args.workload}_b{B}_{precision}", {}).get("kernels", {}).items()}
         except (OSError, ValueError, KeyError):
             return {}
+    # Matrix-pipe utilisation of the two recurrent kernels (BASELINE north_star: "MFMA utilisation ... against gfx950 peak") from the
+    # committed SQ-counter passes of the same eager command (tools/r05_recurrent_sq.sh -> profiles/r05_recurrent_sq_summary.json):
+    # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).  Quoted, like `traffic`: rocprofv3 cannot run inside this process.
+    def sq_mfma_util(precision):
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_recurrent_sq_summary.json")) as f:
+                sq = json.load(f)["kernels"]
+            names = {"lstm_encode": "lstm_encode_coop_kernel", "pointer_decode": "pointer_decode_lean_kernel"}
+            return {k: sq[f"{args.workload}/{precision}/{n}"]["derived"]["mfma_busy_frac_of_all_simds"] for k, n in names.items()
+                    if f"{args.workload}/{precision}/{n}" in sq and B == WORKLOADS[args.workload]["B"]}     # the passes ran the default batch
+        except (OSError, ValueError, KeyError):
+            return {}
     traffic = pmc_traffic(args.precision)
+    util = sq_mfma_util(args.precision)
     for k in kernels:
         k["traffic"] = traffic.get(k["kernel"])
+        if k["kernel"] in util:
+            k["mfma_util"] = util[k["kernel"]]
     if other_line is not None and "kernels" in other_line:
-        t2 = pmc_traffic(other)
+        t2, u2 = pmc_traffic(other), sq_mfma_util(other)
         for k in other_line["kernels"]:
             k["traffic"] = t2.get(k["kernel"])
+            if k["kernel"] in u2:
+                k["mfma_util"] = u2[k["kernel"]]
     if world == 1 and args.graph and not args.no_kernel_timers:
         agg = batched_aggregate_roofline(table, B, dev)
         try:     # the committed PMC passes of tools/r04_aggregate_profiles.sh, keyed by shape (rows per copy x copies) and kernel
@@ -981,7 +1007,11 @@ def main():
     if kernels:
         k0 = kernels[0]
         roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
-                "unit": k0["unit"], "frac": k0["frac"], "traffic": k0["traffic"]}
+                "unit": k0["unit"], "frac": k0["frac"], "traffic": k0["traffic"],
+                # where `traffic` and `mfma_util` come from: committed rocprofv3 --pmc passes of the same eager command, NOT this run
+                "counters_from": "profiles/r05_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r05_recurrent_sq_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles)"}
+        if "mfma_util" in k0:
+            roof["mfma_util"] = k0["mfma_util"]
         if "fp32_equivalent" in k0:      # split: `achieved` counts the six EXECUTED f16 products per fp32 term
             roof["fp32_equivalent"] = k0["fp32_equivalent"]
     line = {

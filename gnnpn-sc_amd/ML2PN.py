@@ -53,10 +53,13 @@ def check(dataset, serCategory, epoch):
     return result
 
 
-def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=128):
+def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=128, precision="f32"):
     """Run ML+2PN inference over ``./data/<dataset>`` on the GPU and write the two artefacts that
     ``check`` reads: the rankings of ALL problems (trainML.py:146-149 format, [P][S] ints) and the
-    High-level actions of the test quarter (trainPNHigh.py:133-144 format, [T][nTest][8])."""
+    High-level actions of the test quarter (trainPNHigh.py:133-144 format, [T][nTest][8]).
+    ``precision``: arithmetic of the recurrent products and of the large-graph GIN layers — "f32" by default here (the artefact
+    files are the reference's hand-off format: the parity path), "split" = what bench.py measures (the exact
+    three-piece products: same selections on every pinned problem)."""
     import torch
     from . import loadData as ld
     from .pipeline import DeviceBatch, DeviceServices, ML2PNPipeline
@@ -67,7 +70,7 @@ def infer(dataset, net, low, high, n_per, epoch=-1, device="cuda:0", batch_size=
     dev = torch.device(device)
     P = len(ds["nodefeatures"])
     T = len(ds["serviceFeature"])
-    pipe = ML2PNPipeline(net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval(), n_per)
+    pipe = ML2PNPipeline(net.to(dev).eval(), low.to(dev).eval(), high.to(dev).eval(), n_per, precision=precision)
     table, _ = ld.tables_from_dataset(ds, 0, 0)
     svc = DeviceServices.from_table(table, dev)
     rankings, actions = [], [[] for _ in range(T)]

@@ -30,8 +30,9 @@ class SCDataset(torch.utils.data.Dataset):
 
 
 @torch.no_grad()
-def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device="cuda:0"):
-    """trainPNHigh.py:131-144: -> (allActions [T][n][8] python lists, val_tour = mean R per batch)."""
+def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device="cuda:0", precision="f32"):
+    """trainPNHigh.py:131-144: -> (allActions [T][n][8] python lists, val_tour = mean R per batch).  ``precision``: "f32" by
+    default (the artefact / parity path), "split" = the exact three-piece products bench.py measures."""
     dev = torch.device(device)
     all_actions = [[] for _ in range(serCategory)]
     val_tour = []
@@ -39,7 +40,7 @@ def evaluate(low_model, model, val_dataset, serCategory, batch_size=128, device=
         items = [val_dataset[i][0] for i in range(lo, min(len(val_dataset), lo + batch_size))]
         inputs = torch.stack(items).to(dev)
         def batch_pass(attempt):
-            out = two_level_greedy(low_model, model, inputs, write_through=attempt > 0)
+            out = two_level_greedy(low_model, model, inputs, write_through=attempt > 0, precision=precision)
             return out["actions"].cpu().numpy(), float(out["R"].mean().item())
         # a timed-out inter-workgroup hand-off must never reach the caller's artefacts: checked per batch, repeated once if it happens
         act, r_mean = ops.run_checked(batch_pass, dev)

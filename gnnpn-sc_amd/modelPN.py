@@ -233,12 +233,14 @@ class PointerNet(nn.Module):
         return d
 
     @torch.no_grad()
-    def run(self, inputs, latent=None, want_queries=False, fold=None, sample_seed=None):
+    def run(self, inputs, latent=None, want_queries=False, fold=None, sample_seed=None, encoder_precision="f32"):
         """Encode + decode (greedy, or with ``sample_seed`` every pick drawn from the window softmax); returns the decode
-        dict of ops.pointer_decode plus enc_out."""
+        dict of ops.pointer_decode plus enc_out.  ``encoder_precision``: operand arithmetic of the ENCODER's recurrent product
+        ("f32" | "split" | "f16": the cooperative encoder, H = 256) — the decode kernels this single-net entry reaches (the general
+        attention kernel, the literal two-stage cooperative build, the streaming form) compute in fp32."""
         inputs = inputs.contiguous()
         enc_args, embedded = self.encode_args(inputs, fold)
-        enc, h_n, c_n = custom_ops.lstm_encode([enc_args])
+        enc, h_n, c_n = custom_ops.lstm_encode([enc_args], precision=encoder_precision)
         impl = 0
         if self.embedding_size != 0:          # the decode kernels gather 8-feature action rows: the category column rejoins below
             rows9, inputs = inputs, inputs[:, :, 1:].contiguous()
@@ -393,12 +395,12 @@ def two_level_greedy(low, high, inputs, fold=None, precision=None, decode_impl=0
     if precision is None:
         precision = default_precision(low, high, fold, sample_high_seed is not None, decode_impl)
     if la.general or ha.general or la.embedding_size != 0 or ha.embedding_size != 0:
-        # 'Bahdanau' attention / glimpses / the category embedding (embeddingTag=1): one net per call
-        if precision != "f32":
-            raise NotImplementedError("the general attention forms and the embedding form decode in fp32")
-        dl = la.run(inputs, None, fold=fold)
+        # 'Bahdanau' attention / glimpses / the category embedding (embeddingTag=1): one net per call.  A non-fp32 ``precision``
+        # applies to the L-step encoder recurrences (the cooperative encoder: "split" exact, "f16" reduced); the T decoder steps of
+        # these forms run kernels that are built in fp32 only (round 5: this used to raise NotImplementedError)
+        dl = la.run(inputs, None, fold=fold, encoder_precision=precision)
         dh = ha.run(inputs, LatentWindows(dl["win_logits"], dl["idx"], None, None, la.C, la.use_tanh), fold=fold,
-                    sample_seed=sample_high_seed)                  # High drawn (modelPN.py:227-228) or greedy; Low greedy
+                    sample_seed=sample_high_seed, encoder_precision=precision)     # High drawn (modelPN.py:227-228) or greedy; Low greedy
         R = torch.ops.gnnpn.qos_reward(dh["actions"][..., -qosandcons:].contiguous(), 0 if high.level == "Low" else 1)
         return {"idx_low": dl["idx"], "idx_high": dh["idx"], "R": R, "actions": dh["actions"],
                 "action_probs": dh["pick_prob"], "win_low": dl["win_logits"], "win_high_raw": dh["win_logits"]}

@@ -72,12 +72,19 @@ def _load_ml_checkpoint(path):
     anything else is refused with a message that names the expected format."""
     import torch
     try:
-        obj = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            obj = torch.load(path, map_location="cpu", weights_only=True)     # a state_dict: no code is executed (ADVICE r4)
+        except Exception:        # noqa: BLE001
+            # a whole-module pickle executes arbitrary code when it is loaded: only for checkpoints the user vouches for
+            if os.environ.get("GNNPN_TRUST_CHECKPOINT") != "1":
+                raise
+            obj = torch.load(path, map_location="cpu", weights_only=False)
     except Exception as e:        # noqa: BLE001  (unpickling a whole-module checkpoint without its classes raises many kinds)
         raise RuntimeError(f"{path}: not loadable here ({type(e).__name__}: {e}).  Expected a state_dict of Net "
                            "(keys 'nodeEncoder.embeddings.0.weight', ...) as `main.py <ds> ML` of this build writes it; a "
                            "whole-module pickle of the reference (trainML.py:147) needs src.models.modelML and "
-                           "torch_geometric==1.7.0 importable — re-save it there with torch.save(model.state_dict(), path)") from e
+                           "torch_geometric==1.7.0 importable AND GNNPN_TRUST_CHECKPOINT=1 (unpickling a module runs its code) — or re-save it there "
+                           "with torch.save(model.state_dict(), path)") from e
     if isinstance(obj, torch.nn.Module):
         obj = obj.state_dict()
     if not (isinstance(obj, dict) and "nodeEncoder.embeddings.0.weight" in obj):

@@ -78,6 +78,17 @@ def test_attention_forms_golden(dev, name):
     R, _, _, idx_h, _ = nets[1](x, None, latent, sample="greedy")
     assert torch.equal(torch.stack(idx_l, 1).int(), out["idx_low"]) and torch.equal(torch.stack(idx_h, 1).int(), out["idx_high"])
     assert torch.equal(R, out["R"])
+    if H == 256:
+        # round 5: a non-fp32 precision with the general attention forms = that arithmetic in the L-step ENCODER recurrences (the
+        # cooperative encoder), fp32 in the general decode kernel — against the same reference fixture, by the same rule
+        for prec in ("split", "f16"):
+            o2 = two_level_greedy(nets[0], nets[1], x, precision=prec)
+            r2 = prefix_parity(o2["idx_low"], o2["idx_high"], fx, f"attn/{name}/{prec}", rows=fx["inputs"])
+            s2 = r2["same_mask"]
+            assert s2.sum() >= 0.7 * len(s2), r2
+            assert np.abs(o2["win_low"].cpu().numpy()[s2] - fx["win_low"][s2]).max() < (LOGIT_ATOL if prec == "split" else 5e-3)
+            assert_R_parity(o2["R"], fx["R"], f"attn/{name}/{prec}", mask=s2)
+            record_agreement(f"attention_forms/{name}_{prec}_encoder", {k: v for k, v in r2.items()})
 
 
 @pytest.mark.parametrize("name", ["bahdanau_g1_small", "dot_g2_small", "embed_small", "bahdanau_g1_qws", "embed_qws"])
@@ -152,6 +163,14 @@ def test_category_embedding_golden(dev, name):
     R, _, actions, idx_h, _ = nets[1](x, None, latent, sample="greedy")
     assert torch.equal(torch.stack(idx_l, 1).int(), out["idx_low"]) and torch.equal(torch.stack(idx_h, 1).int(), out["idx_high"])
     assert torch.equal(R, out["R"]) and actions[0].shape == (x.shape[0], 9)
+    if H == 256:      # the category embedding with the exact-split encoder (pregates form of the cooperative encoder), fp32 decoder
+        o2 = two_level_greedy(nets[0], nets[1], x, precision="split")
+        r2 = prefix_parity(o2["idx_low"], o2["idx_high"], fx, f"embed/{name}/split", rows=fx["inputs"])
+        s2 = r2["same_mask"]
+        assert s2.sum() >= 0.7 * len(s2), r2
+        assert np.abs(o2["win_low"].cpu().numpy()[s2] - fx["win_low"][s2]).max() < LOGIT_ATOL
+        assert_R_parity(o2["R"], fx["R"], f"embed/{name}/split", mask=s2)
+        record_agreement(f"category_embedding/{name}_split_encoder", r2)
 
 
 def test_general_kernel_on_the_shipped_configuration_equals_the_streaming_decoder(dev):
@@ -218,8 +237,9 @@ def test_unsupported_modes_fail_loudly(dev):
         CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Luong", 3, 6)             # modelPN.py:116-117
     g = CombinatorialRL(0, 32, 18, 1, 10, 1, reward, "Bahdanau", 3, 6).to(dev)  # the general forms: greedy and sampled (round 4)
     assert len(g(torch.rand(2, 18, 8, device=dev), None)[3]) == 6               # default sample="sample"
-    with pytest.raises(NotImplementedError):                                    # ... in fp32: the exact-split builds are the shipped form's
-        two_level_greedy(g, g, torch.rand(2, 18, 8, device=dev), precision="split")
+    from gnnpn_sc_amd import ops
+    with pytest.raises(ops.GnnpnError):                                         # a non-fp32 encoder needs the cooperative form (H = 256); at
+        two_level_greedy(g, g, torch.rand(2, 18, 8, device=dev), precision="split")   # H = 256 the general forms take it (test_attention_forms_golden)
     m = CombinatorialRL(0, 32, 18, 0, 10, 1, reward, "Dot", 3, 6).to(dev)
     R, probs, actions, idxs, _ = m(torch.rand(2, 18, 8, device=dev), None)   # default sample="sample": the sampling forward
     assert R.shape == (2,) and len(idxs) == 6 and probs[0].shape == (2,)

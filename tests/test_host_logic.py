@@ -113,7 +113,11 @@ def test_infer_weights_follow_the_epoch(tmp_path, monkeypatch):
     # the reference writes model-{n}.pkl as a pickle of the WHOLE module (trainML.py:147): a module object is taken by its
     # state_dict, anything that is neither is refused by name
     torch.save(net, "solutions/ML/QWS/model-3.pkl")                                 # a whole-module pickle of an importable class
+    with pytest.raises(RuntimeError, match="GNNPN_TRUST_CHECKPOINT"):                # unpickling a module runs code: opt-in only
+        cli._load_ml_checkpoint("solutions/ML/QWS/model-3.pkl")
+    monkeypatch.setenv("GNNPN_TRUST_CHECKPOINT", "1")
     got = cli._load_ml_checkpoint("solutions/ML/QWS/model-3.pkl")
+    monkeypatch.delenv("GNNPN_TRUST_CHECKPOINT")
     assert set(got) == set(sd_ml) and all(torch.equal(got[k_], sd_ml[k_]) for k_ in sd_ml)
     torch.save([1, 2, 3], "solutions/ML/QWS/model-3.pkl")
     with pytest.raises(RuntimeError, match="expected a state_dict of Net"):
