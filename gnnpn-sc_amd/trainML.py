@@ -90,9 +90,6 @@ def _bn_fwd(x, bn, relu=True):
 
 def ml_forward_backward(net, b):
     """Forward in training mode, BCE loss, backward.  -> (loss [1] device tensor, scores [B,S], {parameter name: gradient})."""
-    if not net.isService:
-        raise NotImplementedError("ml_forward_backward: training of the isServices=False ablation (modelML.py:157-162) is not "
-                                  "built — trainML.py:125-126 always trains with the service graph; inference of it is")
     c = net.reqAndServiceChannels
     g = {}
     # ---------------- forward: workflow branch (modelML.py:133-143,165-166)
@@ -111,11 +108,16 @@ def ml_forward_backward(net, b):
     xr = ops.segment_mean(b.seg, z)
     # ---------------- forward: service branch (:145-156,164,167-172)
     s = ops.embed_concat(b.xs, _p(net.serviceEncoder.embeddings[0].weight))
-    norm = ops.gcn_norm(b.svc.rowptr, b.svc.col, b.svc.w)
+    norm = ops.gcn_norm(b.svc.rowptr, b.svc.col, b.svc.w) if net.isService else None
     gcn = []
-    for conv, bn in zip(net.serviceConvs, net.serviceBatchNorms):
-        xw = ops.linear(s, _p(conv.weight).t().contiguous())                       # transform first (GCNConv)
-        agg = ops.csr_aggregate(b.svc.rowptr, b.svc.col, norm, xw, bias=_p(conv.bias))
+    for i, bn in enumerate(net.serviceBatchNorms):
+        if net.isService:
+            conv = net.serviceConvs[i]
+            xw = ops.linear(s, _p(conv.weight).t().contiguous())                   # transform first (GCNConv)
+            agg = ops.csr_aggregate(b.svc.rowptr, b.svc.col, norm, xw, bias=_p(conv.bias))
+        else:                                                                      # the graph-free ablation (modelML.py:157-162)
+            lin = net.noServicesLins[i]
+            agg = ops.linear(s, _p(lin.weight), _p(lin.bias))
         q, xh, is_ = _bn_fwd(agg, bn)
         gcn.append((s, q, xh, is_))
         s = q
@@ -131,12 +133,19 @@ def ml_forward_backward(net, b):
     g["serviceLin.weight"] = ops.gemm(de, s, a_kmajor=True, b_kmajor=True)
     g["serviceLin.bias"] = ops.colsum(de)
     ds = ops.gemm(de, _p(net.serviceLin.weight), b_kmajor=True)
-    norm_t = b.norm_t(norm)
+    norm_t = b.norm_t(norm) if net.isService else None
     for i in reversed(range(len(gcn))):
         s_in, q, xh, is_ = gcn[i]
-        conv, bn = net.serviceConvs[i], net.serviceBatchNorms[i]
+        bn = net.serviceBatchNorms[i]
         dagg, g[f"serviceBatchNorms.{i}.weight"], g[f"serviceBatchNorms.{i}.bias"] = \
             ops.bn_train_backward(ds, q, xh, _p(bn.weight), is_, True)
+        if not net.isService:                                                       # Linear: dW = dagg^T s_in, db = colsum, ds = dagg W
+            lin = net.noServicesLins[i]
+            g[f"noServicesLins.{i}.weight"] = ops.gemm(dagg, s_in, a_kmajor=True, b_kmajor=True)
+            g[f"noServicesLins.{i}.bias"] = ops.colsum(dagg)
+            ds = ops.gemm(dagg, _p(lin.weight), b_kmajor=True)
+            continue
+        conv = net.serviceConvs[i]
         g[f"serviceConvs.{i}.bias"] = ops.colsum(dagg)
         dxw = ops.csr_aggregate(b.svc_t.rowptr, b.svc_t.col, norm_t, dagg)          # the aggregate's transpose
         g[f"serviceConvs.{i}.weight"] = ops.gemm(s_in, dxw, a_kmajor=True, b_kmajor=True)   # [in,out] as stored

@@ -20,8 +20,9 @@ from . import ml as oml
 BN_MOMENTUM = 0.1
 
 
-def trainable_keys(sd, n_gin, n_gcn):
-    """The parameters that receive a gradient, in a fixed order."""
+def trainable_keys(sd, n_gin, n_gcn, is_services=True):
+    """The parameters that receive a gradient, in a fixed order (``is_services=False``: the graph-free ablation of
+    modelML.py:157-162 — noServicesLins instead of the serviceConvs)."""
     keys = ["nodeEncoder.embeddings.0.weight", "serviceEncoder.embeddings.0.weight"]
     for i in range(n_gin):
         p = f"nodeConvs.{i}"
@@ -29,7 +30,8 @@ def trainable_keys(sd, n_gin, n_gcn):
                  f"{p}.nn.3.bias", f"nodeBatchNorms.{i}.weight", f"nodeBatchNorms.{i}.bias"]
     keys += ["nodeLin.weight", "nodeLin.bias"]
     for i in range(n_gcn):
-        keys += [f"serviceConvs.{i}.weight", f"serviceConvs.{i}.bias", f"serviceBatchNorms.{i}.weight", f"serviceBatchNorms.{i}.bias"]
+        conv = f"serviceConvs.{i}" if is_services else f"noServicesLins.{i}"
+        keys += [f"{conv}.weight", f"{conv}.bias", f"serviceBatchNorms.{i}.weight", f"serviceBatchNorms.{i}.bias"]
     keys += ["serviceLin.weight", "serviceLin.bias"]
     assert all(k in sd for k in keys)
     return keys
@@ -50,7 +52,7 @@ def _bn_train(x, p, prefix, stats):
     return (x - mean) / torch.sqrt(var + oml.BN_EPS) * p[prefix + ".weight"] + p[prefix + ".bias"]
 
 
-def train_forward(p, data, n_gin, n_gcn, S, stats=None):
+def train_forward(p, data, n_gin, n_gcn, S, stats=None, is_services=True):
     """Net.forward in training mode on a batched ``data`` (x_service = one copy per graph, edges as the batching left them)
     -> sigmoid scores [B,S].  ``p``: name -> tensor (requires_grad where wanted)."""
     stats = {} if stats is None else stats
@@ -69,24 +71,27 @@ def train_forward(p, data, n_gin, n_gcn, S, stats=None):
     xr = oml.scatter_mean(h, data.batch, n_graphs)                                                    # :166
     sid = data.x_service[:, 0].long()
     xs = torch.cat([p["serviceEncoder.embeddings.0.weight"][sid], data.x_service[:, 1:]], -1)        # :146-149
-    for i in range(n_gcn):                                                                            # :152-155
-        xs = oml.gcn_conv(xs, data.edge_index_service, data.edge_attr_service, p[f"serviceConvs.{i}.weight"],
-                          p[f"serviceConvs.{i}.bias"])
+    for i in range(n_gcn):                                                                            # :152-155 | :157-162
+        if is_services:
+            xs = oml.gcn_conv(xs, data.edge_index_service, data.edge_attr_service, p[f"serviceConvs.{i}.weight"],
+                              p[f"serviceConvs.{i}.bias"])
+        else:
+            xs = F.linear(xs, p[f"noServicesLins.{i}.weight"], p[f"noServicesLins.{i}.bias"])
         xs = F.relu(_bn_train(xs, p, f"serviceBatchNorms.{i}", stats))
     xs = F.linear(xs, p["serviceLin.weight"], p["serviceLin.bias"])                                  # :164
     xs = oml.scatter_mean(xs, torch.arange(S).repeat(n_graphs), S)                                    # :167-172
     return torch.sigmoid(torch.matmul(xr, xs.t()))                                                    # :173-176
 
 
-def train_step(sd, data, y, n_gin, n_gcn, S, lr, adam_state=None, step=1):
+def train_step(sd, data, y, n_gin, n_gcn, S, lr, adam_state=None, step=1, is_services=True):
     """trainML.py:39-45 for ONE batch.  Returns dict(loss, scores, grads {name: tensor}, new_params {name: tensor},
     running {bn prefix: (running_mean, running_var)}, adam_state)."""
-    keys = trainable_keys(sd, n_gin, n_gcn)
+    keys = trainable_keys(sd, n_gin, n_gcn, is_services)
     p = {k: v.clone() for k, v in sd.items()}
     for k in keys:
         p[k].requires_grad_(True)
     stats = {}
-    scores = train_forward(p, data, n_gin, n_gcn, S, stats)
+    scores = train_forward(p, data, n_gin, n_gcn, S, stats, is_services)
     loss = F.binary_cross_entropy(scores, y.view(scores.shape))                                      # :42
     grads = dict(zip(keys, torch.autograd.grad(loss, [p[k] for k in keys])))
     st = adam_state or {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in keys}

@@ -528,7 +528,7 @@ def gen_ml_pygbatch(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, n_t=3,
           f"{float((ref - clean).abs().max()):.3f}")
 
 
-def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3, degree=6, steps=2):
+def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3, degree=6, steps=2, is_services=True):
     """``steps`` consecutive batches of TrainML.train (trainML.py:34-47) on the REAL Net glue (stand-in
     convs) under autograd — model.train(), BCELoss, backward, Adam(lr) — each on a torch_geometric-1.7.0-style batch of two
     graphs.  Stores, for the first and the last step, the loss, every gradient, the weights after the step and the
@@ -537,13 +537,13 @@ def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3
     B = 2
     table = synth.make_service_table(T, S, seed, degree=degree)
     sd = oml.make_state_dict(hidden, emb, n_gin, n_gcn, seed + 2)
-    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=True, dropout=0.0)
+    net = modelML.Net(hidden, S, emb, n_gin, n_gcn, isServices=is_services, dropout=0.0)   # False: the ablation of modelML.py:157-162
     net.load_state_dict(sd, strict=True)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=lr)                                        # trainML.py:130
     crit = torch.nn.BCELoss()                                                              # :28
     xs, eis, eas = (torch.from_numpy(a) for a in (table.x_service, table.edge_index, table.edge_attr))
-    keys = omt.trainable_keys(sd, n_gin, n_gcn)
+    keys = omt.trainable_keys(sd, n_gin, n_gcn, is_services)
     cur, st, out = dict(sd), None, {}
     g = torch.Generator().manual_seed(seed + 7)
     for step in range(1, steps + 1):
@@ -562,7 +562,7 @@ def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3
         assert set(grads) == set(keys), sorted(set(grads) ^ set(keys))
         opt.step()                                                                         # :45
         ref_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        orc = omt.train_step(cur, data, y, n_gin, n_gcn, S, lr, st, step)
+        orc = omt.train_step(cur, data, y, n_gin, n_gcn, S, lr, st, step, is_services)
         assert abs(float(orc["loss"]) - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))
         gmax = max(float(grads[k].abs().max()) for k in keys)
         for k in keys:
@@ -598,7 +598,7 @@ def gen_ml_train(modelML, name, hidden, emb, n_gin, n_gcn, T, S, seed, lr, n_t=3
         named = dict(net.named_parameters())
         st = {k: (opt.state[named[k]]["exp_avg"].clone(), opt.state[named[k]]["exp_avg_sq"].clone()) for k in keys}
     np.savez_compressed(os.path.join(HERE, f"ml_train_{name}.npz"), hidden=hidden, emb=emb, n_gin=n_gin, n_gcn=n_gcn, T=T, S=S,
-                        B=B, seed=seed, lr=lr, steps=steps, x_service=table.x_service, edge_index_service=table.edge_index,
+                        B=B, seed=seed, lr=lr, steps=steps, is_services=int(is_services), x_service=table.x_service, edge_index_service=table.edge_index,
                         edge_attr_service=table.edge_attr, **out)
     print(f"ml_train_{name}: {steps} steps, loss first/last = {out['first_loss']:.6f} / {out.get('last_loss', out['first_loss']):.6f}")
 
@@ -661,6 +661,7 @@ def main():
     gen_ml_pygbatch(modelML, "pygbatch", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=81, n_t=10, degree=8)
     gen_ml_train(modelML, "tiny", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, seed=121, lr=1e-3, steps=3)
     gen_ml_train(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=131, lr=1e-3, n_t=10, degree=8, steps=1)
+    gen_ml_train(modelML, "noservices", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, seed=141, lr=1e-3, steps=2, is_services=False)
     gen_hand_graph()
 
 

@@ -19,7 +19,8 @@ STAT_ATOL = 2e-5
 
 def _net(fx, dev, sd):
     from gnnpn_sc_amd.modelML import Net
-    net = Net(int(fx["hidden"]), int(fx["S"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]))
+    net = Net(int(fx["hidden"]), int(fx["S"]), int(fx["emb"]), int(fx["n_gin"]), int(fx["n_gcn"]),
+              isServices=bool(int(fx["is_services"])) if "is_services" in fx.files else True)
     net.load_state_dict(sd, strict=True)
     return net.to(dev)
 
@@ -44,7 +45,7 @@ def _batch(fx, tag, dev):
 
 
 def _check_step(fx, tag, net, grads, loss, what):
-    keys = omt.trainable_keys(net.state_dict(), int(fx["n_gin"]), int(fx["n_gcn"]))
+    keys = omt.trainable_keys(net.state_dict(), int(fx["n_gin"]), int(fx["n_gcn"]), bool(int(fx["is_services"])) if "is_services" in fx.files else True)
     assert set(grads) == set(keys)
     assert abs(float(loss) - float(fx[f"{tag}_loss"])) <= 2e-6 * max(1.0, abs(float(fx[f"{tag}_loss"])))
     gmax = max(float(np.abs(fx[f"{tag}_grad/{k}"]).max()) for k in keys)
@@ -60,9 +61,10 @@ def _check_step(fx, tag, net, grads, loss, what):
     return worst, gmax
 
 
-@pytest.mark.parametrize("name", ["tiny", "qws"])
+@pytest.mark.parametrize("name", ["tiny", "qws", "noservices"])
 def test_ml_training_step_vs_reference_autograd(dev, name):
-    """First step from the seeded weights: loss, every gradient, the weights after Adam, BatchNorm running statistics."""
+    """First step from the seeded weights: loss, every gradient, the weights after Adam, BatchNorm running statistics.
+    ("noservices": the isServices=False ablation of modelML.py:157-162 — noServicesLins instead of the GCN layers; round 5.)"""
     from gnnpn_sc_amd.trainML import MLAdam, ml_forward_backward
     fx = golden(f"ml_train_{name}.npz")
     n_gin, n_gcn = int(fx["n_gin"]), int(fx["n_gcn"])

@@ -320,7 +320,7 @@ def test_training_oracle_reproduces_reference_autograd(name):
             assert abs(float((got.flatten().double() * vec.double()).sum()) - float(fx[f"gradproj_{s}"])) < 2e-3 * n + 1e-7, k
 
 
-@pytest.mark.parametrize("name", ["tiny", "qws"])
+@pytest.mark.parametrize("name", ["tiny", "qws", "noservices"])
 def test_ml_training_oracle_reproduces_reference_autograd(name):
     """ml_train_*.npz: TrainML.train's loop body (trainML.py:39-45) on the reference's own Net glue under autograd (stand-in
     convs); the autograd restatement oracle/ml_train.py gives the same loss, gradients, post-Adam weights and BatchNorm
@@ -333,10 +333,11 @@ def test_ml_training_oracle_reproduces_reference_autograd(name):
     t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
     ei, ea = oml.pyg_batch_service_edges(t("edge_index_service"), t("edge_attr_service"), fx["first_offsets"])
     data = oml.make_data(t("first_x"), t("first_edge_index"), t("first_batch"), t("x_service").repeat(B, 1), ei, ea)
-    out = omt.train_step(sd, data, t("first_y"), n_gin, n_gcn, S, float(fx["lr"]))
+    is_services = bool(int(fx["is_services"])) if "is_services" in fx.files else True      # "noservices": modelML.py:157-162
+    out = omt.train_step(sd, data, t("first_y"), n_gin, n_gcn, S, float(fx["lr"]), is_services=is_services)
     assert abs(float(out["loss"]) - float(fx["first_loss"])) <= 1e-6
     assert float((out["scores"] - t("first_scores")).abs().max()) <= 1e-6
-    keys = omt.trainable_keys(sd, n_gin, n_gcn)
+    keys = omt.trainable_keys(sd, n_gin, n_gcn, is_services)
     gmax = max(float(np.abs(fx[f"first_grad/{k}"]).max()) for k in keys)
     for k in keys:
         want = t(f"first_grad/{k}")
