@@ -34,6 +34,13 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     B, L, F = inputs.shape
     H, T, K = actor.hidden_size, actor.serCategory, actor.serNumber
     flat = inputs.reshape(B * L, F).contiguous()
+    E = int(getattr(actor, "embedding_size", 0))
+    rows9 = None
+    if E:                                           # embeddingTag=1: rows [category | 8 floats] (modelPN.py:183-188)
+        if F != 9:
+            raise ops.GnnpnError(f"embedding_size != 0: rows [category | 8 floats] expected, got {F} columns")
+        rows9 = flat
+        flat = ops.embed_concat(rows9, p["embedding1.weight"])                                         # [B L, E + 8]
     embedded = ops.linear(flat, p["embedding2.weight"], p["embedding2.bias"])                          # modelPN.py:190
     pregates = ops.linear(embedded, p["encoder.weight_ih_l0"], p["encoder.bias_ih_l0"]).view(B, L, 4 * H)
     tr = lambda w: w.t().contiguous()                                                                  # noqa: E731  [4H,H] -> k-major [H,4H]
@@ -64,6 +71,9 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     d_emb2 = d_emb.view(B * L, H)
     g["embedding2.weight"] = ops.gemm(d_emb2, flat, True, True)
     g["embedding2.bias"] = ops.colsum(d_emb2)
+    if E:                                           # d embedding1: the first E columns of d(embedding2's input), summed per category
+        d_flat = ops.gemm(d_emb2, p["embedding2.weight"], False, True)                                 # [B L, H] . [H, E + 8]
+        g["embedding1.weight"] = ops.embed_grad(d_flat, rows9, E, p["embedding1.weight"].shape[0])
     return g, d["logp"]
 
 
@@ -107,7 +117,7 @@ class ActorAdam:
     def step(self, grads):
         """-> gradient norm before clipping (device tensor [1], float64)."""
         self.steps += 1
-        uniq = [grads[k] for k in ACTOR_KEYS]                      # b_ih and b_hh share a tensor but both count (two parameters)
+        uniq = [grads[k] for k in ACTOR_KEYS + (("embedding1.weight",) if "embedding1.weight" in grads else ())]   # b_ih and b_hh share a tensor but both count (two parameters)
         sumsq = ops.grad_sumsq(uniq)
         for k, p in _params(self.actor).items():
             if p.data.dtype != torch.float32 or not p.data.is_contiguous():
@@ -243,9 +253,10 @@ class TrainModel:
             self.epochs += 1
 
 
-def _pointer_model(level, hidden_size, n_glimpses, tanh_exploration, use_tanh, serNumber, serCategory, use_cuda):
+def _pointer_model(level, hidden_size, n_glimpses, tanh_exploration, use_tanh, serNumber, serCategory, use_cuda, embeddingTag=0):
     from .modelPN import CombinatorialRL, reward
-    return CombinatorialRL(0, hidden_size, serCategory * serNumber, n_glimpses, tanh_exploration, use_tanh, reward,
+    embedding_size = 20 if embeddingTag else 0                                                     # trainPNHigh.py:197-201, trainPNLow.py:196-199
+    return CombinatorialRL(embedding_size, hidden_size, serCategory * serNumber, n_glimpses, tanh_exploration, use_tanh, reward,
                            attention="Dot", level=level, use_cuda=use_cuda, sNumber=serNumber, sCategory=serCategory)
 
 
@@ -255,8 +266,7 @@ class PNHigh:
 
     def __init__(self, dataset, embeddingTag, USE_CUDA, serCategory, epochDiv, serNumber, hidden_size, n_glimpses,
                  tanh_exploration, use_tanh, beta, max_grad_norm, lr, epochML, epochPNLow):
-        if embeddingTag:
-            raise NotImplementedError("embeddingTag=1 is outside the shipped configuration (environment.ini:50,66)")
+        self.embeddingTag = int(bool(embeddingTag))                                                # :179 (round 5: trained too)
         self.dataset = dataset + "/"
         self.USE_CUDA, self.serCategory, self.epochDiv, self.serNumber = USE_CUDA, serCategory, epochDiv, serNumber
         self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh = hidden_size, n_glimpses, tanh_exploration, use_tanh
@@ -266,9 +276,10 @@ class PNHigh:
         from .loadData import loadDataPN
         rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :196
         n_train = len(rows) // 4 * 3
-        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], False)
-        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], False)
-        args = (self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber, self.serCategory, self.USE_CUDA)
+        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], bool(self.embeddingTag))     # :203-204
+        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], bool(self.embeddingTag))
+        args = (self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber, self.serCategory, self.USE_CUDA,
+                self.embeddingTag)
         low, high = _pointer_model("Low", *args), _pointer_model("High", *args)
         root = (f"./solutions/PNLow/{self.dataset}/epoch{self.epochPNLow}.model" if self.epochPNLow >= 0 else
                 f"./solutions/pretrained/{self.dataset[:-1]}-PNLow.model")                          # :237-240
@@ -285,8 +296,7 @@ class PNLow:
 
     def __init__(self, dataset, embeddingTag, USE_CUDA, serCategory, epochDiv, serNumber, hidden_size, n_glimpses,
                  tanh_exploration, use_tanh, beta, max_grad_norm, lr, epochML):
-        if embeddingTag:
-            raise NotImplementedError("embeddingTag=1 is outside the shipped configuration (environment.ini:20)")
+        self.embeddingTag = int(bool(embeddingTag))                                                # trainPNLow.py:173
         self.dataset = dataset + "/"
         self.USE_CUDA, self.serCategory, self.epochDiv, self.serNumber = USE_CUDA, serCategory, epochDiv, serNumber
         self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh = hidden_size, n_glimpses, tanh_exploration, use_tanh
@@ -296,10 +306,10 @@ class PNLow:
         from .loadData import loadDataPN
         rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :190-191
         n_train = len(rows) // 4 * 3
-        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], False)
-        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], False)
+        train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], bool(self.embeddingTag))     # trainPNLow.py:193-194
+        val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], bool(self.embeddingTag))
         model = _pointer_model("Low", self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber,
-                               self.serCategory, self.USE_CUDA)
+                               self.serCategory, self.USE_CUDA, self.embeddingTag)
         dev = torch.device(device)
         tm = TrainModel(model.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, self.dataset[:-1], self.serCategory,
                         self.lr, batch_size, None, self.max_grad_norm, low_model=None, device=device)

@@ -23,6 +23,11 @@ PARAM_KEYS = ("actor.decoder_start_input", "actor.embedding2.weight", "actor.emb
               "actor.decoder.weight_ih_l0", "actor.decoder.weight_hh_l0", "actor.decoder.bias_ih_l0", "actor.decoder.bias_hh_l0")
 
 
+def param_keys(sd):
+    """PARAM_KEYS, plus the category embedding table when the net has one (embedding_size != 0, modelPN.py:153-154)."""
+    return PARAM_KEYS + (("actor.embedding1.weight",) if "actor.embedding1.weight" in sd else ())
+
+
 def _cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
     gates = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
     i, f, g, o = gates.chunk(4, dim=1)
@@ -36,6 +41,9 @@ def pick_log_probs(params, inputs, idx, n_cat, n_per, latent_win=None, C=10.0, u
     latent_win [B,T,K] (the Low net's window logits, constants) or None."""
     B, L, _ = inputs.shape
     p = params
+    if "actor.embedding1.weight" in p:                                                               # :183-188 (embedding_size != 0)
+        x1 = F.embedding(inputs[:, :, 0].long(), p["actor.embedding1.weight"])
+        inputs = torch.cat([x1, inputs[:, :, 1:]], 2)
     embedded = F.linear(inputs, p["actor.embedding2.weight"], p["actor.embedding2.bias"])           # modelPN.py:190
     h = torch.zeros(B, embedded.shape[2])
     c = torch.zeros_like(h)
@@ -69,7 +77,8 @@ def reinforce_step(sd_high, inputs, idx, R, n_cat, n_per, latent_win, critic=Non
                    adam_state=None, step=1):
     """trainPNHigh.py:87-108 for ONE batch.  Returns dict(loss, critic, advantage, grads {name: tensor} BEFORE clipping,
     grad_norm, new_params {name: tensor} after clip + Adam, adam_state)."""
-    params = {k: sd_high[k].clone().requires_grad_(True) for k in PARAM_KEYS}
+    KEYS = param_keys(sd_high)
+    params = {k: sd_high[k].clone().requires_grad_(True) for k in KEYS}
     logp, prob = pick_log_probs(params, inputs, idx, n_cat, n_per, latent_win)
     critic = R.mean() if critic is None else critic * beta + (1.0 - beta) * R.mean()                # :87-90
     advantage = R - critic                                                                           # :92
@@ -77,14 +86,14 @@ def reinforce_step(sd_high, inputs, idx, R, n_cat, n_per, latent_win, critic=Non
     logprobs = logp.sum(1)
     logprobs = torch.where(logprobs < -1000, torch.zeros_like(logprobs), logprobs)
     loss = (advantage.detach() * logprobs).mean()                                                    # :100-101
-    grads = torch.autograd.grad(loss, [params[k] for k in PARAM_KEYS])
-    grads = dict(zip(PARAM_KEYS, grads))
+    grads = torch.autograd.grad(loss, [params[k] for k in KEYS])
+    grads = dict(zip(KEYS, grads))
     total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()                 # clip_grad_norm_(.., 2) :104-105
     coef = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0)
-    st = adam_state or {k: (torch.zeros_like(sd_high[k]), torch.zeros_like(sd_high[k])) for k in PARAM_KEYS}
+    st = adam_state or {k: (torch.zeros_like(sd_high[k]), torch.zeros_like(sd_high[k])) for k in KEYS}
     new_params, new_state = {}, {}
     b1, b2, eps = 0.9, 0.999, 1e-8                                                                   # optim.Adam defaults (:62)
-    for k in PARAM_KEYS:
+    for k in KEYS:
         g = grads[k] * coef
         m = st[k][0] * b1 + (1 - b1) * g
         v = st[k][1] * b2 + (1 - b2) * g * g

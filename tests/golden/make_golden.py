@@ -275,7 +275,7 @@ def gen_pn_sample_forms(modelPN, name, H, T, K, B, seed, sample_seed, attention=
           f"differ from the greedy ones; min draw margin {float(orc['margin_high'].min()):.2e}")
 
 
-def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
+def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0):
     """ONE REINFORCE step of the PNHigh trainer run on the REAL modules (trainPNHigh.py:83-108; the driver class itself
     imports IPython/matplotlib and is not importable here, so its loop body is driven by hand, line for line):
     Low greedy -> latent, High sampled (multinomial routed to the stream), advantage against the first-batch critic,
@@ -284,16 +284,20 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
     seeded samples and seeded projections for H = 256 (4 MB per set otherwise) — after checking that oracle/pn_train.py
     reproduces them."""
     from oracle import pn_train as optr
-    sd_low, sd_high = opn.make_state_dict(H, seed), opn.make_state_dict(H, seed + 1)
+    # E != 0: embeddingTag=1 (trainPNHigh.py:197-201: embedding_size = 20) — rows [category | 8 floats], embedding1 trained too
+    sd_low, sd_high = opn.make_state_dict(H, seed, embedding_size=E, n_cat=T), opn.make_state_dict(H, seed + 1, embedding_size=E, n_cat=T)
     L = T * K
 
     def build(level, sd):
-        m = modelPN.CombinatorialRL(0, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
+        m = modelPN.CombinatorialRL(E, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
         m.load_state_dict(sd, strict=True)
         return m
 
     low, high = build("Low", sd_low), build("High", sd_high)
     x = pn_inputs(B, T, K, seed + 2)
+    if E:
+        cat = torch.arange(T).repeat_interleave(K).float().view(1, L, 1).expand(B, L, 1)     # loadData.py:130-148: column 0 = the category
+        x = torch.cat([cat, x], 2).contiguous()
     state = {"k": 0}
     real = torch.Tensor.multinomial
 
@@ -329,7 +333,9 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
     orc = optr.train_step(sd_low, sd_high, x, T, K, sample_seed)
     assert torch.equal(orc["idx_high"], idx_high) and torch.equal(orc["R"], R.detach())
     worst = 0.0
-    for k in optr.PARAM_KEYS:
+    KEYS = optr.param_keys(sd_high)
+    assert set(grads) == set(KEYS)
+    for k in KEYS:
         g, og = grads[k], orc["grads"][k]
         rel = float((g - og).norm() / (g.norm() + 1e-20))
         worst = max(worst, rel)
@@ -343,9 +349,9 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True):
     out = {"hidden": H, "n_cat": T, "n_per": K, "B": B, "seed_low": seed, "seed_high": seed + 1, "seed_inputs": seed + 2,
            "sample_seed": sample_seed, "idx_low": orc["idx_low"].numpy(), "idx_high": idx_high.numpy(), "R": R.detach().numpy(),
            "loss": float(actor_loss), "grad_norm": float(norm), "margin_low": orc["margin_low"].numpy(),
-           "margin_high": orc["margin_high"].numpy(), "win_low": orc["win_low"].numpy()}
+           "margin_high": orc["margin_high"].numpy(), "win_low": orc["win_low"].numpy(), "embedding_size": E}
     g = torch.Generator().manual_seed(seed)
-    for k in optr.PARAM_KEYS:
+    for k in KEYS:
         short = k.replace("actor.", "").replace(".", "_")
         gk, pk = grads[k].flatten(), new_params[k].flatten()
         if full:
@@ -644,6 +650,8 @@ def main():
     gen_pn_sample_forms(modelPN, "embed_qws", H=256, T=47, K=5, B=16, seed=159, sample_seed=2028, E=20)
     gen_pn_train(modelPN, "small", H=32, T=6, K=3, B=8, seed=101, sample_seed=4242, full=True)
     gen_pn_train(modelPN, "qws", H=256, T=47, K=5, B=32, seed=105, sample_seed=777, full=False)
+    gen_pn_train(modelPN, "embed_small", H=32, T=6, K=3, B=8, seed=161, sample_seed=4343, full=True, E=4)
+    gen_pn_train(modelPN, "embed_qws", H=256, T=47, K=5, B=16, seed=165, sample_seed=778, full=False, E=20)
     gen_pn_attn(modelPN, "dot_g1_small", H=32, T=6, K=3, B=6, seed=111, attention="Dot", n_glimpses=1)
     gen_pn_attn(modelPN, "bahdanau_g0_small", H=32, T=6, K=3, B=6, seed=113, attention="Bahdanau", n_glimpses=0)
     gen_pn_attn(modelPN, "bahdanau_g2_small", H=32, T=6, K=3, B=6, seed=115, attention="Bahdanau", n_glimpses=2)

@@ -14,31 +14,50 @@ pytestmark = pytest.mark.gpu
 GRAD_RTOL = 2e-4        # per parameter: ||g - g_ref|| / ||g_ref||
 
 
+def _E(fx):
+    try:
+        return int(fx["embedding_size"])
+    except (KeyError, ValueError):
+        return 0
+
+
 def _nets(fx, dev):
     from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
-    H, T, K = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"])
+    H, T, K, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), _E(fx)
     nets = []
     for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
-        m = CombinatorialRL(0, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
-        m.load_state_dict(opn.make_state_dict(H, seed), strict=True)
+        m = CombinatorialRL(E, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed, embedding_size=E, n_cat=T), strict=True)
         nets.append(m.to(dev))
     return nets
+
+
+def _inputs(fx):
+    """The fixture's PN inputs; with the category embedding (embeddingTag=1) column 0 is the category (loadData.py:130-148)."""
+    T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
+    if _E(fx):
+        cat = torch.arange(T).repeat_interleave(K).float().view(1, T * K, 1).expand(B, T * K, 1)
+        x = torch.cat([cat, x], 2).contiguous()
+    return x
 
 
 def _short(k):
     return k.replace("actor.", "").replace(".", "_")
 
 
-@pytest.mark.parametrize("name", ["small", "qws"])
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
 def test_actor_gradients_golden(dev, name):
     """Backward with the fixture's picks given (teacher forcing): every actor gradient against the reference's autograd —
-    in full at H = 32, as norm, 64 seeded entries and a seeded projection per parameter at H = 256 — then clip + Adam."""
+    in full at H = 32, as norm, 64 seeded entries and a seeded projection per parameter at H = 256 — then clip + Adam.
+    ("embed_*": embeddingTag=1 — the category embedding in front of embedding2, its table trained too; round 5.)"""
     from gnnpn_sc_amd import ops
     from gnnpn_sc_amd.trainPNHigh import ActorAdam, actor_gradients
     fx = golden(f"pn_train_{name}.npz")
     low, high = _nets(fx, dev)
     T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
-    x = pn_inputs(B, T, K, int(fx["seed_inputs"])).to(dev)
+    x = _inputs(fx).to(dev)
+    KEYS = optr.PARAM_KEYS + (("actor.embedding1.weight",) if _E(fx) else ())
     R = torch.from_numpy(fx["R"]).to(dev)
     gscale = ((R - R.mean()) / B).contiguous()                     # first batch: critic = R.mean() (trainPNHigh.py:87-92)
     idx = torch.from_numpy(fx["idx_high"]).int().to(dev)
@@ -49,7 +68,8 @@ def test_actor_gradients_golden(dev, name):
     assert abs(loss - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"]))), (loss, float(fx["loss"]))
     worst = 0.0
     g = torch.Generator().manual_seed(int(fx["seed_low"]))         # the generator's seed = `seed` of gen_pn_train
-    for k in optr.PARAM_KEYS:
+    assert set(grads) == {k.replace("actor.", "") for k in KEYS}
+    for k in KEYS:
         got = grads[k.replace("actor.", "")].detach().cpu()
         s = _short(k)
         if f"grad_{s}" in fx.files:
@@ -68,12 +88,12 @@ def test_actor_gradients_golden(dev, name):
         worst = max(worst, rel)
         assert rel < GRAD_RTOL, f"{k}: relative gradient error {rel:.2e}"
     record_agreement(f"train_gradients_{name}", {"worst_relative_gradient_error": worst, "loss": loss, "loss_reference": float(fx["loss"]),
-                                                 "parameters": len(optr.PARAM_KEYS), "B": B, "T": T, "K": K})
+                                                 "parameters": len(KEYS), "B": B, "T": T, "K": K})
     # clip_grad_norm_ + Adam (first step)
     opt = ActorAdam(high.actor, lr=0.5e-4, max_grad_norm=2.0)
     norm = float(opt.step(grads))
     assert abs(norm - float(fx["grad_norm"])) < 2e-4 * float(fx["grad_norm"])
-    for k in optr.PARAM_KEYS:
+    for k in KEYS:
         s = _short(k)
         new = dict(high.actor.named_parameters())[k.replace("actor.", "")].detach().cpu()
         if f"new_{s}" in fx.files:
@@ -106,7 +126,7 @@ def test_actor_gradients_vs_live_autograd(dev):
         assert rel < GRAD_RTOL, f"{k}: {rel:.2e}"
 
 
-@pytest.mark.parametrize("name", ["small", "qws"])
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
 def test_train_step_end_to_end(dev, name):
     """TrainModel.train_step (trainPNHigh.py:81-110 in one call): sampled forward with the fixture's stream, backward, clip,
     Adam.  Where the drawn picks equal the reference's (they do unless a draw is fragile) loss and gradient norm match, the
@@ -116,7 +136,7 @@ def test_train_step_end_to_end(dev, name):
     fx = golden(f"pn_train_{name}.npz")
     low, high = _nets(fx, dev)
     T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
-    x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
+    x = _inputs(fx)
     tm = TrainModel(high, None, None, 1, 0.9, True, "QWS", T, lr=0.5e-4, batch_size=B, max_grad_norm=2., low_model=low, device=str(dev))
     before = {k: p.detach().clone() for k, p in high.actor.named_parameters()}
     greedy_before = two_level_greedy(low, high, x.to(dev))
@@ -172,3 +192,15 @@ def test_training_drivers_end_to_end(dev, tmp_path, monkeypatch):
     with contextlib.redirect_stdout(buf):
         score = ML2PN.check("QWS", T, 1)                                            # ./solutions/PNHigh/QWS/allActions1.txt
     assert buf.getvalue().split()[0] == "1" and np.isfinite(score)
+    # embeddingTag=1 (trainPNLow.py:190-199, trainPNHigh.py:197-204; switched off by the shipped configs): rows keep their
+    # category column, embedding_size = 20, the category table is trained with the rest (round 5: used to raise)
+    low_e = PNLow("QWS", 1, 1, T, 1, K, 256, 0, 10, 1, 0.9, 2.0, 1e-4, -1).start(n_epochs=1, device=str(dev), batch_size=4)
+    e1 = low_e.model.actor.embedding1.weight.detach().cpu()
+    assert low_e.actor_optim.steps == 3 and tuple(e1.shape) == (T, 20) and all(np.isfinite(v) for v in low_e.train_tour)
+    ck = torch.load("solutions/PNLow/QWS/epoch0.model", map_location="cpu")["model"]
+    assert torch.equal(ck["actor.embedding1.weight"], e1)
+    high_e = PNHigh("QWS", 1, 1, T, 1, K, 256, 0, 10, 1, 0.9, 2.0, 0.5e-4, -1, 0).start(n_epochs=1, device=str(dev), batch_size=4)
+    assert high_e.actor_optim.steps == 3 and all(np.isfinite(v) for v in high_e.train_tour)
+    with open("solutions/PNHigh/QWS/allActions0.txt") as f:
+        acts_e = json.load(f)
+    assert len(acts_e) == T and len(acts_e[0][0]) == 9                              # action rows WITH their category column

@@ -286,7 +286,7 @@ def test_pn_oracle_sampling_mode_reproduces_reference(name):
     assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.02      # the stream is a sane uniform
 
 
-@pytest.mark.parametrize("name", ["small", "qws"])
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
 def test_training_oracle_reproduces_reference_autograd(name):
     """pn_train_*.npz: one REINFORCE step of the PNHigh trainer on the REAL reference modules and their autograd
     (trainPNHigh.py:83-108).  The oracle's restatement (oracle/pn_train.py) reproduces picks, loss, every gradient (2e-4
@@ -296,13 +296,16 @@ def test_training_oracle_reproduces_reference_autograd(name):
     fx = golden(f"pn_train_{name}.npz")
     torch.set_num_threads(4)
     H, T, K, B = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
+    E = int(fx["embedding_size"]) if "embedding_size" in fx.files else 0                  # "embed_*": embeddingTag=1 (round 5)
     x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
-    out = optr.train_step(opn.make_state_dict(H, int(fx["seed_low"])), opn.make_state_dict(H, int(fx["seed_high"])), x, T, K,
-                          int(fx["sample_seed"]))
+    if E:
+        x = torch.cat([torch.arange(T).repeat_interleave(K).float().view(1, T * K, 1).expand(B, T * K, 1), x], 2).contiguous()
+    sd_low, sd_high = (opn.make_state_dict(H, int(fx[k]), embedding_size=E, n_cat=T) for k in ("seed_low", "seed_high"))
+    out = optr.train_step(sd_low, sd_high, x, T, K, int(fx["sample_seed"]))
     assert np.array_equal(out["idx_high"].numpy(), fx["idx_high"])
     assert abs(float(out["loss"]) - float(fx["loss"])) < 1e-6 and abs(float(out["grad_norm"]) - float(fx["grad_norm"])) < 1e-5
     g = torch.Generator().manual_seed(int(fx["seed_low"]))
-    for k in optr.PARAM_KEYS:
+    for k in optr.param_keys(sd_high):
         s = k.replace("actor.", "").replace(".", "_")
         got = out["grads"][k]
         if f"grad_{s}" in fx.files:
