@@ -281,17 +281,18 @@ __device__ __forceinline__ void tiled_unit(const char* __restrict__ bp, const ch
 // last unit of the tile more than the last wave, and every source-tile switch (a workgroup barrier) waits for the slowest wave.
 __device__ __forceinline__ int unit_of(int p, int wave) { return p * WAVES + ((p & 1) ? WAVES - 1 - wave : wave); }
 
-// `srows` rows of a source tile's 16-channel slice (src: the first row's 16 bytes of this lane) -> LDS through registers,
+// `srows` rows of a source tile's 16-channel slice (src: the tile's first row, uniform over the workgroup: scalar registers; c: this
+// lane's channel; the row offset stays 32-bit: block_rows * ldx < 2^29, checked by the launcher) -> LDS through registers,
 // DEPTH rows in flight per lane
 template <int DEPTH>
-__device__ __forceinline__ void fill_tile(float* __restrict__ tile, const float* __restrict__ src, int64_t ldx, int srows, int tid, int sub) {
+__device__ __forceinline__ void fill_tile(float* __restrict__ tile, const float* __restrict__ src, int ldx, int c, int srows, int tid, int sub) {
     constexpr int RPP = WAVES * 16;
     for (int rr = tid >> 2; rr < srows; rr += DEPTH * RPP) {
         float4 v[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
             const int r = min(rr + k * RPP, srows - 1);                   // clamped: the loads need no branch
-            v[k] = *reinterpret_cast<const float4*>(src + (int64_t)r * ldx);
+            v[k] = *reinterpret_cast<const float4*>(src + (unsigned)(r * ldx + c));
         }
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {                                 // (clamped duplicates rewrite row srows-1 with its own bytes)
@@ -363,7 +364,9 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     };
     f32x2 a01[PASSES], a23[PASSES];
     // the first tile in ONE round trip (10 rows in flight per lane: the accumulators are not live yet) ...
-    fill_tile<10>(tile, x + (int64_t)r0 * ldx + c, ldx, min(g.TR, Rb), tid, sub);
+    const float* xb = x + (int64_t)r0 * ldx;                              // the block's first row: uniform over the workgroup
+    const int ldxi = (int)ldx;
+    fill_tile<10>(tile, xb, ldxi, c, min(g.TR, Rb), tid, sub);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         a01[p] = f32x2{0.f, 0.f};
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     for (int t = 0; t < g.NT; ++t) {
         if (t) {
             __syncthreads();                                              // every gather from the previous tile is done
-            fill_tile<FILL_LATER>(tile, x + (int64_t)(r0 + t * g.TR) * ldx + c, ldx, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
+            fill_tile<FILL_LATER>(tile, xb + (int64_t)(t * g.TR) * ldx, ldxi, c, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
         }
         __syncthreads();
 #pragma unroll
@@ -396,17 +399,11 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
             }
         }
     }
-    // ---- epilogue: the trailing self loop of rows outside the last source tile, then what the gather form's epilogue does
+    // ---- epilogue: the trailing self loop of rows outside the last source tile, then what the gather form's epilogue does.
+    // Every condition but `has_loop` is uniform over the launch: the stages run pass by pass on the packed accumulators, with the
+    // uniform tests outside the element arithmetic (round 5: the per-element test chain with an inlined sigmoid per element was
+    // 1.8 k instructions and 13 % of the launch, issue-bound — profiles/r05_aggregate_phases.json).
     const float one_plus_eps = self_coef ? __fadd_rn(1.0f, *self_coef) : 0.0f;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        if (bias) bv[v] = bias[c + v];
-        if (scale) {
-            sc[v] = scale[c + v];
-            sh[v] = shift[c + v];
-        }
-    }
     const int pos_even = wave * 16 + (lane >> 2), pos_odd = (WAVES - 1 - wave) * 16 + (lane >> 2);   // this lane's row within an even / odd pass
     const int32_t* ob = order + bd * g.U * 16;                            // wave-uniform bases + a 32-bit lane offset
     const float* swb = selfw + bd * g.U * 16;                             // (the loop weights in the same order: the two loads are independent)
@@ -420,47 +417,82 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     }
     // The rows' own features (trailing self loop outside the last source tile, GIN self term) come from global memory: requested
     // for EPI_CHUNK passes at once, unconditionally (rows that need nothing read row 0 of the block and ignore it), then used —
-    // one round trip per chunk.  (Round 4: one load per pass inside `if (has_loop)`, each behind a wait for the previous pass's
-    // STORE as well: ten dependent HBM round trips per workgroup, 0.29 ms of the 0.775 ms launch at 5000 rows x 128 copies —
-    // profiles/r05_aggregate_skeleton.json.)  A workgroup whose rows all lie in the last source tile (wave-uniform test) skips it.
+    // one round trip per chunk.  A workgroup whose rows all lie in the last source tile (wave-uniform test) skips it.
     constexpr int EPI_CHUNK = PASSES < 5 ? PASSES : 5;
     const bool needs_own = self_coef != nullptr || d * g.DR < (g.NT - 1) * g.TR;
+    if (needs_own) {
 #pragma unroll
-    for (int p0 = 0; p0 < PASSES; p0 += EPI_CHUNK) {
-        float4 own[EPI_CHUNK];
+        for (int p0 = 0; p0 < PASSES; p0 += EPI_CHUNK) {
+            float4 own[EPI_CHUNK];
 #pragma unroll
-        for (int k = 0; k < EPI_CHUNK; ++k) {
-            own[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + k < PASSES && needs_own) own[k] = *reinterpret_cast<const float4*>(x + (r0 + max(rl[p0 + k < PASSES ? p0 + k : 0], 0)) * ldx + c);
-        }
+            for (int k = 0; k < EPI_CHUNK; ++k)
+                own[k] = p0 + k < PASSES ? *reinterpret_cast<const float4*>(xb + (unsigned)(max(rl[p0 + k < PASSES ? p0 + k : 0], 0) * ldxi + c))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < EPI_CHUNK; ++k) {
-            const int p = p0 + k;
-            if (p >= PASSES) break;
-            if (rl[p] < 0) continue;
-            const float sw = swl[p];
-            const bool has_loop = sw == sw;
-            const float o4[4] = {own[k].x, own[k].y, own[k].z, own[k].w};
-            float acc[4] = {a01[p].x, a01[p].y, a23[p].x, a23[p].y};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                float tv = acc[v];
-                if (has_loop) tv = __fadd_rn(tv, __fmul_rn(sw, o4[v]));
-                if (self_coef) tv = __fadd_rn(tv, __fmul_rn(one_plus_eps, o4[v]));
-                if (bias) tv = __fadd_rn(tv, bv[v]);
-                if (scale) tv = __fadd_rn(__fmul_rn(tv, sc[v]), sh[v]);
-                acc[v] = apply_act(tv, act);
+            for (int k = 0; k < EPI_CHUNK; ++k) {
+                const int p = p0 + k;
+                if (p >= PASSES) break;
+                const f32x2 o01 = {own[k].x, own[k].y}, o23 = {own[k].z, own[k].w};
+                const float sw = swl[p];
+                const bool has_loop = sw == sw;                           // NaN: no out-of-order self loop on this row
+                const f32x2 sw2 = {sw, sw};
+                const f32x2 t01 = a01[p] + o01 * sw2, t23 = a23[p] + o23 * sw2;      // -ffp-contract=off: product rounded, then the add
+                a01[p] = has_loop ? t01 : a01[p];
+                a23[p] = has_loop ? t23 : a23[p];
+                if (self_coef) {
+                    const f32x2 e2 = {one_plus_eps, one_plus_eps};
+                    a01[p] = a01[p] + o01 * e2;
+                    a23[p] = a23[p] + o23 * e2;
+                }
             }
-            a01[p] = f32x2{acc[0], acc[1]};                 // the results stay in the accumulators' registers ...
-            a23[p] = f32x2{acc[2], acc[3]};
+        }
+    }
+    // (the epilogue vectors are fetched here, behind the self-loop stage: twelve registers the stage above has no room for)
+    f32x2 bv01 = {0.f, 0.f}, bv23 = {0.f, 0.f}, sc01 = {1.f, 1.f}, sc23 = {1.f, 1.f}, sh01 = {0.f, 0.f}, sh23 = {0.f, 0.f};
+    if (bias) {                                                           // (element loads: the vectors need not be 16-byte aligned)
+        bv01 = f32x2{bias[c], bias[c + 1]};
+        bv23 = f32x2{bias[c + 2], bias[c + 3]};
+    }
+    if (scale) {
+        sc01 = f32x2{scale[c], scale[c + 1]};
+        sc23 = f32x2{scale[c + 2], scale[c + 3]};
+        sh01 = f32x2{shift[c], shift[c + 1]};
+        sh23 = f32x2{shift[c + 2], shift[c + 3]};
+    }
+    if (bias) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            a01[p] = a01[p] + bv01;
+            a23[p] = a23[p] + bv23;
+        }
+    }
+    if (scale) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            a01[p] = a01[p] * sc01 + sh01;
+            a23[p] = a23[p] * sc23 + sh23;
+        }
+    }
+    if (act == GNNPN_ACT_RELU) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            a01[p] = f32x2{apply_act(a01[p].x, GNNPN_ACT_RELU), apply_act(a01[p].y, GNNPN_ACT_RELU)};
+            a23[p] = f32x2{apply_act(a23[p].x, GNNPN_ACT_RELU), apply_act(a23[p].y, GNNPN_ACT_RELU)};
+        }
+    } else if (act == GNNPN_ACT_SIGMOID) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            a01[p] = f32x2{sigmoid_f32(a01[p].x), sigmoid_f32(a01[p].y)};
+            a23[p] = f32x2{sigmoid_f32(a23[p].x), sigmoid_f32(a23[p].y)};
         }
     }
     // ... and leave in one burst of stores at the very end: a store reads its data registers after it has been issued, so a store
     // between two chunks made the compiler wait for its completion (vmcnt(0)) before it reused them — two more round trips
+    float* yb = y + (int64_t)r0 * ldy;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         if (rl[p] < 0) continue;
-        *reinterpret_cast<float4*>(y + (r0 + rl[p]) * ldy + c) = make_float4(a01[p].x, a01[p].y, a23[p].x, a23[p].y);
+        *reinterpret_cast<float4*>(yb + (unsigned)(rl[p] * (int)ldy + c)) = make_float4(a01[p].x, a01[p].y, a23[p].x, a23[p].y);
     }
 }
 
@@ -534,6 +566,8 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
     GNNPN_REQUIRE(header && order && selfw && x && y && batches, "csr_aggregate_tiled: null operand");
     GNNPN_REQUIRE((scale == nullptr) == (shift == nullptr), "csr_aggregate_tiled: scale and shift go together");
     GNNPN_REQUIRE(x != y, "csr_aggregate_tiled: in-place aggregation is not supported");
+    GNNPN_REQUIRE((int64_t)block_rows * ldx < (1ll << 29) && (int64_t)block_rows * ldy < (1ll << 29),
+                  "csr_aggregate_tiled: a block's rows must span less than 2 GiB (32-bit offsets inside a block)");
     Geom g;
     const bool vec = (C % 16 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gnnpn_aligned(x, 16) && gnnpn_aligned(y, 16) &&
                      gnnpn_aligned(batches, 16);

@@ -16,15 +16,24 @@ VARIANTS = [0, 1, 2, 3, 4, 8, 12, 16, 19, 31]
 EXTRA = {}            # name -> -D flags of an experiment build: python tools/ablate_aggregate.py build P1=-DGNNPN_TILED_PERSISTENT=1 ...
 
 
+BASE = {"aggregate_switches.patch": "76d19b13d7"}   # the commit whose graph_tiled.hip / graph_lds.h a frozen patch applies to (later kernels moved on)
+
+
 def patched_csrc(patch):
     """A copy of csrc/ (+ include/) with tools/experiments/<patch> applied: the product sources carry no experiment switch, the
-    timing-only builds are compiled from this copy."""
-    import shutil
+    timing-only builds are compiled from this copy.  A patch listed in BASE is frozen: the files it touches are taken from that
+    commit (``git show``; needs the repository, i.e. build here, run on the GPU box)."""
+    import re, shutil
     dst = os.path.join(OUT, "src_" + patch.replace(".patch", ""))
     shutil.rmtree(dst, ignore_errors=True)
     os.makedirs(os.path.join(dst, "gnnpn-sc_amd"), exist_ok=True)
     shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(dst, "gnnpn-sc_amd", "csrc"))
-    subprocess.run(["git", "apply", "--unsafe-paths", "--directory=" + dst, os.path.join(ROOT, "tools", "experiments", patch)], check=True, cwd=ROOT)
+    ppath = os.path.join(ROOT, "tools", "experiments", patch)
+    if patch in BASE:
+        for f in sorted(set(re.findall(r"^\+\+\+ b/(\S+)", open(ppath).read(), re.M))):
+            blob = subprocess.run(["git", "show", f"{BASE[patch]}:{f}"], check=True, cwd=ROOT, capture_output=True).stdout
+            open(os.path.join(dst, f), "wb").write(blob)
+    subprocess.run(["git", "apply", "--unsafe-paths", "--directory=" + dst, ppath], check=True, cwd=ROOT)
     return os.path.join(dst, "gnnpn-sc_amd", "csrc")
 
 
