@@ -276,6 +276,41 @@ __device__ __forceinline__ void tiled_unit(const char* __restrict__ bp, const ch
     }
 }
 
+// ---- the same walk in batches of TWO quads, two batches in flight (round 5).  Where the rows' runs per source tile are short
+// (10000 / 20000 rows per block: 2 - 3 / 1 - 2 quads per unit and tile) the form above loads four quads to use one or two and has
+// ONE request in flight per unit — a unit then costs an L2 round trip, not its arithmetic.  Here a lane's ONE 16-byte load per batch
+// holds, by its position in the row's lane group, the offsets of quad 0 | offsets of quad 1 | weights of quad 0 | weights of
+// quad 1 (same stream, other addresses), the consumer takes offsets from lane P and weights from lane P + 2 of the group, and the
+// requests run two batches ahead of the adds through a cursor over (unit, quad) that crosses units, passes and source tiles.
+// Same sums in the same order: bit-identical to the four-quad walk.  20000 x 8: 0.440 -> 0.378 ms, 10000 x 32: 0.527 -> 0.508;
+// at 5000 x 128 and 2507 x 256 (5 - 9 quads per unit and tile) the four-quad walk stays ahead (0.739 / 0.608 against 0.749 / 0.657),
+// so the launcher takes this walk for blocks of three or more source tiles.
+template <int PO, int PW>      // four edges: offsets from lane PO, weights from lane PW of the row's lane group
+__device__ __forceinline__ void pair_read4(const char* __restrict__ tile, const uint4& bv, int lane_off, float4 (&xv)[4]) {
+    const int cc[4] = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const float4*>(tile + (quad_from<4, PO>(cc[k]) + lane_off));
+}
+template <int PW>
+__device__ __forceinline__ void pair_add4(const float4 (&xv)[4], const uint4& bv, f32x2& a01, f32x2& a23) {
+    const int wb[4] = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wq = __int_as_float(quad_from<4, PW>(wb[k]));
+        const f32x2 w2 = {wq, wq};
+        a01 = a01 + f32x2{xv[k].x, xv[k].y} * w2;     // -ffp-contract=off: the product is rounded before the add
+        a23 = a23 + f32x2{xv[k].z, xv[k].w} * w2;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void lds_agg_consume_pair(const char* __restrict__ tile, const uint4& bv, int lane_off, f32x2& a01, f32x2& a23) {
+    float4 xa[4], xb[4];
+    pair_read4<0, 2>(tile, bv, lane_off, xa);
+    if (NP > 1) pair_read4<1, 3>(tile, bv, lane_off, xb);
+    pair_add4<2>(xa, bv, a01, a23);
+    if (NP > 1) pair_add4<3>(xb, bv, a01, a23);
+}
+
 // The unit of wavefront `wave` in pass p.  The units are sorted by descending work, so the passes deal them serpentine:
 // with every pass giving wave 0 the heaviest of its units, wave 0 would carry the difference between the first and the
 // last unit of the tile more than the last wave, and every source-tile switch (a workgroup barrier) waits for the slowest wave.
@@ -314,7 +349,7 @@ __device__ __forceinline__ void fill_tile(float* __restrict__ tile, const float*
 // passes not unrolled and the unit's sums swapped into fixed registers by a switch — 0.71 / 0.87 / 0.56 ms: the scalar
 // control per unit (switches, header look-ups, tile-switch events) costs more than the deeper look-ahead saves, and at
 // 2.5 quads per unit (20000 rows) it dominates.)
-template <int PASSES, int HREGS>      // HREGS: registers that hold the headers, 64 (source tile, pass) entries each
+template <int PASSES, int HREGS, bool PAIRS = false>      // HREGS: registers that hold the headers, 64 (source tile, pass) entries each; PAIRS: the two-quad walk
 __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
     const int2* __restrict__ header, const int32_t* __restrict__ order, const float* __restrict__ selfw,
     const uint4* __restrict__ batches, const float* __restrict__ x, int64_t ldx, const float* __restrict__ self_coef,
@@ -372,30 +407,68 @@ __global__ __launch_bounds__(WAVES * 64) void csr_aggregate_tiled_kernel(
         a01[p] = f32x2{0.f, 0.f};
         a23[p] = f32x2{0.f, 0.f};
     }
-    uint4 co, wv;                                                         // the pair of loads in flight (tiled_unit)
-    {
-        const char* b0 = stream_b + (int64_t)first_of(0) * 512;
-        co = *reinterpret_cast<const uint4*>(b0 + lane_boff);
-        wv = *reinterpret_cast<const uint4*>(b0 + lane_boff + 256);
-    }
-    for (int t = 0; t < g.NT; ++t) {
-        if (t) {
-            __syncthreads();                                              // every gather from the previous tile is done
-            fill_tile<FILL_LATER>(tile, xb + (int64_t)(t * g.TR) * ldx, ldxi, c, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
-        }
-        __syncthreads();
+    if constexpr (PAIRS) {
+        const int n_e = g.NT * PASSES;
+        const unsigned pair_boff = (unsigned)((sub & 1) * 512 + (sub >> 1) * 256 + (lane >> 2) * 16);
+        // the request cursor: (ce, cq) = the next batch to ask for — quads cq, cq + 1 of header entry ce; n_e: none left
+        int ce = 0, cq = 0;
+        while (ce < n_e && quads_of(ce) == 0) ++ce;
+        auto request = [&]() -> uint4 {
+            const char* src = ce < n_e ? stream_b + ((int64_t)first_of(ce) + cq) * 512 : stream_b;   // (past the end: any valid address)
+            const uint4 v = *reinterpret_cast<const uint4*>(src + pair_boff);
+            if (ce < n_e) {
+                cq += 2;
+                if (cq >= quads_of(ce)) {
+                    cq = 0;
+                    do ++ce; while (ce < n_e && quads_of(ce) == 0);
+                }
+            }
+            return v;
+        };
+        uint4 b0 = request(), b1 = request();                             // (one and three in flight measured slower: profiles/LOG_r05.md)
+        for (int t = 0; t < g.NT; ++t) {
+            if (t) {
+                __syncthreads();                                          // every gather from the previous tile is done
+                fill_tile<FILL_LATER>(tile, xb + (int64_t)(t * g.TR) * ldx, ldxi, c, min(g.TR, Rb - t * g.TR), tid, sub);
+            }
+            __syncthreads();
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int e = t * PASSES + p;
-            const int nq = quads_of(e);
-            // the unit after this one (the next pass, or the first pass of the next source tile; after the last: any valid address)
-            const int e_next = e + 1 < g.NT * PASSES ? e + 1 : 0;
-            const char* nb = stream_b + (int64_t)first_of(e_next) * 512;
-            if (nq > 0) {
-                tiled_unit(stream_b + (int64_t)first_of(e) * 512, nb, lane_boff, nq, co, wv, tile_b, lane_off, a01[p], a23[p]);
-            } else {                                  // no edges into this tile: the pair in flight was this unit's — replace it
-                co = *reinterpret_cast<const uint4*>(nb + lane_boff);
-                wv = *reinterpret_cast<const uint4*>(nb + lane_boff + 256);
+            for (int p = 0; p < PASSES; ++p) {
+                for (int nq = quads_of(t * PASSES + p); nq > 0; nq -= 2) {
+                    const uint4 cur = b0;
+                    b0 = b1;
+                    b1 = request();
+                    if (nq >= 2) lds_agg_consume_pair<2>(tile_b, cur, lane_off, a01[p], a23[p]);
+                    else lds_agg_consume_pair<1>(tile_b, cur, lane_off, a01[p], a23[p]);
+                }
+            }
+        }
+    } else {
+        uint4 co, wv;                                                         // the pair of loads in flight (tiled_unit)
+        {
+            const char* b0 = stream_b + (int64_t)first_of(0) * 512;
+            co = *reinterpret_cast<const uint4*>(b0 + lane_boff);
+            wv = *reinterpret_cast<const uint4*>(b0 + lane_boff + 256);
+        }
+        for (int t = 0; t < g.NT; ++t) {
+            if (t) {
+                __syncthreads();                                              // every gather from the previous tile is done
+                fill_tile<FILL_LATER>(tile, xb + (int64_t)(t * g.TR) * ldx, ldxi, c, min(g.TR, Rb - t * g.TR), tid, sub);   // ... the later ones in two (40 accumulator registers are live)
+            }
+            __syncthreads();
+    #pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int e = t * PASSES + p;
+                const int nq = quads_of(e);
+                // the unit after this one (the next pass, or the first pass of the next source tile; after the last: any valid address)
+                const int e_next = e + 1 < g.NT * PASSES ? e + 1 : 0;
+                const char* nb = stream_b + (int64_t)first_of(e_next) * 512;
+                if (nq > 0) {
+                    tiled_unit(stream_b + (int64_t)first_of(e) * 512, nb, lane_boff, nq, co, wv, tile_b, lane_off, a01[p], a23[p]);
+                } else {                                  // no edges into this tile: the pair in flight was this unit's — replace it
+                    co = *reinterpret_cast<const uint4*>(nb + lane_boff);
+                    wv = *reinterpret_cast<const uint4*>(nb + lane_boff + 256);
+                }
             }
         }
     }
@@ -580,11 +653,22 @@ extern "C" int gnnpn_csr_aggregate_tiled_f32(const int32_t* header, const int32_
     const int n_jj = ((g.n_blocks + 7) / 8) * g.ND * n_slices;
     dim3 grid((unsigned)(n_jj * 8)), block(WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
+    // which walk (speed only: the two give the same bits).  GNNPN_TILED_WALK = quads | pairs overrides the rule (tests run both).
+    const char* walk = getenv("GNNPN_TILED_WALK");
+    const bool pairs = walk && walk[0] == 'p' ? true : walk && walk[0] == 'q' ? false : g.NT >= 3;
 #define GNNPN_AGG_TILED(P_, H_)                                                                                             \
     do {                                                                                                                  \
         if (hipFuncSetAttribute((const void*)csr_aggregate_tiled_kernel<P_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                  \
             GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot reserve %u B of LDS", lds);                           \
+        if (pairs) {                                                                                                      \
+            if (hipFuncSetAttribute((const void*)csr_aggregate_tiled_kernel<P_, H_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess)                                                              \
+                GNNPN_FAIL(GNNPN_E_LAUNCH, "csr_aggregate_tiled: cannot reserve %u B of LDS", lds);                       \
+            hipLaunchKernelGGL((csr_aggregate_tiled_kernel<P_, H_, true>), grid, block, lds, st, reinterpret_cast<const int2*>(header), \
+                               order, selfw, static_cast<const uint4*>(batches), x, ldx, self_coef, bias, scale, shift, act, \
+                               y, ldy, n_rows, g, n_slices);                                                        \
+        } else                                                                                                            \
         hipLaunchKernelGGL((csr_aggregate_tiled_kernel<P_, H_>), grid, block, lds, st, reinterpret_cast<const int2*>(header), \
                            order, selfw, static_cast<const uint4*>(batches), x, ldx, self_coef, bias, scale, shift, act, \
                            y, ldy, n_rows, g, n_slices);                                                            \

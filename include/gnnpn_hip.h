@@ -106,6 +106,8 @@ int gnnpn_csr_block_row_order(const int32_t* rowptr, int32_t n_rows, int32_t blo
  * src/loadData.py:56-65 emits the pairs in lexicographic order, add_remaining_self_loops appends the loops; the check is
  * part of the plan).  The edge lists are consumed from a PLAN built once per (graph, weights): a sliced-ELL stream in the
  * order the wavefronts read it (quads of 512 B: [16 rows][4] LDS offsets + [16 rows][4] weights).
+ * The kernel walks a unit's quads four at a time, or two at a time with two requests in flight for blocks of three or more source
+ * tiles (short runs per tile); same bits.  GNNPN_TILED_WALK=quads|pairs in the environment overrides the choice (test hook).
  *
  *   1. gnnpn_csr_tile_plan_geometry: tile counts and the byte sizes of the plan's arrays (host only).
  *   2. gnnpn_csr_tile_plan_rows: fills header / order / tstart / selfw / meta (device).  Read meta back (stream-ordered):

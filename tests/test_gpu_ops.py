@@ -1,6 +1,7 @@
 """-m gpu: every C-ABI entry point against the CPU oracle on the same seeded inputs.
 Tolerances: integer/index outputs bit-exact; fp32 outputs within the stated absolute bounds
 (different summation order than MKL: ~1e-6 relative per 256-long dot)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -571,6 +572,14 @@ def test_csr_aggregate_tiled_equals_gather(dev, S, copies, C, degree, weighted, 
     assert torch.equal(got, want)
     assert ops.csr_tile_plan(rp, col, w, S) is plan                               # cached per (graph, weights)
     assert torch.equal(plan.aggregate(x2), want2)                                 # a second layer on the same plan, no epilogue
+    # the kernel walks a unit's quads four at a time or (blocks of three or more source tiles) two at a time: both walks, every case
+    for walk in ("quads", "pairs"):
+        os.environ["GNNPN_TILED_WALK"] = walk
+        try:
+            assert torch.equal(plan.aggregate(x, eps, bias, scale, shift, ops.ACT_RELU), want), walk
+            assert torch.equal(plan.aggregate(x2), want2), walk
+        finally:
+            del os.environ["GNNPN_TILED_WALK"]
     # the stream ends with FOUR quads of slack: an empty unit at the end of the scan order (5000 rows per block: the second
     # destination tile has 2488 rows, its last unit none) starts AT the stream's end and still requests its first four quads —
     # loaded, never used (three quads of slack left that read 512 B out of bounds)
