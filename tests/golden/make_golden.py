@@ -275,7 +275,7 @@ def gen_pn_sample_forms(modelPN, name, H, T, K, B, seed, sample_seed, attention=
           f"differ from the greedy ones; min draw margin {float(orc['margin_high'].min()):.2e}")
 
 
-def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0):
+def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0, attention="Dot", n_glimpses=0):
     """ONE REINFORCE step of the PNHigh trainer run on the REAL modules (trainPNHigh.py:83-108; the driver class itself
     imports IPython/matplotlib and is not importable here, so its loop body is driven by hand, line for line):
     Low greedy -> latent, High sampled (multinomial routed to the stream), advantage against the first-batch critic,
@@ -285,11 +285,14 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0):
     reproduces them."""
     from oracle import pn_train as optr
     # E != 0: embeddingTag=1 (trainPNHigh.py:197-201: embedding_size = 20) — rows [category | 8 floats], embedding1 trained too
-    sd_low, sd_high = opn.make_state_dict(H, seed, embedding_size=E, n_cat=T), opn.make_state_dict(H, seed + 1, embedding_size=E, n_cat=T)
+    # attention / n_glimpses: the forms the reference's configurations switch off ('Bahdanau' attention, glimpse rounds,
+    # modelPN.py:80-90,208-211) — both nets built with them, the High net trained through them
+    sd_low = opn.make_state_dict(H, seed, embedding_size=E, n_cat=T, attention=attention)
+    sd_high = opn.make_state_dict(H, seed + 1, embedding_size=E, n_cat=T, attention=attention)
     L = T * K
 
     def build(level, sd):
-        m = modelPN.CombinatorialRL(E, H, L, 0, 10, 1, modelPN.reward, "Dot", K, T, use_cuda=False, level=level)
+        m = modelPN.CombinatorialRL(E, H, L, n_glimpses, 10, 1, modelPN.reward, attention, K, T, use_cuda=False, level=level)
         m.load_state_dict(sd, strict=True)
         return m
 
@@ -323,14 +326,15 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0):
         actor_loss = (advantage * logprobs).mean()                                   # :100-101
         optim.zero_grad()
         actor_loss.backward()                                                        # :103-104
-        grads = {"actor." + n: p.grad.clone() for n, p in high.actor.named_parameters()}
-        norm = torch.nn.utils.clip_grad_norm_(high.actor.parameters(), 2.0, norm_type=2)   # :105-106
+        grads = {"actor." + n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))     # (the glimpse module without rounds)
+                 for n, p in high.actor.named_parameters()}
+        norm = torch.nn.utils.clip_grad_norm_([p for p in high.actor.parameters() if p.grad is not None], 2.0, norm_type=2)   # :105-106
         optim.step()                                                                 # :108
     finally:
         torch.Tensor.multinomial = real
     new_params = {"actor." + n: p.detach().clone() for n, p in high.actor.named_parameters()}
     idx_high = torch.stack(idxs, 1)
-    orc = optr.train_step(sd_low, sd_high, x, T, K, sample_seed)
+    orc = optr.train_step(sd_low, sd_high, x, T, K, sample_seed, attention=attention, n_glimpses=n_glimpses)
     assert torch.equal(orc["idx_high"], idx_high) and torch.equal(orc["R"], R.detach())
     worst = 0.0
     KEYS = optr.param_keys(sd_high)
@@ -349,7 +353,7 @@ def gen_pn_train(modelPN, name, H, T, K, B, seed, sample_seed, full=True, E=0):
     out = {"hidden": H, "n_cat": T, "n_per": K, "B": B, "seed_low": seed, "seed_high": seed + 1, "seed_inputs": seed + 2,
            "sample_seed": sample_seed, "idx_low": orc["idx_low"].numpy(), "idx_high": idx_high.numpy(), "R": R.detach().numpy(),
            "loss": float(actor_loss), "grad_norm": float(norm), "margin_low": orc["margin_low"].numpy(),
-           "margin_high": orc["margin_high"].numpy(), "win_low": orc["win_low"].numpy(), "embedding_size": E}
+           "margin_high": orc["margin_high"].numpy(), "win_low": orc["win_low"].numpy(), "embedding_size": E, "attention": attention, "n_glimpses": n_glimpses}
     g = torch.Generator().manual_seed(seed)
     for k in KEYS:
         short = k.replace("actor.", "").replace(".", "_")
@@ -652,6 +656,10 @@ def main():
     gen_pn_train(modelPN, "qws", H=256, T=47, K=5, B=32, seed=105, sample_seed=777, full=False)
     gen_pn_train(modelPN, "embed_small", H=32, T=6, K=3, B=8, seed=161, sample_seed=4343, full=True, E=4)
     gen_pn_train(modelPN, "embed_qws", H=256, T=47, K=5, B=16, seed=165, sample_seed=778, full=False, E=20)
+    gen_pn_train(modelPN, "bahdanau_g1_small", H=32, T=6, K=3, B=8, seed=171, sample_seed=4444, full=True, attention="Bahdanau", n_glimpses=1)
+    gen_pn_train(modelPN, "dot_g2_small", H=32, T=6, K=3, B=8, seed=173, sample_seed=4445, full=True, attention="Dot", n_glimpses=2)
+    gen_pn_train(modelPN, "bahdanau_g0_small", H=32, T=6, K=3, B=8, seed=175, sample_seed=4446, full=True, attention="Bahdanau", n_glimpses=0)
+    gen_pn_train(modelPN, "bahdanau_g1_qws", H=256, T=47, K=5, B=8, seed=177, sample_seed=779, full=False, attention="Bahdanau", n_glimpses=1)
     gen_pn_attn(modelPN, "dot_g1_small", H=32, T=6, K=3, B=6, seed=111, attention="Dot", n_glimpses=1)
     gen_pn_attn(modelPN, "bahdanau_g0_small", H=32, T=6, K=3, B=6, seed=113, attention="Bahdanau", n_glimpses=0)
     gen_pn_attn(modelPN, "bahdanau_g2_small", H=32, T=6, K=3, B=6, seed=115, attention="Bahdanau", n_glimpses=2)

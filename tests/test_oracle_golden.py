@@ -286,7 +286,8 @@ def test_pn_oracle_sampling_mode_reproduces_reference(name):
     assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.02      # the stream is a sane uniform
 
 
-@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws", "bahdanau_g1_small", "dot_g2_small", "bahdanau_g0_small",
+                                  "bahdanau_g1_qws"])
 def test_training_oracle_reproduces_reference_autograd(name):
     """pn_train_*.npz: one REINFORCE step of the PNHigh trainer on the REAL reference modules and their autograd
     (trainPNHigh.py:83-108).  The oracle's restatement (oracle/pn_train.py) reproduces picks, loss, every gradient (2e-4
@@ -300,8 +301,10 @@ def test_training_oracle_reproduces_reference_autograd(name):
     x = pn_inputs(B, T, K, int(fx["seed_inputs"]))
     if E:
         x = torch.cat([torch.arange(T).repeat_interleave(K).float().view(1, T * K, 1).expand(B, T * K, 1), x], 2).contiguous()
-    sd_low, sd_high = (opn.make_state_dict(H, int(fx[k]), embedding_size=E, n_cat=T) for k in ("seed_low", "seed_high"))
-    out = optr.train_step(sd_low, sd_high, x, T, K, int(fx["sample_seed"]))
+    attention = str(fx["attention"]) if "attention" in fx.files else "Dot"               # 'Bahdanau' attention / glimpse rounds (round 5)
+    n_glimpses = int(fx["n_glimpses"]) if "n_glimpses" in fx.files else 0
+    sd_low, sd_high = (opn.make_state_dict(H, int(fx[k]), embedding_size=E, n_cat=T, attention=attention) for k in ("seed_low", "seed_high"))
+    out = optr.train_step(sd_low, sd_high, x, T, K, int(fx["sample_seed"]), attention=attention, n_glimpses=n_glimpses)
     assert np.array_equal(out["idx_high"].numpy(), fx["idx_high"])
     assert abs(float(out["loss"]) - float(fx["loss"])) < 1e-6 and abs(float(out["grad_norm"]) - float(fx["grad_norm"])) < 1e-5
     g = torch.Generator().manual_seed(int(fx["seed_low"]))
