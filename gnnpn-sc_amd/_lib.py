@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
 LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -74,6 +74,8 @@ _SIGNATURES = {
     "gnnpn_decode_train_forward_f32": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
     "gnnpn_decode_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
     "gnnpn_lstm_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "gnnpn_decode_attn_train_forward_f32": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
+    "gnnpn_decode_attn_train_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_int, _P]),
     "gnnpn_colsum_f32": (c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
     "gnnpn_scatter_dx_f32": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "gnnpn_sumsq_f32": (c_int, [_P, c_int64, _P, _P]),
@@ -126,6 +128,13 @@ class DecodeTrain(ctypes.Structure):
     """gnnpn_decode_train_t of include/gnnpn_hip.h."""
     _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih", "whh", "bih", "bhh", "latent_win", "idx",
                                   "x_all", "gates_pre", "c_all", "h_all", "z0", "probs", "logp")]
+
+
+class DecodeAttnTrain(ctypes.Structure):
+    """gnnpn_decode_attn_train_t of include/gnnpn_hip.h."""
+    _fields_ = ([("base", DecodeTrain), ("bahdanau", c_int32), ("n_glimpses", c_int32)]
+                + [(n, _P) for n in ("p_wq_t", "p_wq", "p_bq", "p_v", "p_ref", "g_wq_t", "g_wq", "g_bq", "g_v", "g_ref", "q_all", "a_all",
+                                     "d_p_ref", "d_g_ref", "d_p_qp", "d_g_qp", "d_p_v", "d_g_v")])
 
 
 class EncodeNet(ctypes.Structure):

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgnnpn_hip.so")
-SOURCES = ["api.hip", "dense.hip", "graph.hip", "graph_tiled.hip", "gin_layer.hip", "gin_layer_split.hip", "request_branch.hip", "select.hip", "lstm.hip", "lstm_coop.hip", "decode.hip", "decode_coop.hip", "decode_lean.hip", "train.hip", "train_ml.hip", "decode_glimpse.hip", "woa.hip", "split_probe.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "graph_lds.h"), os.path.join(CSRC, "recurrent.h"), os.path.join(CSRC, "lstm_shared.h"), os.path.join(CSRC, "decode_shared.h"), os.path.join(CSRC, "coop_common.h"),
+SOURCES = ["api.hip", "dense.hip", "graph.hip", "graph_tiled.hip", "gin_layer.hip", "gin_layer_split.hip", "request_branch.hip", "select.hip", "lstm.hip", "lstm_coop.hip", "decode.hip", "decode_coop.hip", "decode_lean.hip", "train.hip", "train_attn.hip", "train_ml.hip", "decode_glimpse.hip", "woa.hip", "split_probe.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "graph_lds.h"), os.path.join(CSRC, "recurrent.h"), os.path.join(CSRC, "lstm_shared.h"), os.path.join(CSRC, "decode_shared.h"), os.path.join(CSRC, "coop_common.h"), os.path.join(CSRC, "train_common.h"),
            os.path.join(ROOT, "include", "gnnpn_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -1000,6 +1000,72 @@ def decode_train_backward(d, gscale):
     return de, dg, dx, dh0, dc0
 
 
+def _decode_attn_struct(d):
+    t = _lib.DecodeAttnTrain()
+    t.base = _decode_train_struct(d)
+    t.bahdanau, t.n_glimpses = int(d["bahdanau"]), int(d["n_glimpses"])
+    for name, _ in _lib.DecodeAttnTrain._fields_[3:]:
+        v = d.get(name)
+        setattr(t, name, None if v is None else v.data_ptr())
+    return t
+
+
+def decode_attn_train_forward(embedded, enc_out, h0, c0, start, wih, whh, bih, bhh, latent_win, idx, n_cat, n_per, attention,
+                              n_glimpses, pointer, glimpse, tanh_c=10.0, use_tanh=True):
+    """decode_train_forward through 'Bahdanau' attention and / or glimpse rounds (modelPN.py:80-90,103-109,208-211).
+    pointer / glimpse: dicts {wq [H,H], bq [H], wref [H,H,1], bref [H], v [H]} of the two Attention modules ('Bahdanau'; ignored
+    for 'Dot').  Returns the dict decode_attn_train_backward takes."""
+    B, L, H = enc_out.shape
+    dev = enc_out.device
+    bah = attention == "Bahdanau"
+    if attention not in ("Dot", "Bahdanau"):
+        raise NotImplementedError(f"attention '{attention}' (modelPN.py:116-117)")
+    d = {"embedded": embedded, "enc_out": enc_out, "h0": h0, "c0": c0, "start": start, "wih": wih, "whh": whh, "bih": bih,
+         "bhh": bhh, "latent_win": latent_win, "idx": idx, "bahdanau": bah, "n_glimpses": int(n_glimpses)}
+    G = int(n_glimpses)
+    for name, shape in (("x_all", (B, n_cat, H)), ("gates_pre", (B, n_cat, 4 * H)), ("c_all", (B, n_cat, H)),
+                        ("h_all", (B, n_cat, H)), ("z0", (B, n_cat, n_per)), ("probs", (B, n_cat, n_per)), ("logp", (B, n_cat)),
+                        ("q_all", (B, n_cat, G + 1, H))):
+        d[name] = torch.empty(shape, dtype=F32, device=dev)
+    if G:
+        d["a_all"] = torch.empty((B, n_cat, G, L), dtype=F32, device=dev)
+    if bah:
+        flat = enc_out.reshape(B * L, H)
+        for tag, side in (("p", pointer),) + ((("g", glimpse),) if G else ()):
+            wq = side["wq"].detach().float().contiguous()
+            d[tag + "_wq"], d[tag + "_wq_t"] = wq, wq.t().contiguous()
+            d[tag + "_bq"], d[tag + "_v"] = side["bq"].detach().float().contiguous(), side["v"].detach().float().contiguous()
+            d[tag + "_wref"] = side["wref"].detach().float().reshape(H, H).contiguous()
+            d[tag + "_ref"] = linear(flat, d[tag + "_wref"], side["bref"].detach().float().contiguous()).view(B, L, H)   # :106
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            dev_ptr(v, I32 if k == "idx" else F32, k)        # validation (device, dtype, contiguity)
+    check(_lib.load().gnnpn_decode_attn_train_forward_f32(_lib.ctypes.byref(_decode_attn_struct(d)), B, n_cat, n_per, H,
+                                                          float(tanh_c), int(bool(use_tanh)), stream_ptr()),
+          "gnnpn_decode_attn_train_forward_f32")
+    d.update(n_cat=n_cat, n_per=n_per, tanh_c=float(tanh_c), use_tanh=bool(use_tanh))
+    return d
+
+
+def decode_attn_train_backward(d, gscale):
+    """-> (d_enc_out [B,L,H] — the part that does not pass through `ref` —, dgates [B,T,4H], dx [B,T,H], dh0, dc0 [B,H]); with
+    'Bahdanau' attention d additionally holds d_p_ref / d_g_ref [B,L,H], d_p_qp [B,T,H] / d_g_qp [B,T,G,H], d_p_v / d_g_v [B,H]."""
+    B, L, H = d["enc_out"].shape
+    T, K, G = d["n_cat"], d["n_per"], d["n_glimpses"]
+    dev = d["enc_out"].device
+    de = torch.zeros((B, L, H), dtype=F32, device=dev)                   # added to, step by step
+    dg, dx, dh0, dc0 = (torch.empty(s, dtype=F32, device=dev) for s in ((B, T, 4 * H), (B, T, H), (B, H), (B, H)))
+    if d["bahdanau"]:
+        d["d_p_ref"], d["d_p_qp"], d["d_p_v"] = (torch.zeros(s, dtype=F32, device=dev) for s in ((B, L, H), (B, T, H), (B, H)))
+        if G:
+            d["d_g_ref"], d["d_g_qp"], d["d_g_v"] = (torch.zeros(s, dtype=F32, device=dev) for s in ((B, L, H), (B, T, G, H), (B, H)))
+    check(_lib.load().gnnpn_decode_attn_train_backward_f32(
+        _lib.ctypes.byref(_decode_attn_struct(d)), dev_ptr(gscale, F32, "gscale"), dev_ptr(de, F32, "d_enc_out"),
+        dev_ptr(dg, F32, "dgates"), dev_ptr(dx, F32, "dx"), dev_ptr(dh0, F32, "dh0"), dev_ptr(dc0, F32, "dc0"), B, T, K, H,
+        d["tanh_c"], int(d["use_tanh"]), stream_ptr()), "gnnpn_decode_attn_train_backward_f32")
+    return de, dg, dx, dh0, dc0
+
+
 def lstm_train_backward(whh, gates_pre, c_all, d_enc_out, dh0, dc0):
     B, L, H = c_all.shape
     dg = torch.empty((B, L, 4 * H), dtype=F32, device=c_all.device)

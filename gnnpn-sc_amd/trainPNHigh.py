@@ -27,9 +27,7 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     """Gradient of sum_b gscale[b] * sum_k log p_{b,k}(picks) wrt every parameter of ``actor`` (a modelPN.PointerNet):
     -> (dict name -> gradient tensor, logp [B,T]).  inputs [B,L,8]; idx [B,T] int32 picks (global positions); latent_win
     [B,T,K] the Low net's window logits (constants) or None."""
-    if getattr(actor, "general", False):
-        raise NotImplementedError("actor_gradients differentiates the shipped decoder ('Dot' attention, no glimpses): "
-                                  "'Bahdanau' attention / glimpse rounds (modelPN.py:83-109,208-211) have no backward here")
+    general = bool(getattr(actor, "general", False))      # 'Bahdanau' attention / glimpse rounds (modelPN.py:83-109,208-211): csrc/train_attn.hip
     p = {k: v.detach().float().contiguous() for k, v in _params(actor).items()}
     B, L, F = inputs.shape
     H, T, K = actor.hidden_size, actor.serCategory, actor.serNumber
@@ -46,13 +44,39 @@ def actor_gradients(actor, inputs, idx, latent_win, gscale):
     tr = lambda w: w.t().contiguous()                                                                  # noqa: E731  [4H,H] -> k-major [H,4H]
     enc_out, gates_e, c_e = ops.lstm_train_forward(pregates, tr(p["encoder.weight_hh_l0"]), p["encoder.bias_hh_l0"])   # :191
     h0, c0 = enc_out[:, L - 1].contiguous(), c_e[:, L - 1].contiguous()
-    d = ops.decode_train_forward(embedded.view(B, L, H), enc_out, h0, c0, p["decoder_start_input"],
-                                 tr(p["decoder.weight_ih_l0"]), tr(p["decoder.weight_hh_l0"]), p["decoder.bias_ih_l0"],
-                                 p["decoder.bias_hh_l0"], latent_win, idx, T, K, actor.C, actor.use_tanh)   # :204-239
-    d.update(wih=p["decoder.weight_ih_l0"], whh=p["decoder.weight_hh_l0"])                             # the backward's layout
-    d_enc_out, dg_d, dx, dh0, dc0 = ops.decode_train_backward(d, gscale)
-    dg_e = ops.lstm_train_backward(p["encoder.weight_hh_l0"], gates_e, c_e, d_enc_out, dh0, dc0)
     g = {}
+    if general:
+        d = ops.decode_attn_train_forward(embedded.view(B, L, H), enc_out, h0, c0, p["decoder_start_input"],
+                                          tr(p["decoder.weight_ih_l0"]), tr(p["decoder.weight_hh_l0"]), p["decoder.bias_ih_l0"],
+                                          p["decoder.bias_hh_l0"], latent_win, idx, T, K, actor.attention, actor.n_glimpses,
+                                          actor.pointer.side(), actor.glimpse.side(), actor.C, actor.use_tanh)   # :204-239
+        d.update(wih=p["decoder.weight_ih_l0"], whh=p["decoder.weight_hh_l0"])                         # the backward's layout
+        d_enc_out, dg_d, dx, dh0, dc0 = ops.decode_attn_train_backward(d, gscale)
+        G = actor.n_glimpses
+        if d["bahdanau"]:                                  # the two Attention modules' parameters (modelPN.py:82-90), d enc_out through ref
+            flat_enc = enc_out.reshape(B * L, H)
+            for tag, name, rounds in (("p", "pointer", 1),) + ((("g", "glimpse", G),) if G else ()):
+                dqp = d[f"d_{tag}_qp"].reshape(B * T * rounds, H)
+                # the queries the projections saw: q_G for the pointer, q_0 .. q_{G-1} for the glimpse rounds
+                q_in = (d["q_all"][:, :, G] if tag == "p" else d["q_all"][:, :, :G]).reshape(B * T * rounds, H).contiguous()
+                g[f"{name}.W_query.weight"] = ops.gemm(dqp, q_in, True, True)
+                g[f"{name}.W_query.bias"] = ops.colsum(dqp)
+                g[f"{name}.V"] = ops.colsum(d[f"d_{tag}_v"])
+                dref = d[f"d_{tag}_ref"].view(B * L, H)
+                g[f"{name}.W_ref.weight"] = ops.gemm(dref, flat_enc, True, True).view(H, H, 1)          # ref = W_ref enc + b_ref (:106)
+                g[f"{name}.W_ref.bias"] = ops.colsum(dref)
+                d_enc_out += ops.gemm(dref, d[f"{tag}_wref"], False, True).view(B, L, H)
+            if not G:                                      # the glimpse module took no part (the reference leaves .grad = None)
+                for k, v in p.items():
+                    if k.startswith("glimpse."):
+                        g[k] = torch.zeros_like(v)
+    else:
+        d = ops.decode_train_forward(embedded.view(B, L, H), enc_out, h0, c0, p["decoder_start_input"],
+                                     tr(p["decoder.weight_ih_l0"]), tr(p["decoder.weight_hh_l0"]), p["decoder.bias_ih_l0"],
+                                     p["decoder.bias_hh_l0"], latent_win, idx, T, K, actor.C, actor.use_tanh)   # :204-239
+        d.update(wih=p["decoder.weight_ih_l0"], whh=p["decoder.weight_hh_l0"])                         # the backward's layout
+        d_enc_out, dg_d, dx, dh0, dc0 = ops.decode_train_backward(d, gscale)
+    dg_e = ops.lstm_train_backward(p["encoder.weight_hh_l0"], gates_e, c_e, d_enc_out, dh0, dc0)
     dgd = dg_d.view(B * T, 4 * H)
     hprev_d = torch.cat([h0.unsqueeze(1), d["h_all"][:, :-1]], 1).reshape(B * T, H).contiguous()      # h_{k-1} of every step
     g["decoder.weight_hh_l0"] = ops.gemm(dgd, hprev_d, True, True)
@@ -81,8 +105,6 @@ class ActorAdam:
     """torch.optim.Adam(model.actor.parameters(), lr) (trainPNHigh.py:62) + clip_grad_norm_ (:105-106), state on the device."""
 
     def __init__(self, actor, lr=0.5e-4, max_grad_norm=2.0):
-        if getattr(actor, "general", False):
-            raise NotImplementedError("ActorAdam steps the parameters of the shipped decoder ('Dot' attention, no glimpses)")
         self.actor, self.lr, self.max_grad_norm, self.steps = actor, lr, max_grad_norm, 0
         self.state = {k: (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32))
                       for k, p in _params(actor).items()}
@@ -117,7 +139,8 @@ class ActorAdam:
     def step(self, grads):
         """-> gradient norm before clipping (device tensor [1], float64)."""
         self.steps += 1
-        uniq = [grads[k] for k in ACTOR_KEYS + (("embedding1.weight",) if "embedding1.weight" in grads else ())]   # b_ih and b_hh share a tensor but both count (two parameters)
+        extra = tuple(k for k in grads if k not in ACTOR_KEYS)         # embedding1.weight (embeddingTag=1), pointer.* / glimpse.* ('Bahdanau')
+        uniq = [grads[k] for k in ACTOR_KEYS + extra]                   # b_ih and b_hh share a tensor but both count (two parameters)
         sumsq = ops.grad_sumsq(uniq)
         for k, p in _params(self.actor).items():
             if p.data.dtype != torch.float32 or not p.data.is_contiguous():

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 7   /* 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 8   /* 8: gnnpn_decode_attn_train_{forward,backward}_f32 (training through 'Bahdanau' attention / glimpse rounds); 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -574,6 +574,43 @@ int gnnpn_decode_train_backward_f32(const gnnpn_decode_train_t* t, const float* 
 int gnnpn_lstm_train_backward_f32(const float* whh, const float* gates_pre, const float* c_all, const float* d_enc_out,
                                   const float* dh0, const float* dc0, float* dgates, int32_t B, int32_t L, int32_t H,
                                   void* stream);
+
+/* The same two decoder passes THROUGH the attention forms the reference's configurations switch off — 'Bahdanau' attention
+ * (src/models/modelPN.py:80-90,103-109) and glimpse rounds (:208-211), any combination; replaces autograd over :204-239 for them.
+ * `ref` = W_ref(enc_out) + b_ref per attention module ([B,L,H], gnnpn_linear_f32 by the caller).  The forward saves the queries
+ * q_0 = h_k ... q_G of every step and the glimpse softmaxes; the backward (d_enc_out is ADDED to: the caller zeroes it, as d_p_ref /
+ * d_g_ref) leaves d ref, the gradients wrt the projected queries (W_query's gradient = their GEMM with the saved queries, its
+ * bias' their column sum) and per-problem sums for V.  W_ref's gradient and d enc_out's share through ref are GEMMs over d ref. */
+typedef struct {
+    gnnpn_decode_train_t base;
+    int32_t bahdanau;        /* 0 'Dot', 1 'Bahdanau' */
+    int32_t n_glimpses;      /* 0..8 */
+    /* 'Bahdanau' only (NULL for 'Dot'); the glimpse module's only with n_glimpses > 0 */
+    const float* p_wq_t;     /* pointer.W_query.weight TRANSPOSED [H,H] (forward products) */
+    const float* p_wq;       /* ... row-major [H,H] (transposed products of the backward) */
+    const float* p_bq;       /* [H] */
+    const float* p_v;        /* [H] */
+    const float* p_ref;      /* [B,L,H] */
+    const float* g_wq_t;
+    const float* g_wq;
+    const float* g_bq;
+    const float* g_v;
+    const float* g_ref;
+    float* q_all;            /* [B,T,G+1,H] saved queries */
+    float* a_all;            /* [B,T,G,L] saved glimpse softmaxes (NULL with G = 0) */
+    /* backward outputs ('Bahdanau'; the *_ref buffers are added to) */
+    float* d_p_ref;          /* [B,L,H] */
+    float* d_g_ref;
+    float* d_p_qp;           /* [B,T,H] */
+    float* d_g_qp;           /* [B,T,G,H] */
+    float* d_p_v;            /* [B,H] */
+    float* d_g_v;
+} gnnpn_decode_attn_train_t;
+int gnnpn_decode_attn_train_forward_f32(const gnnpn_decode_attn_train_t* t, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                        float tanh_c, int use_tanh, void* stream);
+int gnnpn_decode_attn_train_backward_f32(const gnnpn_decode_attn_train_t* t, const float* gscale, float* d_enc_out, float* dgates,
+                                         float* dx, float* dh0, float* dc0, int32_t B, int32_t T, int32_t n_per, int32_t H,
+                                         float tanh_c, int use_tanh, void* stream);
 int gnnpn_colsum_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, float* out, void* stream);
 /* first pass of a two-pass column sum over many rows: partial[c][col] = sum of rows [c*rows_per_chunk, (c+1)*rows_per_chunk) */
 int gnnpn_colsum_chunks_f32(const float* X, int64_t ld, int64_t rows, int32_t cols, int64_t rows_per_chunk, float* partial,

@@ -12,6 +12,9 @@ from pn_inputs import pn_inputs
 
 pytestmark = pytest.mark.gpu
 GRAD_RTOL = 2e-4        # per parameter: ||g - g_ref|| / ||g_ref||
+# 'Bahdanau' attention + a glimpse round at the QWS shape: the step's advantages nearly cancel (loss -4e-4, gradient norm 0.15), so
+# the fp32 summation order of 47 steps x 235 positions shows — the autograd oracle itself stands at 1.4e-4 from the reference here
+GRAD_RTOL_OF = {"bahdanau_g1_qws": 5e-4}
 
 
 def _E(fx):
@@ -21,13 +24,22 @@ def _E(fx):
         return 0
 
 
+def _form(fx):
+    """(attention, n_glimpses) of a fixture: 'Bahdanau' attention / glimpse rounds (round 5), else the shipped ('Dot', 0)."""
+    try:
+        return str(fx["attention"]), int(fx["n_glimpses"])
+    except (KeyError, ValueError):
+        return "Dot", 0
+
+
 def _nets(fx, dev):
     from gnnpn_sc_amd.modelPN import CombinatorialRL, reward
     H, T, K, E = int(fx["hidden"]), int(fx["n_cat"]), int(fx["n_per"]), _E(fx)
+    attention, n_glimpses = _form(fx)
     nets = []
     for level, seed in (("Low", int(fx["seed_low"])), ("High", int(fx["seed_high"]))):
-        m = CombinatorialRL(E, H, T * K, 0, 10, 1, reward, "Dot", K, T, use_cuda=True, level=level)
-        m.load_state_dict(opn.make_state_dict(H, seed, embedding_size=E, n_cat=T), strict=True)
+        m = CombinatorialRL(E, H, T * K, n_glimpses, 10, 1, reward, attention, K, T, use_cuda=True, level=level)
+        m.load_state_dict(opn.make_state_dict(H, seed, embedding_size=E, n_cat=T, attention=attention), strict=True)
         nets.append(m.to(dev))
     return nets
 
@@ -46,18 +58,22 @@ def _short(k):
     return k.replace("actor.", "").replace(".", "_")
 
 
-@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
+FORMS = ["bahdanau_g1_small", "dot_g2_small", "bahdanau_g0_small", "bahdanau_g1_qws"]      # the switched-off attention forms (round 5)
+
+
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"] + FORMS)
 def test_actor_gradients_golden(dev, name):
     """Backward with the fixture's picks given (teacher forcing): every actor gradient against the reference's autograd —
     in full at H = 32, as norm, 64 seeded entries and a seeded projection per parameter at H = 256 — then clip + Adam.
-    ("embed_*": embeddingTag=1 — the category embedding in front of embedding2, its table trained too; round 5.)"""
+    ("embed_*": embeddingTag=1 — the category embedding in front of embedding2, its table trained too; "bahdanau_*" / "dot_g2":
+    'Bahdanau' attention and / or glimpse rounds, the two Attention modules' parameters trained too; round 5.)"""
     from gnnpn_sc_amd import ops
     from gnnpn_sc_amd.trainPNHigh import ActorAdam, actor_gradients
     fx = golden(f"pn_train_{name}.npz")
     low, high = _nets(fx, dev)
     T, K, B = int(fx["n_cat"]), int(fx["n_per"]), int(fx["B"])
     x = _inputs(fx).to(dev)
-    KEYS = optr.PARAM_KEYS + (("actor.embedding1.weight",) if _E(fx) else ())
+    KEYS = optr.param_keys(opn.make_state_dict(int(fx["hidden"]), int(fx["seed_high"]), embedding_size=_E(fx), n_cat=T, attention=_form(fx)[0]))
     R = torch.from_numpy(fx["R"]).to(dev)
     gscale = ((R - R.mean()) / B).contiguous()                     # first batch: critic = R.mean() (trainPNHigh.py:87-92)
     idx = torch.from_numpy(fx["idx_high"]).int().to(dev)
@@ -66,7 +82,7 @@ def test_actor_gradients_golden(dev, name):
     ops.check_status(dev)
     loss = float(((R - R.mean()) * logp.sum(1)).mean())
     assert abs(loss - float(fx["loss"])) < 2e-5 * max(1.0, abs(float(fx["loss"]))), (loss, float(fx["loss"]))
-    worst = 0.0
+    worst, rtol = 0.0, GRAD_RTOL_OF.get(name, GRAD_RTOL)
     g = torch.Generator().manual_seed(int(fx["seed_low"]))         # the generator's seed = `seed` of gen_pn_train
     assert set(grads) == {k.replace("actor.", "") for k in KEYS}
     for k in KEYS:
@@ -82,11 +98,11 @@ def test_actor_gradients_golden(dev, name):
             assert np.array_equal(pos.numpy(), fx[f"gradpos_{s}"])
             want_n = float(fx[f"gradnorm_{s}"])
             rel = abs(float(flat.norm()) - want_n) / (want_n + 1e-20)
-            assert float((flat[pos] - torch.from_numpy(fx[f"gradval_{s}"])).abs().max()) < GRAD_RTOL * want_n + 1e-7, k
+            assert float((flat[pos] - torch.from_numpy(fx[f"gradval_{s}"])).abs().max()) < rtol * want_n + 1e-7, k
             proj = float((flat.double() * vec.double()).sum())                # a seeded random projection of the whole tensor
-            assert abs(proj - float(fx[f"gradproj_{s}"])) < 2 * GRAD_RTOL * want_n * float(vec.norm()) / np.sqrt(flat.numel()) * 4 + 1e-7, k
+            assert abs(proj - float(fx[f"gradproj_{s}"])) < 2 * rtol * want_n * float(vec.norm()) / np.sqrt(flat.numel()) * 4 + 1e-7, k
         worst = max(worst, rel)
-        assert rel < GRAD_RTOL, f"{k}: relative gradient error {rel:.2e}"
+        assert rel < rtol, f"{k}: relative gradient error {rel:.2e}"
     record_agreement(f"train_gradients_{name}", {"worst_relative_gradient_error": worst, "loss": loss, "loss_reference": float(fx["loss"]),
                                                  "parameters": len(KEYS), "B": B, "T": T, "K": K})
     # clip_grad_norm_ + Adam (first step)
@@ -126,7 +142,7 @@ def test_actor_gradients_vs_live_autograd(dev):
         assert rel < GRAD_RTOL, f"{k}: {rel:.2e}"
 
 
-@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"])
+@pytest.mark.parametrize("name", ["small", "qws", "embed_small", "embed_qws"] + FORMS)
 def test_train_step_end_to_end(dev, name):
     """TrainModel.train_step (trainPNHigh.py:81-110 in one call): sampled forward with the fixture's stream, backward, clip,
     Adam.  Where the drawn picks equal the reference's (they do unless a draw is fragile) loss and gradient norm match, the
@@ -204,3 +220,9 @@ def test_training_drivers_end_to_end(dev, tmp_path, monkeypatch):
     with open("solutions/PNHigh/QWS/allActions0.txt") as f:
         acts_e = json.load(f)
     assert len(acts_e) == T and len(acts_e[0][0]) == 9                              # action rows WITH their category column
+    # n_glimpses = 1 (environment.ini ships 0; the drivers pass it through, attention stays 'Dot': trainPNLow.py:205-210,
+    # trainPNHigh.py:207-231): sampled forward and REINFORCE step through a glimpse round (round 5: used to raise)
+    low_g = PNLow("QWS", 0, 1, T, 1, K, 256, 1, 10, 1, 0.9, 2.0, 1e-4, -1).start(n_epochs=1, device=str(dev), batch_size=4)
+    assert low_g.actor_optim.steps == 3 and all(np.isfinite(v) for v in low_g.train_tour)
+    high_g = PNHigh("QWS", 0, 1, T, 1, K, 256, 1, 10, 1, 0.9, 2.0, 0.5e-4, -1, 0).start(n_epochs=1, device=str(dev), batch_size=4)
+    assert high_g.actor_optim.steps == 3 and all(np.isfinite(v) for v in high_g.train_tour)
