@@ -65,6 +65,7 @@ _SIGNATURES = {
     "gnnpn_pointer_decode_attn_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int32, c_int32, c_int32, c_int32, _P]),
     "gnnpn_attention_logits_f32": (c_int, [_P, _P, c_int64, _P, c_float, c_int, _P, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, _P]),
+    "gnnpn_attention_logits_bahdanau_f32": (c_int, [_P, _P, c_int64, _P, _P, c_float, c_int, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "gnnpn_qos_reward_f32": (c_int, [_P, _P, c_int32, c_int32, c_int, _P]),
     "gnnpn_split3_pieces_f32": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "gnnpn_recurrent_product_f32": (c_int, [_P, _P, c_int32, _P, _P, _P]),

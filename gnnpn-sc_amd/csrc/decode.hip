@@ -287,6 +287,23 @@ __global__ __launch_bounds__(256) void attention_logits_kernel(const float* __re
     if (lane == 0) logits[row] = v;
 }
 
+// 'Bahdanau' form of the same (modelPN.py:103-109): V . tanh(qp + ref_l), qp = W_query q + b_query and ref = W_ref(enc_out) + b_ref given
+__global__ __launch_bounds__(256) void attention_logits_bahdanau_kernel(const float* __restrict__ ref, const float* __restrict__ qp,
+                                                                        int64_t ld_q, const float* __restrict__ v, float tanh_c,
+                                                                        int use_tanh, float* __restrict__ logits, int64_t n_rows,
+                                                                        int32_t L, int32_t H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* r = ref + row * H;
+    const float* q = qp + (row / L) * ld_q;
+    float part = 0.0f;
+    for (int i = lane; i < H; i += 64) part = fmaf(v[i], tanhf(q[i] + r[i]), part);
+    float u = wave_sum(part);
+    if (use_tanh) u = __fmul_rn(tanh_c, tanhf(u));
+    if (lane == 0) logits[row] = u;
+}
+
 __global__ void mask_logits_kernel(const int32_t* __restrict__ masked_idx, float* __restrict__ logits, int32_t B,
                                    int32_t L, int32_t n_masked, int32_t ld_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,6 +331,23 @@ extern "C" int gnnpn_attention_logits_f32(const float* enc_out, const float* que
         hipLaunchKernelGGL(mask_logits_kernel, dim3((B * n_masked + 255) / 256), dim3(256), 0, s, masked_idx, logits,
                            B, L, n_masked, ld_idx);
     GNNPN_CHECK_LAUNCH("attention_logits_f32");
+    return GNNPN_OK;
+}
+
+extern "C" int gnnpn_attention_logits_bahdanau_f32(const float* ref, const float* qp, int64_t ld_q, const float* v,
+                                                   const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits, int32_t B,
+                                                   int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx, void* stream) {
+    GNNPN_REQUIRE(ref && qp && v && logits && B >= 0 && L > 0 && H > 0 && ld_q >= H, "attention_logits_bahdanau: bad argument");
+    GNNPN_REQUIRE(n_masked == 0 || (masked_idx && ld_idx >= n_masked), "attention_logits_bahdanau: bad mask");
+    if (B == 0) return GNNPN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_rows = (int64_t)B * L;
+    hipLaunchKernelGGL(attention_logits_bahdanau_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, ref, qp, ld_q, v,
+                       tanh_c, use_tanh, logits, n_rows, L, H);
+    if (n_masked > 0)
+        hipLaunchKernelGGL(mask_logits_kernel, dim3((B * n_masked + 255) / 256), dim3(256), 0, s, masked_idx, logits, B, L,
+                           n_masked, ld_idx);
+    GNNPN_CHECK_LAUNCH("attention_logits_bahdanau_f32");
     return GNNPN_OK;
 }
 

@@ -137,7 +137,6 @@ __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_glimpse_kern
             lstm_cell_update(gate[0], gate[1], gate[2], gate[3], c[0], h[0]);
             hs[cur ^ 1][0][j] = h[0];
             qv[j] = h[0];                                              // query = hidden (:207)
-            if (net.queries) net.queries[((int64_t)b * T + k) * H + j] = h[0];
         }
         __syncthreads();
         cur ^= 1;
@@ -180,6 +179,8 @@ __global__ __launch_bounds__((H < 64 ? 64 : H)) void pointer_decode_glimpse_kern
             __syncthreads();
         }
 
+        // the query the pointer sees (after the glimpse rounds): what the full-length logits of the step are formed from on demand
+        if (owner && net.queries) net.queries[((int64_t)b * T + k) * H + j] = qv[j];
         // ---- pointer logits of the step's window (:213; every other position is -inf after :220-222)
         if constexpr (BAHDANAU) {
             if (owner) {

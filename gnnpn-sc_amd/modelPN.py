@@ -45,10 +45,11 @@ class LatentWindows:
     tensor for step k (window logits in place, -inf at previously chosen positions, the remaining
     positions computed by gnnpn_attention_logits_f32)."""
 
-    def __init__(self, win, idx, enc_out, queries, tanh_c, use_tanh):
+    def __init__(self, win, idx, enc_out, queries, tanh_c, use_tanh, bahdanau=None):
         self.win, self.idx = win, idx
-        self._enc_out, self._queries = enc_out, queries
+        self._enc_out, self._queries = enc_out, queries            # queries: what the pointer attention saw (after the glimpse rounds)
         self._tanh_c, self._use_tanh = tanh_c, use_tanh
+        self._bahdanau, self._ref = bahdanau, None                 # 'Bahdanau': the pointer module's {wq, bq, wref, bref, v} (modelPN.py:82-90)
 
     def __len__(self):
         return self.win.shape[1]
@@ -58,9 +59,14 @@ class LatentWindows:
             return [self[i] for i in range(*k.indices(len(self)))]
         if k < 0:
             k += len(self)
-        if self._queries is None:
-            raise NotImplementedError("full-length logits of the 'Bahdanau' / glimpse forms are not materialised; the "
-                                      "window logits (.win) are all the High level reads (modelPN.py:216,220-222)")
+        if self._bahdanau is not None:                             # V . tanh(W_query q + b + W_ref(enc) + b) (modelPN.py:103-109)
+            from . import ops
+            a = {n: v.detach().float().contiguous() for n, v in self._bahdanau.items()}
+            B, L, H = self._enc_out.shape
+            if self._ref is None:                                  # once per forward
+                self._ref = ops.linear(self._enc_out.reshape(B * L, H), a["wref"].reshape(H, H).contiguous(), a["bref"]).view(B, L, H)
+            qp = ops.linear(self._queries[:, k, :].contiguous(), a["wq"], a["bq"])
+            return ops.attention_logits_bahdanau(self._ref, qp, a["v"], k, self.idx, self._tanh_c, self._use_tanh)
         return torch.ops.gnnpn.attention_logits(self._enc_out, self._queries, k, self.idx, self._tanh_c, self._use_tanh)
 
     def __iter__(self):
@@ -274,8 +280,7 @@ class PointerNet(nn.Module):
         are lazily materialised full-length views (see LatentWindows)."""
         out = self.run(inputs, latent, want_queries=True,
                        sample_seed=None if sample == "greedy" else self.next_sample_seed())      # :225-228
-        lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], None if self.general else out["queries"],
-                            self.C, self.use_tanh)
+        lat = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.C, self.use_tanh, self.pointer.side())
         idxs = [out["idx"][:, k].long() for k in range(self.serCategory)]
         return _ProbList(out, latent, self.serCategory, self.serNumber), idxs, lat
 
@@ -354,7 +359,7 @@ class CombinatorialRL(nn.Module):
         actions = [out["actions"][:, k, :] for k in range(T)]                       # :293-295
         action_probs = [out["pick_prob"][:, k] for k in range(T)]                   # :297-299
         latent_p = LatentWindows(out["win_logits"], out["idx"], out["enc_out"], out["queries"], self.actor.C,
-                                 self.actor.use_tanh)
+                                 self.actor.use_tanh, self.actor.pointer.side())
         if training == "RL":                                                        # :301-304
             R = self.reward(actions, labs, self.serCategory, USE_CUDA=self.use_cuda, level=self.level,
                             embedding_size=self.embedding_size)

@@ -852,6 +852,18 @@ def attention_logits(enc_out, queries, step, idx, tanh_c=10.0, use_tanh=True):
     return out
 
 
+def attention_logits_bahdanau(ref, qp, v, step, idx, tanh_c=10.0, use_tanh=True):
+    """The 'Bahdanau' form of attention_logits (modelPN.py:103-109): ref [B,L,H] = W_ref(enc_out) + b_ref, qp [B,H] = W_query q +
+    b_query of the step's pointer query, v [H]; -inf at the ``step`` previously chosen positions."""
+    B, L, H = ref.shape
+    out = torch.empty((B, L), dtype=F32, device=ref.device)
+    check(_lib.load().gnnpn_attention_logits_bahdanau_f32(
+        dev_ptr(ref, F32, "ref"), dev_ptr(qp, F32, "qp"), H, dev_ptr(v, F32, "v"), dev_ptr(idx, I32, "idx"), float(tanh_c),
+        int(bool(use_tanh)), dev_ptr(out, F32, "logits"), B, L, H, step, idx.shape[1], stream_ptr()),
+        "gnnpn_attention_logits_bahdanau_f32")
+    return out
+
+
 def qos_reward(actions, level):
     """actions [B,T,8] -> R [B]; level 'Low' -> #violations, 'High' -> round(violations + objective, 5)."""
     B, T, _ = actions.shape

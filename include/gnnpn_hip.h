@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 8   /* 8: gnnpn_decode_attn_train_{forward,backward}_f32 (training through 'Bahdanau' attention / glimpse rounds); 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 8   /* 8: gnnpn_decode_attn_train_{forward,backward}_f32 (training through 'Bahdanau' attention / glimpse rounds), gnnpn_attention_logits_bahdanau_f32; 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -508,6 +508,12 @@ int gnnpn_attention_logits_f32(const float* enc_out, const float* queries, int64
                                const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits,
                                int32_t B, int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx,
                                void* stream);
+/* The 'Bahdanau' form (src/models/modelPN.py:103-109,119-120): logits[b,l] = C*tanh(V . tanh(qp[b,:] + ref[b,l,:])) with
+ * qp = W_query q + b_query [B,H] (row b at qp + b*ld_q) and ref = W_ref(enc_out) + b_ref [B,L,H] formed by the caller
+ * (gnnpn_linear_f32); same mask.  Not on the fast path. */
+int gnnpn_attention_logits_bahdanau_f32(const float* ref, const float* qp, int64_t ld_q, const float* v,
+                                        const int32_t* masked_idx, float tanh_c, int use_tanh, float* logits,
+                                        int32_t B, int32_t L, int32_t H, int32_t n_masked, int32_t ld_idx, void* stream);
 
 /* QoS reward of decoded compositions: per problem, violate = #global constraints whose product
  * QoS (q2, q3 over the T actions, fp32 running product) falls outside [lo,hi] read from the

@@ -78,6 +78,17 @@ def test_attention_forms_golden(dev, name):
     R, _, _, idx_h, _ = nets[1](x, None, latent, sample="greedy")
     assert torch.equal(torch.stack(idx_l, 1).int(), out["idx_low"]) and torch.equal(torch.stack(idx_h, 1).int(), out["idx_high"])
     assert torch.equal(R, out["R"])
+    # the returned logits (modelPN.py:239) of these forms, materialised on demand (round 5: used to raise): full length, -inf at the
+    # positions chosen before the step (:165-173), against the oracle's on the problems whose Low picks equal the oracle's
+    sd_low = opn.make_state_dict(H, int(fx["seed_low"]), attention=att)
+    _, o_idx, o_logits = opn.pointer_forward(sd_low, x.cpu(), T, K, attention=att, n_glimpses=ng)
+    eq = (torch.stack(idx_l, 1).cpu() == torch.stack(o_idx, 1)).all(1)
+    for k in (0, 1, T - 1):
+        mine, want = latent[k].cpu(), o_logits[k]
+        assert mine.shape == want.shape == (x.shape[0], T * K)
+        assert torch.equal(torch.isinf(mine)[eq], torch.isinf(want)[eq]) and int(torch.isinf(want[eq]).sum()) == k * int(eq.sum())
+        fin = ~torch.isinf(want)
+        assert float((mine - want)[eq][fin[eq]].abs().max()) < LOGIT_ATOL, (name, k)
     if H == 256:
         # round 5: a non-fp32 precision with the general attention forms = that arithmetic in the L-step ENCODER recurrences (the
         # cooperative encoder), fp32 in the general decode kernel — against the same reference fixture, by the same rule
