@@ -16,7 +16,7 @@ VARIANTS = [0, 1, 2, 3, 4, 8, 12, 16, 19, 31]
 EXTRA = {}            # name -> -D flags of an experiment build: python tools/ablate_aggregate.py build P1=-DGNNPN_TILED_PERSISTENT=1 ...
 
 
-BASE = {"aggregate_switches.patch": "76d19b13d7"}   # the commit whose graph_tiled.hip / graph_lds.h a frozen patch applies to (later kernels moved on)
+BASE = {"aggregate_switches.patch": "76d19b13d7", "aggregate_prefetch_wave.patch": "f5daec2"}   # the commit whose sources a frozen patch applies to (later kernels moved on)
 
 
 def patched_csrc(patch):
@@ -32,6 +32,7 @@ def patched_csrc(patch):
     if patch in BASE:
         for f in sorted(set(re.findall(r"^\+\+\+ b/(\S+)", open(ppath).read(), re.M))):
             blob = subprocess.run(["git", "show", f"{BASE[patch]}:{f}"], check=True, cwd=ROOT, capture_output=True).stdout
+            os.makedirs(os.path.dirname(os.path.join(dst, f)), exist_ok=True)    # (a frozen patch may also touch the header, the oracle, a test)
             open(os.path.join(dst, f), "wb").write(blob)
     subprocess.run(["git", "apply", "--unsafe-paths", "--directory=" + dst, ppath], check=True, cwd=ROOT)
     return os.path.join(dst, "gnnpn-sc_amd", "csrc")
