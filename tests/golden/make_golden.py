@@ -679,6 +679,8 @@ def main():
     gen_ml_train(modelML, "qws", hidden=128, emb=20, n_gin=2, n_gcn=2, T=47, S=300, seed=131, lr=1e-3, n_t=10, degree=8, steps=1)
     gen_ml_train(modelML, "noservices", hidden=16, emb=8, n_gin=2, n_gcn=2, T=6, S=40, seed=141, lr=1e-3, steps=2, is_services=False)
     gen_hand_graph()
+    import manifest
+    manifest.update()                           # sha256 + key lists of every fixture: what the CPU suite holds the committed files to
 
 
 if __name__ == "__main__":

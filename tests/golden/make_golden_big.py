@@ -95,6 +95,8 @@ def main():
     torch.set_num_threads(8)                    # picks are pinned against the oracle on the same thread count, same chunks
     for name in (sys.argv[1:] or list(CONFIGS)):
         gen(modelPN, name, **CONFIGS[name])
+    import manifest
+    manifest.update()                           # sha256 + key lists of every fixture: what the CPU suite holds the committed files to
 
 
 if __name__ == "__main__":

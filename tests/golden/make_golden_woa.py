@@ -194,6 +194,9 @@ def gen_driver(WOA, loadData_mod):
     with open(os.path.join(HERE, "woa_driver.json"), "w") as f:
         json.dump(fx, f)
     print("wrote woa_driver.json", os.path.getsize(os.path.join(HERE, "woa_driver.json")), "bytes")
+    sys.path.insert(0, HERE)
+    import manifest
+    manifest.update()
 
 
 if __name__ == "__main__":

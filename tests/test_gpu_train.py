@@ -25,11 +25,8 @@ def _E(fx):
 
 
 def _form(fx):
-    """(attention, n_glimpses) of a fixture: 'Bahdanau' attention / glimpse rounds (round 5), else the shipped ('Dot', 0)."""
-    try:
-        return str(fx["attention"]), int(fx["n_glimpses"])
-    except (KeyError, ValueError):
-        return "Dot", 0
+    """(attention, n_glimpses) of a fixture: every pn_train_* file carries both (tests/golden/MANIFEST.json pins the key lists)."""
+    return str(fx["attention"]), int(fx["n_glimpses"])
 
 
 def _nets(fx, dev):

@@ -384,3 +384,24 @@ def test_gcn_conv_against_dense_fp64_formula():
     want = (dis[:, None] * A * dis[None, :]) @ (x.double() @ W.double()) + b.double()
     got = oml.gcn_conv(x, ei, w, W, b)
     assert float((got.double() - want).abs().max()) < 2e-5
+
+
+def test_committed_fixtures_are_what_the_generators_wrote():
+    """Every fixture in tests/golden is byte for byte (sha256) the file its generator wrote, with the key list the generator
+    writes today: MANIFEST.json is written by the generators themselves (tests/golden/manifest.py).  A fixture regenerated and not
+    committed, or committed from an older generator, fails here instead of being papered over by a default in a test
+    (VERDICT r5, item 4).  No fixture may be missing from the manifest and no manifest entry from the directory."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import manifest
+    with open(manifest.PATH) as f:
+        want = json.load(f)
+    have = manifest.fixture_files()
+    assert sorted(want) == have, (sorted(set(want) ^ set(have)))
+    for name in have:
+        got = manifest.describe(name)
+        assert got == want[name], f"{name}: committed file differs from what its generator wrote ({got} != {want[name]})"
+    # the REINFORCE fixtures all say which attention form they were made with (the four stale ones of round 5 did not)
+    for name in have:
+        if name.startswith("pn_train_"):
+            assert {"attention", "n_glimpses"} <= set(want[name]["keys"]), name
