@@ -23,6 +23,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--graph", default="scan", help="scan: pairs in the reference's emission order (rows sorted by source); random: as drawn")
 ap.add_argument("--forms", default="gather,lds,tiled", help="gather, lds, tiled")
 ap.add_argument("--no-check", action="store_true", help="timing-only (ablation) builds: do not compare the forms")
+ap.add_argument("--tiled-forms", default="default", help="only with tools/experiments/aggregate_two_buffers.patch applied: 0 (one tile buffer), 1 (two), or 0,1")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 F32, I32 = torch.float32, torch.int32
@@ -84,19 +85,24 @@ for cfg in a.configs.split(","):
         ms_g = timed(gather, a.reps)
         rec["gather"] = {"ms": round(ms_g, 4), "GBps": round(alg / ms_g / 1e6, 1), "frac_of_8TBps": round(alg / ms_g / 8e9, 4)}
     if "tiled" in forms:
-        plan = ops.csr_tile_plan(rp, col, norm, S)
-        st = plan.stats
-        rec["tiled"] = {"plan_valid": plan.valid, **({"geometry": plan.geom} if plan.stats else {}),
+        tforms = [None] if a.tiled_forms == "default" else [int(v) for v in a.tiled_forms.split(",")]
+        for tf in tforms:
+            if tf == 1 and S > getattr(ops, "TILED2_ROWS_MAX", 0):
+                continue
+            plan = ops.csr_tile_plan(rp, col, norm, S) if tf is None else ops.TilePlan(rp, col, norm, S, form=tf)
+            st = plan.stats
+            key = "tiled" if len(tforms) == 1 else f"tiled_form{tf}"
+            rec[key] = {"plan_valid": plan.valid, **({"geometry": plan.geom} if plan.stats else {}),
                         "stream": {k: st.get(k) for k in ("edges", "slots", "efficiency", "stream_bytes", "mean_run")},
                         "run_histogram": st.get("run_histogram")}
-        if plan.valid:
-            tiled = lambda: plan.aggregate(x, None, bias, scale, shift, ops.ACT_RELU)   # noqa: E731
-            assert a.no_check or torch.equal(tiled(), want), f"tiled form differs from the gather form at S={S}"
-            ms_t = timed(tiled, a.reps)
-            alg_t = 2 * N * C * 4 + st["stream_bytes"] + N * 8          # what this form reads instead of the CSR: stream, row order, self-loop weights
-            rec["tiled"].update(ms=round(ms_t, 4), ms_best_round=round(timed.best, 4), rounds_ms=timed.rounds, GBps=round(alg / ms_t / 1e6, 1), frac_of_8TBps=round(alg / ms_t / 8e9, 4),
-                                bytes_this_form_moves=alg_t, bit_identical_to_gather=not a.no_check)
-        del plan
+            if plan.valid:
+                tiled = lambda: plan.aggregate(x, None, bias, scale, shift, ops.ACT_RELU)   # noqa: E731
+                assert a.no_check or torch.equal(tiled(), want), f"tiled form {tf} differs from the gather form at S={S}"
+                ms_t = timed(tiled, a.reps)
+                alg_t = 2 * N * C * 4 + st["stream_bytes"] + N * 8          # what this form reads instead of the CSR: stream, row order, self-loop weights
+                rec[key].update(ms=round(ms_t, 4), ms_median=round(ms_t, 4), ms_best_round=round(timed.best, 4), rounds_ms=timed.rounds, GBps=round(alg / ms_t / 1e6, 1),
+                                frac_of_8TBps=round(alg / ms_t / 8e9, 4), bytes_this_form_moves=alg_t, bit_identical_to_gather=not a.no_check)
+            del plan
     if S <= ops.LDS_BLOCK_ROWS_MAX and "lds" in forms:
         order = ops.csr_block_row_order(rp, S)                              # once per graph
         lds = lambda: blocks_form(rp, col, norm, x, bias, scale, shift, S, order)   # noqa: E731
