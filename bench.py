@@ -337,7 +337,7 @@ def pcie_inclusive_rate(runner, batches, B, T, steps, dev):
 def gpu_identity(local_rank):
     """Which physical card a rank runs on — the card's unique id and PCI location from the KFD topology in sysfs (the GPU nodes this
     process may open, in node order = HIP's device order; no exec, no GPU call): hand-off time-outs have been card-dependent
-    (DESIGN.md section 13.3), so every rank says where it ran (`per_rank` of the bench line)."""
+    (profiles/LOG_r01_r04.md section 13.3), so every rank says where it ran (`per_rank` of the bench line)."""
     import glob
     try:
         gpus = []
@@ -512,7 +512,7 @@ def main():
     ap.add_argument("--precision", default="split", choices=["f32", "f16", "split"],
                     help="arithmetic of the recurrent W_hh.h products.  split (default): fp32 operands decomposed EXACTLY into "
                          "three fp16 pieces, every cross term >= 2^-24 kept, fp32 accumulate — fp32 in, fp32 out, no operand "
-                         "bit dropped (DESIGN.md section 12); f32: the fp32 matrix cores; f16: opt-in fp16-operand encoder "
+                         "bit dropped (DESIGN.md section 5; profiles/LOG_r01_r04.md section 12); f32: the fp32 matrix cores; f16: opt-in fp16-operand encoder "
                          "(BASELINE configs[4]), NOT parity-exact — the line then carries the agreement with the f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -962,25 +962,41 @@ def main():
     # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
     # profiles/r05_pmc_traffic.json (tools/r05_profiles.sh + tools/collect_profiles.py; r04's while that one is absent), FETCH_SIZE doubled as the gfx950 guide
     # prescribes; only quoted when this run is a workload / batch / precision those passes measured.
+    # Both summaries carry the source hash of the tree they were measured on (gnnpn_sc_amd._lib.source_hash); they are quoted only
+    # while it equals the loaded library's — after any kernel change they read null until the passes have been re-run.
+    from gnnpn_sc_amd import _lib as _glib
+    lib_hash = _glib.source_hash()
+    counters_state = {}
+
+    def committed(name):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        counters_state[name] = "current" if d.get("source_hash") == lib_hash else f"stale (measured on sources {d.get('source_hash')}, library is {lib_hash}): not quoted"
+        return d if d.get("source_hash") == lib_hash else None
+
     def pmc_traffic(precision):
         try:
-            name = next(n for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                pmc = json.load(f)
+            name = next(n for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc = committed(name)
+            if pmc is None:
+                return {}
             return {k: v["traffic"] for k, v in pmc.get(f"{args.workload}_b{B}_{precision}", {}).get("kernels", {}).items()}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, StopIteration):
             return {}
     # Matrix-pipe utilisation of the two recurrent kernels (BASELINE north_star: "MFMA utilisation ... against gfx950 peak") from the
     # committed SQ-counter passes of the same eager command (tools/r05_recurrent_sq.sh -> profiles/r05_recurrent_sq_summary.json):
     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).  Quoted, like `traffic`: rocprofv3 cannot run inside this process.
     def sq_mfma_util(precision):
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_recurrent_sq_summary.json")) as f:
-                sq = json.load(f)["kernels"]
+            name = next(n for n in ("r06_recurrent_sq_summary.json", "r05_recurrent_sq_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            sq = committed(name)
+            if sq is None:
+                return {}
+            sq = sq["kernels"]
             names = {"lstm_encode": "lstm_encode_coop_kernel", "pointer_decode": "pointer_decode_lean_kernel"}
             return {k: sq[f"{args.workload}/{precision}/{n}"]["derived"]["mfma_busy_frac_of_all_simds"] for k, n in names.items()
                     if f"{args.workload}/{precision}/{n}" in sq and B == WORKLOADS[args.workload]["B"]}     # the passes ran the default batch
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, StopIteration):
             return {}
     traffic = pmc_traffic(args.precision)
     util = sq_mfma_util(args.precision)
@@ -997,11 +1013,13 @@ def main():
     if world == 1 and args.graph and not args.no_kernel_timers:
         agg = batched_aggregate_roofline(table, B, dev)
         try:     # the committed PMC passes of tools/r04_aggregate_profiles.sh, keyed by shape (rows per copy x copies) and kernel
-            with open(os.path.join(ROOT, "profiles", "r04_csr_aggregate_pmc_traffic.json")) as f:
-                pm = json.load(f)
+            pname = next(n for n in ("r06_csr_aggregate_pmc_traffic.json", "r05_csr_aggregate_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pm = committed(pname)
+            if pm is None:
+                raise KeyError(pname)
             kname = {"tiled": "csr_aggregate_tiled_kernel", "l2-gather": "csr_aggregate_kernel"}.get(agg["form"])
             agg["traffic"] = pm["shapes"][f"{agg['rows'] // agg['copies']}x{agg['copies']}"][kname]["traffic"]
-        except (OSError, ValueError, KeyError, ZeroDivisionError):
+        except (OSError, ValueError, KeyError, ZeroDivisionError, StopIteration):
             agg["traffic"] = None
     roof = None
     if kernels:
@@ -1009,7 +1027,8 @@ def main():
         roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
                 "unit": k0["unit"], "frac": k0["frac"], "traffic": k0["traffic"],
                 # where `traffic` and `mfma_util` come from: committed rocprofv3 --pmc passes of the same eager command, NOT this run
-                "counters_from": "profiles/r05_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r05_recurrent_sq_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles)"}
+                "counters_from": {"what": "committed rocprofv3 --pmc passes of the same eager command: FETCH_SIZE x 2 + WRITE_SIZE per launch; SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles",
+                                  "library_source_hash": lib_hash, "files": counters_state}}
         if "mfma_util" in k0:
             roof["mfma_util"] = k0["mfma_util"]
         if "fp32_equivalent" in k0:      # split: `achieved` counts the six EXECUTED f16 products per fp32 term

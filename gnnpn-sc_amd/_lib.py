@@ -150,6 +150,23 @@ class GnnpnError(RuntimeError):
     pass
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the device sources this library is built from — csrc/*.hip, csrc/*.h, csrc/torch_ops.cpp and
+    include/gnnpn_hip.h, names and contents in sorted order.  The committed counter summaries under profiles/ (PMC traffic, SQ
+    matrix-pipe utilisation) carry the hash of the tree they were measured on; bench.py quotes them beside freshly measured numbers
+    only while it equals this one (they used to be keyed by workload, batch and precision alone and went stale silently)."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".hip", ".h", ".cpp")))
+    files.append(os.path.join(root, "include", "gnnpn_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Load libgnnpn_hip.so (once) and declare every entry point.  Raises if it is not built."""
     global _lib

@@ -202,7 +202,7 @@ namespace {   // one copy per translation unit
 // The zeros are written with AGENT-scope stores (sc1: write-through to the level the cooperative kernel's atomics and sc1 loads
 // work on), not left dirty in the L2 of whichever XCD ran the block: the words of the status area are modified by device-scope
 // atomics of the next kernel, and a failure record of round 4 showed a launch that started on seat counters of 32 + 3 and 32 + 20
-// on two XCDs — the previous launch's totals, i.e. zeros that had not arrived.
+// on two XCDs — the previous launch's totals, i.e. zeros that had not arrived (profiles/LOG_r01_r04.md section 13.3).
 // The same kernel books the work the launch behind it is EXPECTED to do (`expected` workgroup-tiles, added to word `word` of the
 // caller's status block: gnnpn_launch_opts_t.sticky_status, GNNPN_STATUS_*): every seated workgroup of the cooperative kernel adds
 // the tiles it FINISHED to the word next to it when it leaves (coop_note_finished), and the host compares the two after a
@@ -479,7 +479,7 @@ __device__ __forceinline__ void mfma_chain_pair(const float* src, int c, int kq,
 // recurrent step against 128 x 32.  The three magnitude classes accumulate in three SEPARATE fp32 accumulators (the matrix
 // core aligns the products of a group to its largest term and drops what falls below 2^-24 of it — measured,
 // tools/probes/mfma_accum_model.hip — so small terms must not share an accumulator with large ones) and are combined once,
-// by two fused multiply-adds.  Error bound and measurements: DESIGN.md section 12.
+// by two fused multiply-adds.  Error bound and measurements: DESIGN.md section 5; profiles/LOG_r01_r04.md section 12.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDH16 = 264;                 // row stride in halfs (528 B: 16-B aligned, bank slots spread)
 constexpr int SPLIT_TILE = 16 * LDH16;     // halfs per piece tile; the LDS h tile is [3 pieces][16 rows][LDH16]
@@ -591,7 +591,7 @@ __device__ __forceinline__ void split_chain(const _Float16* base, const f16x8 (&
     // of 8 k's, aligning a group's 8 products and the accumulator to the largest of them, dropping what falls below 2^-24 of
     // it and rounding once (tools/probes/mfma_accum_model.hip) — 10 error events of <= 2^-24 of the running magnitude per
     // group.  16 groups per accumulator keep the worst-case constant at 10 x 16 + 2 = 162 units of 2^-24 sum|h w|, below the
-    // 256 of a 256-term fp32 fma chain (32 groups in one accumulator would be 320); DESIGN.md section 12.
+    // 256 of a 256-term fp32 fma chain (32 groups in one accumulator would be 320); profiles/LOG_r01_r04.md section 12.
     f32x4 a0[NT], a0b[NT], a1[NT], a2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) a0[n] = a0b[n] = a1[n] = a2[n] = f32x4{0.f, 0.f, 0.f, 0.f};

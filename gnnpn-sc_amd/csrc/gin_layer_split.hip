@@ -1,5 +1,5 @@
 // The one-launch GIN layer of gin_layer.hip with its three dense products on the fp16 matrix cores through the EXACT SPLIT
-// of coop_common.h (the arithmetic the recurrent kernels use): every fp32 operand — activations and
+// of coop_common.h (the arithmetic the recurrent kernels use; profiles/LOG_r01_r04.md section 12): every fp32 operand — activations and
 // weights — is decomposed into three fp16 pieces that reproduce it bit for bit, the six cross products that can reach
 // 2^-24 of a term run on v_mfma_f32_16x16x32_f16 into three fp32 accumulators (one per magnitude class), and nothing else
 // of the layer changes: the neighbour aggregate, bias, BatchNorm and ReLU are the fp32 instructions of gin_layer.hip.
@@ -23,7 +23,7 @@
 #include "coop_common.h"
 
 // (The timing-only builds and the tile / depth / occupancy / piece-form variants that were measured and not kept live in
-// tools/experiments/gin_layer_split_switches.patch, applied by tools/ablate_gin_layer.py; profiles/LOG_r04.md has the numbers.)
+// tools/experiments/gin_layer_split_switches.patch, applied by tools/ablate_gin_layer.py; profiles/LOG_r01_r04.md has the numbers.)
 
 namespace {
 
@@ -64,7 +64,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // the activation fragment its second: the accumulator is the transposed tile — lane (c, kq) holds features 4 kq .. 4 kq + 3 of
 // batch row c, i.e. four CONSECUTIVE k's of the next stage (one 8-byte LDS store per piece, one row maximum per lane).
 // FIRST: k-blocks 0..3 (the leading product goes to a0), else to a0b — 16 groups of 8 k's per accumulator at most, the bound
-// of DESIGN.md section 12.
+// of DESIGN.md section 5; profiles/LOG_r01_r04.md section 12.
 template <bool FIRST>
 __device__ __forceinline__ void kblock(const _Float16* a_lane, int lda, int piece, int kk, const BFrag (&b)[NCT], Acc (&acc)[RT][NCT]) {
     f16x8 h0[RT], h1[RT], h2[RT];

@@ -45,7 +45,7 @@ constexpr int META_INVALID = 0, META_QUADS = 1, META_EDGES = 2, META_SLOTS = 3, 
 
 // (The variants that were measured and not kept — 8 waves with half-size tiles, a persistent walk, a shared plan, eight quads of
 // stream look-ahead, deeper fills — and the timing-only ablation builds live in tools/experiments/aggregate_switches.patch, applied by
-// tools/ablate_aggregate.py; profiles/LOG_r04.md has the numbers.)
+// tools/ablate_aggregate.py; profiles/LOG_r01_r04.md has the numbers.)
 constexpr int WAVES = 16;                 // wavefronts per workgroup: one workgroup per CU
 constexpr int TILE_ROWS_MAX = 2559;       // source rows per tile: (2559 + 1 zero row) * 16 channels * 4 B = 160 KB
 constexpr int FILL_LATER = 5;             // rows in flight per lane when a later source tile is filled (the accumulators are live)

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool sweep_quarter(const u64* buf, unsigned tag, floa
 // PREC 2 = exact-split operands (coop_common.h): W_hh and h_{t-1} each as THREE fp16 pieces that reproduce the fp32 value
 // bit for bit, every cross term that can reach 2^-24 of a product kept (6 products on the fp16 matrix cores, fp32
 // accumulation in three magnitude classes: 96 MFMAs of 16 cycles per step instead of 128 of 32).  h travels between the
-// members already split (the publisher splits its own value once).  Error bound and measurements: DESIGN.md section 12.
+// members already split (the publisher splits its own value once).  Error bound and measurements: DESIGN.md section 5; profiles/LOG_r01_r04.md section 12.
 template <int PREC, bool PRE, bool DIAG>
 __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets, u64* __restrict__ xchg,
                                                                   unsigned* __restrict__ err, unsigned* __restrict__ sticky,

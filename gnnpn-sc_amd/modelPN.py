@@ -27,7 +27,7 @@ from . import custom_ops, ops
 # evaluated inside the recurrent kernel (W_ih.(W_e x + b_e) + b_ih = (W_ih W_e) x + (W_ih b_e + b_ih)):
 # an exact algebraic identity that removes the [B*L,256]x[256,1024] GEMM and the 246 MB pre-gate
 # round trip per net.  It rounds differently from the reference's two-stage evaluation (by about the
-# reference's own rounding error, DESIGN.md §5); set False for the literal two-stage order.
+# reference's own rounding error, DESIGN.md section 6 item 7); set False for the literal two-stage order.
 FOLD_INPUT_PROJECTION = True
 
 qosandcons = 8   # modelPN.py:10
@@ -371,7 +371,7 @@ class CombinatorialRL(nn.Module):
 def default_precision(low, high, fold=None, sampling=False, decode_impl=0):
     """The arithmetic of the two recurrent W_hh.h products when the caller does not choose: the exact three-piece split
     ("split": fp32 in, fp32 out, no operand bit dropped, error bound and measured error below the fp32 matrix chain's,
-    identical selections on every pinned problem, 1.4-1.5 x the throughput — DESIGN.md section 12, and what bench.py
+    identical selections on every pinned problem, 1.4-1.5 x the throughput — DESIGN.md section 5; profiles/LOG_r01_r04.md section 12, and what bench.py
     measures) wherever its kernels apply — the cooperative, folded, greedy form: hidden size 256, windows of at most 16
     candidates, no category embedding, no general attention — and the fp32 matrix cores ("f32") everywhere else."""
     la, ha = low.actor, high.actor

@@ -51,7 +51,7 @@ LDS_BLOCK_ROWS_MAX = 10239      # (block_rows + 1) * 16 B <= 160 KB: the block a
 LDS_MIN_WORKGROUPS = 128        # below this many (block, slice) workgroups the one-wave-per-row gather fills the chip better
 LDS_SLICE16_ROWS_MAX = 2559     # blocks up to here stage 16-channel slices: the LDS-staged form is the faster one there
 PREFER_LDS_AGGREGATE = None     # None: the LDS-staged form where it is measured faster (16-channel slices, enough workgroups:
-#                                 profiles/r02_csr_aggregate_roofline.json, DESIGN.md section 8); True / False force the choice
+#                                 profiles/r02_csr_aggregate_roofline.json, DESIGN.md section 3); True / False force the choice
 _row_orders = {}                # id(rowptr tensor) -> (weak reference to it, block_rows, order)
 
 
@@ -421,6 +421,7 @@ class Workspaces:
         self.launched = [0, 0]            # workgroup-tiles asked of the encoder / decoder launches on this object (host count)
         self._captured = [0, 0]           # ... of the launches recorded into a HIP graph that nobody has claimed yet (take_captured)
         self._untracked = False           # a captured graph replays these launches without telling: the host count is unknown
+        self._warned_untracked = False    # ... said once per object (_read)
         self.last_progress = None         # the counters the last poll / check read (diagnosis; bench.py's per_rank)
         self._encode = None
         self._decode = None
@@ -476,6 +477,14 @@ class Workspaces:
         word = w[0]
         if any(p["finished"] != p["expected"] or (not self._untracked and p["expected"] != p["host_expected"]) for p in prog.values()):
             word |= self.SHORTFALL
+        if self._untracked and not self._warned_untracked:
+            # a capture made outside ops.graph_replay replays cooperative launches without booking them: finished == expected is
+            # still checked, expected == the host's own count is not (and stays off for this object) — say so, once
+            import warnings
+            warnings.warn("gnnpn: cooperative launches on this Workspaces were captured into a HIP graph that ops.graph_replay does "
+                          "not wrap; the host-count half of the proof of work (expected == what the host asked for) is off for it — "
+                          "wrap the graph with ops.graph_replay(graph, [workspaces]) to keep it", RuntimeWarning, stacklevel=3)
+            self._warned_untracked = True
         self.last_progress = prog
         return word, prog
 
@@ -518,10 +527,12 @@ class Workspaces:
             if word & 2:
                 rec = decode_failure_record()
                 detail = f"; decoder failure record: {rec['failures']} sweeps, first: {rec['records'][:4]}"
-            raise GnnpnError(f"{what}: status {word:#x} — at least one cooperative launch since the last check failed (its outputs "
+            err = GnnpnError(f"{what}: status {word:#x} — at least one cooperative launch since the last check failed (its outputs "
                              f"are invalid); bits: 1 encoder sweep timed out, 2 decoder sweep timed out, 4 a group member never "
                              f"showed up, 8 the workspace was not clean when a launch began, 16 workgroup-tiles finished != expected "
                              f"(a launch did not do its work): {prog}; last launches' own words (encoder, decoder) = {last}{detail}")
+            err.status = word                 # the word itself, for callers with a degraded mode (PipelinedRunner.synchronize): no parsing of the text
+            raise err
 
 
 class lds_footprint:
@@ -619,7 +630,7 @@ def run_checked(fn, device=None, retries=1):
     inter-workgroup hand-off (its outputs are invalid) the batch is run AGAIN — ``attempt`` 1, 2, .. — up to ``retries`` times
     before the error is raised.  The drivers that write artefacts (ML2PN.infer, evalPN.evaluate) call their batches through this
     and pass ``write_through = attempt > 0`` (the placement-independent hand-off form) to the repeat: a time-out is rare and
-    box-dependent, results never silently come from a failed launch, and one bad launch does not end a
+    box-dependent (profiles/LOG_r01_r04.md section 13.3), results never silently come from a failed launch, and one bad launch does not end a
     run over thousands of batches.  Every repeat is reported with ``warnings.warn``."""
     import warnings
     for attempt in range(retries + 1):

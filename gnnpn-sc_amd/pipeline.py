@@ -90,7 +90,7 @@ class DeviceBatch:
 # fast form is liveness, not data: a granule is ONE 8-byte store carrying its own tag, so a reader sees an old granule or a new
 # one, never a mixture — a store that does not become visible ends in a bounded-spin time-out (status 1 / 2), and a launch that
 # did not run at all in a shortfall of finished workgroup-tiles (status 16): both are loud at the next poll / synchronize, and
-# the runner then switches ITSELF to the write-through form for the rest of its life (``auto_degrade``).  DESIGN.md section 5.
+# the runner then switches ITSELF to the write-through form for the rest of its life (``auto_degrade``).  DESIGN.md sections 4.5-4.6.
 DEFAULT_WRITE_THROUGH = os.environ.get("GNNPN_PIPE_WRITE_THROUGH", "0") == "1"
 HOST_COPY_ON_ITS_OWN_STREAM = os.environ.get("GNNPN_HOST_COPY_INLINE") != "1"
 COMMON_START_US = 0.0       # PipelinedRunner: > 0 holds the first replays of a burst until both are enqueued, at most this long.  OPT-IN since
@@ -605,5 +605,5 @@ class PipelinedRunner:
                 except ops.GnnpnError as e:      # every workspace is read (and cleared) before the first failure is raised
                     err = err or e
             if err is not None:
-                self._degrade(int(str(err).split("status ")[1].split(" ")[0], 16) if "status " in str(err) else 0xffff)
+                self._degrade(int(getattr(err, "status", 0xffff)))
                 raise err

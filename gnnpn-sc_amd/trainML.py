@@ -13,7 +13,7 @@ loss + gradient, embedding-table gradient, dot for GINConv's eps).  torch suppli
 Batches are assembled as torch_geometric 1.7.0's ``DataLoader(batch_size=2)`` assembles them (trainML.py:121-122): node
 features concatenated, workflow edges shifted by the node counts, one copy of the service table per graph, and the service
 edges of graph b shifted by the WORKFLOW node count of the graphs before it (``Data.__inc__`` keys on "index" — the
-reference's own batching, reproduced, not repaired; see DESIGN.md §5).
+reference's own batching, reproduced, not repaired; see DESIGN.md section 6 item 1).
 """
 import json
 import os

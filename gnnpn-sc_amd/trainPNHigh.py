@@ -283,6 +283,22 @@ def _pointer_model(level, hidden_size, n_glimpses, tanh_exploration, use_tanh, s
                            attention="Dot", level=level, use_cuda=use_cuda, sNumber=serNumber, sCategory=serCategory)
 
 
+def artefact_dataset(dataset, embeddingTag):
+    """The dataset part of every artefact path of a PNLow / PNHigh run, WITH its trailing slash: the reference appends
+    "20embeddings/" when the category embedding is on (trainPNHigh.py:197-198, trainPNLow.py:190-191: ``self.dataset += "20embeddings/"``
+    after the candidate rows have been loaded from the plain dataset directory), so that an embeddingTag=1 run writes its checkpoints,
+    allActions, val and time files under ./solutions/PN{Low,High}/<ds>/20embeddings/ and PNHigh finds its Low net there — beside, not
+    over, the embeddingTag=0 artefacts.  (The reference mutates self.dataset, so a second start() would append twice; this is a
+    function of the constructor's value.)"""
+    return dataset + ("20embeddings/" if embeddingTag else "")
+
+
+def low_checkpoint_path(ds, epochPNLow):
+    """Where PNHigh loads its Low net from (trainPNHigh.py:237-240); ``ds`` = artefact_dataset(...).  With the embedding on the
+    pretrained file is ./solutions/pretrained/<ds>/20embeddings-PNLow.model, as the reference's ``self.dataset[:-1]`` gives."""
+    return (f"./solutions/PNLow/{ds}/epoch{epochPNLow}.model" if epochPNLow >= 0 else f"./solutions/pretrained/{ds[:-1]}-PNLow.model")
+
+
 class PNHigh:
     """PNHigh (trainPNHigh.py:175-251): same constructor; ``start`` loads the candidate rows (loadDataPN), the trained Low
     net (./solutions/PNLow/<ds>/epoch{n}.model or ./solutions/pretrained/<ds>-PNLow.model) and trains the High net."""
@@ -298,17 +314,17 @@ class PNHigh:
     def start(self, n_epochs=100, device="cuda:0", batch_size=128):
         from .loadData import loadDataPN
         rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :196
+        ds = artefact_dataset(self.dataset, self.embeddingTag)                                     # :197-198
         n_train = len(rows) // 4 * 3
         train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], bool(self.embeddingTag))     # :203-204
         val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], bool(self.embeddingTag))
         args = (self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber, self.serCategory, self.USE_CUDA,
                 self.embeddingTag)
         low, high = _pointer_model("Low", *args), _pointer_model("High", *args)
-        root = (f"./solutions/PNLow/{self.dataset}/epoch{self.epochPNLow}.model" if self.epochPNLow >= 0 else
-                f"./solutions/pretrained/{self.dataset[:-1]}-PNLow.model")                          # :237-240
+        root = low_checkpoint_path(ds, self.epochPNLow)                                            # :237-240
         low.load_state_dict(torch.load(root, map_location="cpu")["model"])                         # :241-242
         dev = torch.device(device)
-        tm = TrainModel(high.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, self.dataset[:-1], self.serCategory,
+        tm = TrainModel(high.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, ds[:-1], self.serCategory,
                         self.lr, batch_size, None, self.max_grad_norm, low_model=low.to(dev), device=device)
         tm.train_and_validate(n_epochs, self.epochDiv)                                             # :251
         return tm
@@ -328,13 +344,14 @@ class PNLow:
     def start(self, n_epochs=50, device="cuda:0", batch_size=128):
         from .loadData import loadDataPN
         rows, labels = loadDataPN(epoch=self.epochML, dataset=self.dataset[:-1], serviceNumber=self.serNumber)   # :190-191
+        ds = artefact_dataset(self.dataset, self.embeddingTag)                                     # trainPNLow.py:190-191
         n_train = len(rows) // 4 * 3
         train_ds = evalPN.SCDataset(rows[:n_train], labels[:n_train], bool(self.embeddingTag))     # trainPNLow.py:193-194
         val_ds = evalPN.SCDataset(rows[n_train:], labels[n_train:], bool(self.embeddingTag))
         model = _pointer_model("Low", self.hidden_size, self.n_glimpses, self.tanh_exploration, self.use_tanh, self.serNumber,
                                self.serCategory, self.USE_CUDA, self.embeddingTag)
         dev = torch.device(device)
-        tm = TrainModel(model.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, self.dataset[:-1], self.serCategory,
+        tm = TrainModel(model.to(dev), train_ds, val_ds, self.epochDiv, self.beta, self.USE_CUDA, ds[:-1], self.serCategory,
                         self.lr, batch_size, None, self.max_grad_norm, low_model=None, device=device)
         tm.train_and_validate(n_epochs, self.epochDiv)                                             # :223
         return tm

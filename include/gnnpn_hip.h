@@ -267,7 +267,7 @@ int gnnpn_precision_at_k(const int32_t* ranking, int64_t ld_rank, const float* l
  *     the kernel as inputs_t . w_in^T + b_in (F must be 8).  With w_in = W_ih . W_emb and
  *     b_in = W_ih . b_emb + b_ih this folds embedding2 (modelPN.py:190) and the LSTM's input
  *     projection into one [4H, 8] matrix — an exact algebraic identity, rounded differently
- *     (DESIGN.md §5); only the cooperative form evaluates it in-kernel.
+ *     (DESIGN.md section 6 item 7); only the cooperative form evaluates it in-kernel.
  *   whh_packed [H/4][gate][j][4] fp32  = W_hh[gate*H + j][k..k+3]   (ops.pack_lstm_weight)
  *   bhh [4H];   outputs enc_out [B, L, H], h_n / c_n [B, H]
  * H must be 256 or 32 (environment.ini:55 and the unit fixtures).  `nets` is a HOST array.
@@ -292,7 +292,7 @@ typedef struct {
  *   GNNPN_PREC_SPLIT every operand as THREE fp16 pieces that reproduce the fp32 value bit for bit (x 2^s = p0 + p1/2^11 +
  *                    p2/2^22), every cross term that can reach 2^-24 of a product kept (6 products on the fp16 matrix
  *                    cores), fp32 accumulation in three magnitude classes: fp32 operands, fp32 result, no operand bit
- *                    dropped; error bound <= the fp32 fma chain's (gnnpn_split3_pieces_f32 and
+ *                    dropped; error bound <= the fp32 fma chain's (profiles/LOG_r01_r04.md section 12; gnnpn_split3_pieces_f32 and
  *                    gnnpn_recurrent_product_f32 below expose the arithmetic to the tests)
  * F16/SPLIT need the cooperative form (H = 256 and a workspace): GNNPN_E_UNSUP otherwise. */
 #define GNNPN_PREC_F32 0
@@ -646,7 +646,7 @@ int gnnpn_debug_lds_interferer(int32_t n_workgroups, int32_t lds_bytes, int32_t 
 /* Test hook: D = A . B + C by ONE v_mfma_f32_16x16x32_f16 (A [16][32], B [32][16] fp32 values representable in fp16; C, D
  * [16][16] fp32) — lets a test pin the accumulate model of the f16 matrix core that the a-priori error bound of the
  * exact-split recurrent product rests on (groups of 8 k, truncation below 2^-24 of the group's largest operand, one
- * round-to-nearest-even per group: DESIGN.md section 12, tools/probes/mfma_accum_model.hip). */
+ * round-to-nearest-even per group: DESIGN.md section 5; profiles/LOG_r01_r04.md section 12, tools/probes/mfma_accum_model.hip). */
 int gnnpn_debug_mfma_f16(const float* A, const float* B, const float* C, float* D, void* stream);
 
 /* ES-WOA fine-tuning of P compositions in one launch (one wavefront per problem).  Replaces `ESWOA.__init__` +

@@ -4,7 +4,7 @@ path, restated in plain Python/numpy from /root/reference/src/loadData.py and
 tests/golden/make_golden.py (fixtures tests/golden/data_*.json).
 
 All functions take already-parsed JSON (python lists / dicts) so that tests need no files; the
-reference's file names are listed in DESIGN.md §artefacts.
+reference's file names are listed in DESIGN.md section 1 and INTEGRATION.md.
 """
 import numpy as np
 

@@ -22,7 +22,7 @@ def golden(name):
 
 def _record_box():
     """Which card this run is on (unique id, partition modes, firmware): gpurun_out/parity/box_info.json — hand-off time-outs
-    have been box-dependent, so every GPU run of the suite says where it ran."""
+    have been box-dependent (profiles/LOG_r01_r04.md section 13.3), so every GPU run of the suite says where it ran."""
     import json
     import subprocess
     info = {}

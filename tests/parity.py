@@ -112,3 +112,26 @@ def prefix_parity(got_low, got_high, fx, what, rows=None, tau_high=None):
             "identical_decisions": int(2 * first.sum()),
             "flips": len(flips), "flip_margins": [round(f["margin"], 7) for f in flips][:64],
             "same_mask": (first == T)}
+
+
+def oracle_candidate_rows(pb, table, rankings, n_per, nodes_per):
+    """The candidate rows of the first len(rankings) problems of a synthetic batch by the ORACLE's reduction
+    (oracle.data.reduce_candidates, pinned to the real loadDataPN — src/loadData.py:101-149 — by tests/golden/make_golden.py),
+    not by the product's host helper gnnpn_sc_amd.loadData.reduce_from_ranking: the synthetic problem and table are first put into
+    the reference's own formats (nodes = one-hot type + 6 floats, loadData.py:26-33; serviceFeature = {"1": [[q0..q3], ...], ...},
+    :35-40).  -> float32 [n, T * n_per, 8] (column 0, the category, dropped as SCDataset does, trainPNHigh.py:23-31)."""
+    import numpy as np
+    from oracle import data as odata
+    T = table.n_cat
+    feature = {str(c + 1): [[float(v) for v in table.qos[s]] for s in range(int(table.cat_ptr[c]), int(table.cat_ptr[c + 1]))]
+               for c in range(T)}
+    out = []
+    for i, ranking in enumerate(rankings):
+        nodes = []
+        for row in pb.x[i * nodes_per:(i + 1) * nodes_per]:
+            onehot = [0] * (T + 1)
+            onehot[int(row[0])] = 1
+            nodes.append(onehot + [float(v) for v in row[1:]])
+        rows, _ = odata.reduce_candidates([int(s) for s in ranking], nodes, feature, n_per)
+        out.append(rows)
+    return torch.tensor(np.asarray(out, dtype=np.float64), dtype=torch.float32)[:, :, 1:]

@@ -309,7 +309,7 @@ def test_first_replays_of_a_burst_start_together(dev):
     other slot's first one are held behind ONE gate (gnnpn_gate_wait on slot 0's transfer stream, opened by the host when the second
     replay is enqueued, by synchronize / poll, or after pipeline.COMMON_START_US) — the later
     ones are not, batches from host memory are not, a runner without the option is not; the results are what a single stream
-    gives.  (What the common start is worth is a measurement: tools/probes/stagger_probe.py)"""
+    gives.  (What the common start is worth is a measurement: tools/probes/stagger_probe.py, profiles/LOG_r01_r04.md section 13.4.)"""
     import gnnpn_sc_amd.synth as synth
     from bench import build_models
     from gnnpn_sc_amd import ops, pipeline
@@ -762,7 +762,7 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
     assert runner.halves == (shape != "qws_two_slots")
     packed = [runner.pack(b) for b in batches]
     # the single-stream reference runs use the device's default workspaces: conftest.eager_reference checks their status like the
-    # runner's and repeats a failed attempt once (seen on some boxes of the pool); repeats are recorded
+    # runner's and repeats a failed attempt once (seen on some boxes of the pool; profiles/LOG_r01_r04.md section 13.3); repeats are recorded
     import warnings
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")

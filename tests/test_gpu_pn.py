@@ -545,7 +545,7 @@ def test_a_launch_on_a_dirty_workspace_is_loud(dev):
     """coop_place's check that the status area was clean when the launch began (status code 8): with the per-launch zeroing
     switched off (test hook: lstm_ablate bit 13) a second encoder launch on the same workspace finds the first one's seat and
     arrival counters — every workgroup would leave as surplus and the outputs would be garbage with nothing timing out; instead the
-    launch's own word and the sticky word carry code 8 and ops.check_status raises.  (Seen for real: DESIGN.md section 13.3.)"""
+    launch's own word and the sticky word carry code 8 and ops.check_status raises.  (Seen for real: DESIGN.md section 4.4; profiles/LOG_r01_r04.md section 13.3.)"""
     from gnnpn_sc_amd import custom_ops, ops
     cfg = {"hidden": 256, "n_cat": 6, "n_per": 4, "seed_low": 1, "seed_high": 2}
     low, high = build(cfg, dev)

@@ -429,3 +429,77 @@ def test_run_checked_repeats_a_batch_once_after_a_failed_handoff(monkeypatch):
         warnings.simplefilter("ignore")
         with pytest.raises(ops.GnnpnError):
             ops.run_checked(lambda attempt: None)
+
+
+def test_embedding_runs_keep_their_artefacts_apart(tmp_path, monkeypatch):
+    """embeddingTag=1 runs write and read under ./solutions/PN{Low,High}/<ds>/20embeddings/ (the reference appends "20embeddings/" to
+    self.dataset after loading the candidate rows: trainPNHigh.py:197-198,237-240, trainPNLow.py:190-191), so they neither overwrite
+    the embeddingTag=0 checkpoints nor pick them up.  Host logic only: the drivers' path functions, and PNHigh.start /
+    PNLow.start up to the point where the paths are used (loadDataPN and TrainModel stubbed)."""
+    from gnnpn_sc_amd import trainPNHigh as tp
+    assert tp.artefact_dataset("QWS/", 0) == "QWS/" and tp.artefact_dataset("QWS/", 1) == "QWS/20embeddings/"
+    assert tp.low_checkpoint_path("QWS/", 7) == "./solutions/PNLow/QWS//epoch7.model"
+    assert tp.low_checkpoint_path("QWS/20embeddings/", 7) == "./solutions/PNLow/QWS/20embeddings//epoch7.model"
+    assert tp.low_checkpoint_path("QWS/", -1) == "./solutions/pretrained/QWS-PNLow.model"
+    assert tp.low_checkpoint_path("QWS/20embeddings/", -1) == "./solutions/pretrained/QWS/20embeddings-PNLow.model"
+    monkeypatch.chdir(tmp_path)
+    seen = {}
+
+    class FakeTM:
+        def __init__(self, model, train_ds, val_ds, epochDiv, beta, use_cuda, dataset, *a, **k):
+            seen["tm_dataset"] = dataset
+
+        def train_and_validate(self, *a):
+            pass
+
+    rows = [[[0.0] * 9 for _ in range(6)] for _ in range(8)]
+    import gnnpn_sc_amd.loadData as ld
+    monkeypatch.setattr(ld, "loadDataPN", lambda **k: (seen.setdefault("load_dataset", k["dataset"]) and None) or (rows, [[0] * 2] * 8))
+    monkeypatch.setattr(tp, "TrainModel", FakeTM)
+    monkeypatch.setattr(tp.evalPN, "SCDataset", lambda *a: None)
+
+    class FakeNet:
+        def load_state_dict(self, sd):
+            seen["loaded"] = sd
+
+        def to(self, dev):
+            return self
+    monkeypatch.setattr(tp, "_pointer_model", lambda *a, **k: FakeNet())
+    import torch
+    monkeypatch.setattr(torch, "load", lambda path, **k: seen.setdefault("low_path", path) and {"model": "sd"})
+    for tag, want_dir, want_low in ((0, "QWS", "./solutions/PNLow/QWS//epoch3.model"),
+                                    (1, "QWS/20embeddings", "./solutions/PNLow/QWS/20embeddings//epoch3.model")):
+        seen.clear()
+        tp.PNHigh("QWS", tag, False, 2, 1, 3, 32, 0, 10, True, 0.9, 2.0, 1e-4, 5, 3).start(1, device="cpu")
+        assert seen["load_dataset"] == "QWS"                     # the candidate rows always come from the plain dataset directory
+        assert seen["tm_dataset"] == want_dir and seen["low_path"] == want_low
+        seen.clear()
+        tp.PNLow("QWS", tag, False, 2, 1, 3, 32, 0, 10, True, 0.9, 2.0, 1e-4, 5).start(1, device="cpu")
+        assert seen["load_dataset"] == "QWS" and seen["tm_dataset"] == want_dir
+    p = tp.PNHigh("QWS", 1, False, 2, 1, 3, 32, 0, 10, True, 0.9, 2.0, 1e-4, 5, 3)
+    p.start(1, device="cpu")
+    p.start(1, device="cpu")                                      # a second start does not append twice (the reference would)
+    assert seen["tm_dataset"] == "QWS/20embeddings"
+
+
+def test_oracle_and_product_candidate_reduction_agree():
+    """The whole-pipeline GPU tests take the oracle-side candidate rows from oracle.data.reduce_candidates (tests/parity.py::
+    oracle_candidate_rows: the synthetic batch put into the reference's formats) — on the CPU the product's host helper of the
+    artefact path, loadData.reduce_from_ranking, is held to it on random rankings (dummy rows for absent categories included)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+    import torch
+    import gnnpn_sc_amd.synth as synth
+    from gnnpn_sc_amd.loadData import reduce_from_ranking
+    from parity import oracle_candidate_rows
+    for T, S, K, n_t in ((12, 300, 3, 5), (6, 90, 5, 6), (20, 400, 2, 7)):
+        table = synth.make_service_table(T, S, seed=T, degree=8)
+        pb = synth.make_problem_batch(table, 5, seed=S, tasks_per_problem=n_t, lo_range=(0.2, 0.99))
+        rng = np.random.default_rng(K)
+        rank = [rng.permutation(S) for _ in range(5)]
+        want = oracle_candidate_rows(pb, table, rank, K, min(T, n_t) + 1)
+        cat_of = np.repeat(np.arange(T), np.diff(table.cat_ptr))
+        got = torch.tensor([reduce_from_ranking(rank[i], pb.local_bounds[i], pb.present[i], pb.global_bounds[i], cat_of, table.qos, K)
+                            for i in range(5)], dtype=torch.float32)[:, :, 1:]
+        assert torch.equal(got, want), (T, S, K)

@@ -52,7 +52,9 @@ short = {"lstm_encode_coop_kernel": "lstm_encode", "pointer_decode_lean_kernel":
          "csr_aggregate_kernel<true>": "csr_aggregate_gcn", "select_candidates_kernel": "select_candidates", "select_candidates16_kernel": "select_candidates", "linear_f32_kernel<128": "linear_128",
          "linear_f32_kernel<64": "linear_64", "segment_mean_kernel": "segment_mean", "gin_layer_split_kernel<true>": "gin_layer1_split",
          "gin_layer_split_kernel<false>": "gin_layer0_split", "gin_layer_kernel<true>": "gin_layer1_f32", "gin_layer_kernel<false>": "gin_layer0_f32"}
-out = {"unit": "bytes per launch",
+sys.path.insert(0, R)
+from gnnpn_sc_amd._lib import source_hash   # noqa: E402  (the tree the passes were measured on: collect BEFORE editing csrc/)
+out = {"source_hash": source_hash(), "unit": "bytes per launch",
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over `bench.py --graph 0 --inflight 1` "
                  "(eager, one stream); counters are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
                  "reads); WRITE_SIZE as read; mean over the dispatches of the run"}
