@@ -581,8 +581,25 @@ def main():
 
     force_dist = os.environ.get("GNNPN_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
     use_dist = world > 1 or force_dist
+    first_collective_ms = None
     if use_dist:
         gdist.init_process_group("gloo" if share else "nccl", None if share else dev)
+        # the process group's FIRST collective (communicator set-up, ring discovery over xGMI) and a second one of the step's
+        # shape, timed on the host: a slow 8-GPU line whose cause is the collective, not the kernels, shows here (`per_rank`)
+        import time as _t
+        probe = torch.zeros((B, T), dtype=torch.int32, device=dev)
+        t0 = _t.perf_counter()
+        g0, w0 = gdist.all_gather_indices_async(probe, None)
+        if w0 is not None:
+            w0.wait()
+        torch.cuda.synchronize(dev)
+        t1 = _t.perf_counter()
+        g0, w0 = gdist.all_gather_indices_async(probe, g0)
+        if w0 is not None:
+            w0.wait()
+        torch.cuda.synchronize(dev)
+        first_collective_ms = {"first": round((t1 - t0) * 1e3, 3), "second": round((_t.perf_counter() - t1) * 1e3, 3)}
+        del probe, g0
 
     net, low, high = build_models(T, S, K, dev, w["n_gcn"])
     pipe = ML2PNPipeline(net, low, high, K, precision=args.precision)
@@ -678,6 +695,18 @@ def main():
                     gathers[key] = (gathers[key][0], None)
             return gathers[key][0], out["R"]
         return out["idx_high"], out["R"]
+
+    def seat_totals(r):
+        """Declined / off-canonical seats summed over every cooperative launch since the status blocks were last cleared, with the
+        encoder workgroup-tiles booked over the same launches (8 x nets x ceil(problems / 16) per launch) as the denominator."""
+        tot = {"declined": 0, "off_canonical": 0, "encoder_tiles_booked": 0}
+        for wsp in r.workspaces:
+            for k in ("declined", "off_canonical"):
+                tot[k] += (wsp.last_seats or {}).get(k, 0)
+            tot["encoder_tiles_booked"] += ((wsp.last_progress or {}).get("encoder") or {}).get("expected", 0)
+        launches = tot["encoder_tiles_booked"] / max(1, ops.Workspaces.coop_units(2, B if r.n_slots > 1 or not getattr(r, "halves", False) else B // 2))
+        tot["declined_per_encoder_launch"] = round(tot["declined"] / launches, 4) if launches else None
+        return tot
 
     def flush_bucket(st):
         """Gather the filled part of the current staging buffer (called on the slot's stream) and switch to the other one,
@@ -841,6 +870,10 @@ def main():
             "degraded": cur["degraded"], "placement_last_launch": [w.placement() for w in runner.workspaces] if runner is not None else None,
             # proof of work at the last poll of the timed rounds (one poll per round; counters are cumulative since the last failure)
             "progress": {"polls": getattr(timed_rounds, "polls", 0), "workspaces": runner.progress()} if runner is not None else None,
+            # placement events summed over EVERY cooperative launch of the run (sticky status words 1-2, ABI 9) and per timed step;
+            # the all-gather's first and second call on this rank (host wall clock, ms)
+            "seats": seat_totals(runner) if runner is not None else None,
+            "collective_ms": first_collective_ms,
             "gpu": gpu_identity(0 if share else local_rank)}
     per_rank = [mine]
     if world > 1:

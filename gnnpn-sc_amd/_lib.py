@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNPN_LIB: another build of the same library (the timing-only ablation builds of tools/ablate_aggregate.py); never set in a measured run
 LIB_PATH = os.environ.get("GNNPN_LIB") or os.path.join(_HERE, "libgnnpn_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -38,6 +38,8 @@ _SIGNATURES = {
     "gnnpn_gin_layer_f32": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, c_int32,
                                     _P, c_int64, c_int64, _P]),
     "gnnpn_split_weights_bytes": (c_int64, [c_int32, c_int32]),
+    "gnnpn_lstm_split_weights_bytes": (c_int64, []),
+    "gnnpn_lstm_pack_split_weights_f32": (c_int, [_P, _P, _P]),
     "gnnpn_pack_split_weights_f16": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "gnnpn_gin_layer_split": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32,
                                       _P, _P, _P, c_int32, _P, c_int64, c_int64, _P]),
@@ -96,7 +98,7 @@ class DecodeNet(ctypes.Structure):
     _fields_ = [(n, _P) for n in ("embedded", "enc_out", "h0", "c0", "start", "wih_packed", "whh_packed", "bih",
                                   "bhh", "latent_win", "emb_w", "emb_b", "xw_fold", "xb_fold", "start_fold", "idx", "win_logits", "pick_prob", "actions",
                                   "queries")] + \
-               [("latent_from", c_int32), ("sample", c_int32), ("sample_seed", ctypes.c_uint64)]
+               [("latent_from", c_int32), ("sample", c_int32), ("sample_seed", ctypes.c_uint64), ("whh_split", _P)]
 
 
 class Attention(ctypes.Structure):
@@ -140,7 +142,7 @@ class DecodeAttnTrain(ctypes.Structure):
 
 class EncodeNet(ctypes.Structure):
     """gnnpn_encode_net_t of include/gnnpn_hip.h."""
-    _fields_ = [(n, _P) for n in ("pregates", "inputs", "w_in", "b_in", "whh_packed", "bhh", "enc_out", "h_n", "c_n")]
+    _fields_ = [(n, _P) for n in ("pregates", "inputs", "w_in", "b_in", "whh_packed", "bhh", "enc_out", "h_n", "c_n", "whh_split")]
 
 
 _lib = None

@@ -333,6 +333,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 const bool reserve_arrival = arrival + target >= gridDim.x / 8;
                 if (fragments && !reserve_arrival) {
                     atomicAdd(status + 3, 1u);                                // statistics: arrivals that left because of their LDS position
+                    if (sticky) atomicAdd(sticky + GNNPN_STATUS_DECLINED_SEATS, 1u);   // ... cumulative over the caller's launches (ABI 9)
                     g = -2;                                                   // leave without holding the slot; the seat stays open
                 } else if (!fragments) {                         // (a badly placed RESERVE arrival does not rush for the seat either: it waits
                     //                                              with the reserve below and takes an open seat only if nobody better placed has)
@@ -382,6 +383,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                                 m = (int)(seat % G);
                                 coop_note_staffed(status, count, target, seats);
                                 atomicAdd(status + 2, 1u);       // statistics: seats taken off the canonical CU
+                                if (sticky) atomicAdd(sticky + GNNPN_STATUS_OFF_CANONICAL_SEATS, 1u);
                             }
                         }
                     }
@@ -575,6 +577,32 @@ __device__ __forceinline__ float split_weights(const float* __restrict__ Wp, int
     }
     return ldexpf(1.0f, -(15 + s));
 }
+// ---- the same split, made ONCE per model (round 6: gnnpn_lstm_pack_split_weights_f32).  Splitting inside the kernel costs every
+// cooperative launch 9-13 us of its fixed part (profiles/LOG_r05.md section 10: each lane reads its 128 weights twice — column maximum, then the
+// pieces: ~2 k vector instructions); the packed image holds exactly what split_weights leaves in a lane's registers and LDS slot, in
+// the order the lanes load it (64 lanes x 16 B contiguous per load instruction).  Per member m (8 per weight matrix), in uint4:
+//   [((tile * 2 + piece) * 8 + kk) * 256 + tid]      pieces 0 / 1 of k-block kk, tid = 64 * wave + lane          (8192 entries)
+//   [8192 + kk * 256 + tid]                          the third pieces' bytes {tile 0 lo, hi, tile 1 lo, hi}      (2048 entries)
+//   [10240 ...] as float[tile * 256 + tid]           the columns' un-scaling factors                             (128 entries)
+// Made by split_weights itself (lstm_pack_split_kernel, lstm_coop.hip): bit-identical to splitting in the kernel by construction.
+constexpr int SPLIT_PACK_U4_PER_MEMBER = 2 * 2 * 8 * 256 + 8 * 256 + 2 * 256 / 4;   // 10368 x 16 B = 165,888 B
+constexpr int SPLIT_PACK_MEMBERS = 8;
+__device__ __forceinline__ void load_split_weights(const uint4* __restrict__ pk, int tid, f16x8 (&w0)[2][8], f16x8 (&w1)[2][8],
+                                                   unsigned* wt_lane, float (&inv)[2]) {
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            w0[tl][kk] = __builtin_bit_cast(f16x8, pk[((tl * 2 + 0) * 8 + kk) * 256 + tid]);
+            w1[tl][kk] = __builtin_bit_cast(f16x8, pk[((tl * 2 + 1) * 8 + kk) * 256 + tid]);
+        }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) *reinterpret_cast<uint4*>(wt_lane + 4 * 64 * kk) = pk[8192 + kk * 256 + tid];
+    const float* fi = reinterpret_cast<const float*>(pk + 10240);
+    inv[0] = fi[tid];
+    inv[1] = fi[256 + tid];
+}
+
 // four third-piece bytes -> two packed fp16 pairs (byte b becomes the half b << 8)
 __device__ __forceinline__ f16x8 split_expand(unsigned lo, unsigned hi) {
     const u32x4 r = {__builtin_amdgcn_perm(0u, lo, 0x010c000cu), __builtin_amdgcn_perm(0u, lo, 0x030c020cu),

@@ -212,6 +212,7 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         GNNPN_REQUIRE(gnnpn_aligned(d.wih_packed, 16) && gnnpn_aligned(d.whh_packed, 16) &&
                           gnnpn_aligned(d.enc_out, 16) && (!d.embedded || gnnpn_aligned(d.embedded, 16)),
                       "pointer_decode: weights / enc_out / embedded must be 16-byte aligned");
+        GNNPN_REQUIRE(!d.whh_split || gnnpn_aligned(d.whh_split, 16), "pointer_decode: whh_split must be 16-byte aligned");
         static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "layout");
         memcpy(&args.net[n], &d, sizeof(DecodeNet));
     }

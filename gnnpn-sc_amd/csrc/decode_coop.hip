@@ -123,12 +123,16 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     float winv[2] = {1.0f, 1.0f};
     __shared__ __attribute__((aligned(16))) unsigned wts[SPLIT ? SPLIT_WT_DWORDS : 4];
     unsigned* wt_lane = wts + (SPLIT ? (wave * 8 * 64 + lane) * 4 : 0);
+    const uint4* __restrict__ Wsplit = SPLIT ? static_cast<const uint4*>(net.whh_split) : nullptr;   // uniform: packed once per model, or split here
+    if constexpr (SPLIT) {
+        if (Wsplit) load_split_weights(Wsplit + (size_t)member * SPLIT_PACK_U4_PER_MEMBER, tid, wH16, wL16, wt_lane, winv);
+    }
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = net.bhh[wrow[tl]];
         if constexpr (SPLIT) {
-            winv[tl] = split_weights<H>(net.whh, gate, u, kq, wH16[tl], wL16[tl], wt_lane + 2 * tl);
+            if (!Wsplit) winv[tl] = split_weights<H>(net.whh, gate, u, kq, wH16[tl], wL16[tl], wt_lane + 2 * tl);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 64; ++kk) wBh[tl][kk] = net.whh[((size_t)(kk * 4 + gate) * H + u) * 4 + kq];

@@ -28,6 +28,7 @@ struct DecodeNet {
     int32_t latent_from;
     int32_t sample;
     uint64_t sample_seed;
+    const void* whh_split;       // or nullptr (gnnpn_lstm_pack_split_weights_f32)
 };
 static_assert(sizeof(DecodeNet) == sizeof(gnnpn_decode_net_t), "DecodeNet must mirror gnnpn_decode_net_t");
 

@@ -108,6 +108,8 @@ extern "C" int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* in, i
         nets.w_in[n] = e.w_in;
         nets.b_in[n] = e.b_in;
         nets.whh[n] = e.whh_packed;
+        GNNPN_REQUIRE(!e.whh_split || gnnpn_aligned(e.whh_split, 16), "lstm_encode: whh_split must be 16-byte aligned");
+        nets.whh_split[n] = e.whh_split;
         nets.bhh[n] = e.bhh;
         nets.enc_out[n] = e.enc_out;
         nets.h_n[n] = e.h_n;

@@ -143,12 +143,16 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     float winv[2] = {1.0f, 1.0f};                            // ... and the columns' un-scaling factors
     __shared__ __attribute__((aligned(16))) unsigned wts[SPLIT ? SPLIT_WT_DWORDS : 4];
     unsigned* wt_lane = wts + (SPLIT ? (wave * 8 * 64 + lane) * 4 : 0);
+    const uint4* __restrict__ Wsplit = SPLIT ? static_cast<const uint4*>(nets.whh_split[net]) : nullptr;   // uniform: packed once per model, or split here
+    if constexpr (SPLIT) {
+        if (Wsplit) load_split_weights(Wsplit + (size_t)member * SPLIT_PACK_U4_PER_MEMBER, threadIdx.x, wB16, wL16, wt_lane, winv);
+    }
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
         const int gate = wrow[tl] / H, u = wrow[tl] % H;
         bh[tl] = nets.bhh[net][wrow[tl]];
         if constexpr (SPLIT) {
-            winv[tl] = split_weights<H>(Wp, gate, u, kq, wB16[tl], wL16[tl], wt_lane + 2 * tl);
+            if (!Wsplit) winv[tl] = split_weights<H>(Wp, gate, u, kq, wB16[tl], wL16[tl], wt_lane + 2 * tl);
         } else if constexpr (F16) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
@@ -383,6 +387,44 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     }
 }
 
+
+// ---- the exact split of a recurrent weight matrix, once per model (coop_common.h: load_split_weights).  One workgroup per member;
+// every lane runs the SAME split_weights the cooperative kernels run for themselves and writes out what it leaves behind.
+__global__ __launch_bounds__(256) void lstm_pack_split_kernel(const float* __restrict__ Wp, uint4* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned wts[SPLIT_WT_DWORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, c = lane & 15;
+    const int member = blockIdx.x;
+    const int unit = member * UNITS + wave * 8 + (c & 7);
+    f16x8 w0[2][8], w1[2][8];
+    float inv[2];
+    unsigned* wt_lane = wts + (wave * 8 * 64 + lane) * 4;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) inv[tl] = split_weights<H>(Wp, 2 * tl + (c >> 3), unit, kq, w0[tl], w1[tl], wt_lane + 2 * tl);
+    uint4* pk = out + (size_t)member * SPLIT_PACK_U4_PER_MEMBER;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            pk[((tl * 2 + 0) * 8 + kk) * 256 + tid] = __builtin_bit_cast(uint4, w0[tl][kk]);
+            pk[((tl * 2 + 1) * 8 + kk) * 256 + tid] = __builtin_bit_cast(uint4, w1[tl][kk]);
+        }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) pk[8192 + kk * 256 + tid] = *reinterpret_cast<const uint4*>(wt_lane + 4 * 64 * kk);   // (this lane's own slot: no barrier needed)
+    float* fi = reinterpret_cast<float*>(pk + 10240);
+    fi[tid] = inv[0];
+    fi[256 + tid] = inv[1];
+}
+
+extern "C" int64_t gnnpn_lstm_split_weights_bytes(void) { return (int64_t)SPLIT_PACK_MEMBERS * SPLIT_PACK_U4_PER_MEMBER * 16; }
+
+extern "C" int gnnpn_lstm_pack_split_weights_f32(const float* whh_packed, void* split, void* stream) {
+    GNNPN_REQUIRE(whh_packed && split, "lstm_pack_split_weights: null operand");
+    GNNPN_REQUIRE(gnnpn_aligned(whh_packed, 16) && gnnpn_aligned(split, 16), "lstm_pack_split_weights: operands must be 16-byte aligned");
+    static_assert(G == SPLIT_PACK_MEMBERS, "one packed block per group member");
+    hipLaunchKernelGGL(lstm_pack_split_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, whh_packed, static_cast<uint4*>(split));
+    GNNPN_CHECK_LAUNCH("lstm_pack_split_weights");
+    return GNNPN_OK;
+}
 
 // workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
 // stamps, hello granules), then the exchange buffers

@@ -10,6 +10,7 @@ struct LstmNets {
     const float* w_in[GNNPN_MAX_NETS];
     const float* b_in[GNNPN_MAX_NETS];
     const float* whh[GNNPN_MAX_NETS];
+    const void* whh_split[GNNPN_MAX_NETS];   // or nullptr: the exact-split build splits whh itself (coop_common.h: load_split_weights)
     const float* bhh[GNNPN_MAX_NETS];
     float* enc_out[GNNPN_MAX_NETS];
     float* h_n[GNNPN_MAX_NETS];

@@ -273,12 +273,13 @@ gnnpn_launch_opts_t launch_opts(int64_t impl, int64_t lds_kb, bool write_through
     return o;
 }
 
-// net_tensors: per net pregates, inputs, w_in, b_in, whh (packed), bhh (custom_ops.ENCODE_KEYS; None = absent).
+// net_tensors: per net pregates, inputs, w_in, b_in, whh (packed), bhh, whh_split (custom_ops.ENCODE_KEYS; None = absent).
 // workspace / status: ops.Workspaces.encode() and .status (required for the cooperative form, H = 256).
 // -> enc_out x n, h_n x n, c_n x n
 std::vector<Tensor> lstm_encode(const c10::List<OptTensor>& net_tensors, int64_t n_nets, std::string precision, int64_t impl, int64_t lds_kb,
                                 bool write_through, const OptTensor& workspace, const OptTensor& status, bool paired_start) {
-    TORCH_CHECK(n_nets >= 1 && (int64_t)net_tensors.size() == 6 * n_nets, "lstm_encode: six tensors per net");
+    constexpr size_t EK = 7;
+    TORCH_CHECK(n_nets >= 1 && net_tensors.size() == EK * (size_t)n_nets, "lstm_encode: seven tensors per net (custom_ops.ENCODE_KEYS)");
     std::vector<OptTensor> t(net_tensors.size());
     for (size_t i = 0; i < t.size(); ++i) t[i] = net_tensors.get(i);
     auto has = [&](size_t i) { return t[i].has_value() && t[i]->defined(); };
@@ -294,7 +295,7 @@ std::vector<Tensor> lstm_encode(const c10::List<OptTensor>& net_tensors, int64_t
     std::vector<gnnpn_encode_net_t> nets(n_nets);
     std::vector<Tensor> enc, hn, cn, keep;
     for (int64_t i = 0; i < n_nets; ++i) {
-        const size_t o = 6 * i;
+        const size_t o = EK * i;
         Tensor pre = has(o) ? *t[o] : Tensor();
         if (!pre.defined() && !coop) {                     // no in-kernel input projection in the streaming form: the same fma chain + bias
             TORCH_CHECK(has(o + 1) && has(o + 2) && has(o + 3), "lstm_encode: nets[", i, "] needs pregates or inputs + w_in + b_in");
@@ -312,6 +313,7 @@ std::vector<Tensor> lstm_encode(const c10::List<OptTensor>& net_tensors, int64_t
         }
         TORCH_CHECK(has(o + 4) && has(o + 5), "lstm_encode: nets[", i, "].whh / bhh required");
         a.whh_packed = f32(*t[o + 4], "nets.whh"), a.bhh = f32(*t[o + 5], "nets.bhh");
+        a.whh_split = has(o + 6) ? cptr<uint8_t>(*t[o + 6], at::kByte, "nets.whh_split") : nullptr;   // the exact split, made once per model
         a.enc_out = out_f32(enc.back()), a.h_n = out_f32(hn.back()), a.c_n = out_f32(cn.back());
     }
     const bool ws = coop && workspace.has_value() && workspace->defined();
@@ -325,16 +327,16 @@ std::vector<Tensor> lstm_encode(const c10::List<OptTensor>& net_tensors, int64_t
     return out;
 }
 
-// net_tensors: per net enc_out, h0, c0, start, wih, whh, bih, bhh, embedded, emb_w, emb_b, xw_fold, xb_fold, start_fold, latent_win
+// net_tensors: per net enc_out, h0, c0, start, wih, whh, bih, bhh, embedded, emb_w, emb_b, xw_fold, xb_fold, start_fold, latent_win, whh_split
 // (custom_ops.DECODE_KEYS).  -> per net idx, win_logits, pick_prob, actions, queries (empty when not wanted)
 std::vector<Tensor> pointer_decode(const c10::List<OptTensor>& net_tensors, at::IntArrayRef latent_from, const Tensor& inputs, int64_t n_cat,
                                    int64_t n_per, double tanh_c, bool use_tanh, bool want_queries, std::string precision, int64_t impl,
                                    int64_t lds_kb, bool write_through, const OptTensor& workspace, const OptTensor& status,
                                    at::IntArrayRef sample_seeds, bool paired_start) {
     GNNPN_ON_DEVICE_OF(inputs);
-    constexpr size_t NK = 15;
+    constexpr size_t NK = 16;
     const size_t n_nets = latent_from.size();
-    TORCH_CHECK(n_nets >= 1 && n_nets <= 2 && net_tensors.size() == NK * n_nets, "pointer_decode: fifteen tensors per net, 1 or 2 nets");
+    TORCH_CHECK(n_nets >= 1 && n_nets <= 2 && net_tensors.size() == NK * n_nets, "pointer_decode: sixteen tensors per net (custom_ops.DECODE_KEYS), 1 or 2 nets");
     std::vector<OptTensor> t(net_tensors.size());
     for (size_t i = 0; i < t.size(); ++i) t[i] = net_tensors.get(i);
     auto has = [&](size_t i) { return t[i].has_value() && t[i]->defined(); };
@@ -368,6 +370,7 @@ std::vector<Tensor> pointer_decode(const c10::List<OptTensor>& net_tensors, at::
             a.emb_w = f32(*t[o + 9], "emb_w"), a.emb_b = f32(*t[o + 10], "emb_b");
         }
         a.latent_win = has(o + 14) ? f32(*t[o + 14], "latent_win") : nullptr;
+        a.whh_split = has(o + 15) ? cptr<uint8_t>(*t[o + 15], at::kByte, "whh_split") : nullptr;
         a.latent_from = (int32_t)latent_from[i];
         const int64_t seed = i < sample_seeds.size() ? sample_seeds[i] : -1;     // >= 0: draw this net's picks from the stream of that seed
         a.sample = seed >= 0 ? 1 : 0;

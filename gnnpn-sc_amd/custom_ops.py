@@ -29,9 +29,9 @@ import torch
 from . import _lib, ops
 
 DECODE_KEYS = ("enc_out", "h0", "c0", "start", "wih", "whh", "bih", "bhh", "embedded", "emb_w", "emb_b",
-               "xw_fold", "xb_fold", "start_fold", "latent_win")
+               "xw_fold", "xb_fold", "start_fold", "latent_win", "whh_split")
 DECODE_OUTS = ("idx", "win_logits", "pick_prob", "actions", "queries")
-ENCODE_KEYS = ("pregates", "inputs", "w_in", "b_in", "whh", "bhh")
+ENCODE_KEYS = ("pregates", "inputs", "w_in", "b_in", "whh", "bhh", "whh_split")
 REQUEST_LAYER_KEYS = ("w0p", "b0", "a1", "s1", "w3p", "b3", "a2", "s2", "eps")
 
 TORCH_LIB_PATH = os.environ.get("GNNPN_TORCH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgnnpn_torch.so")

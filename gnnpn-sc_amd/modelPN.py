@@ -18,6 +18,8 @@ the streaming decode kernel.  Those forms run in fp32 (the exact-split builds ar
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -168,6 +170,13 @@ class PointerNet(nn.Module):
             # arithmetic every committed parity record was measured with); while a trainer steps the weights
             # (``fold_on_device``, set by trainPNHigh.ActorAdam) the same fp64 products run on the device instead of a
             # 1 MB round trip through the host per step.
+            # the exact split of the two recurrent matrices, once per set of weights (ops.pack_lstm_split_weights: what a "split"
+            # launch otherwise works out for itself every time); not while a capture is recording (an allocation there would live in
+            # the graph's pool) — the kernels then split for themselves, same bits
+            if self.hidden_size == 256 and self.embedding2.weight.is_cuda and not torch.cuda.is_current_stream_capturing() \
+                    and os.environ.get("GNNPN_PRESPLIT", "1") != "0":            # (GNNPN_PRESPLIT=0: A/B switch of tools/r06/presplit_ab.sh)
+                self._packed["enc_whh_split"] = ops.pack_lstm_split_weights(self._packed["enc_whh"])
+                self._packed["dec_whh_split"] = ops.pack_lstm_split_weights(self._packed["dec_whh"])
             if self.embedding_size != 0:     # the folded input side needs W_e [H, 8]: with the category embedding the literal order runs
                 self._packed["whh_absmax"] = None
                 return self._packed
@@ -213,15 +222,15 @@ class PointerNet(nn.Module):
             flat = torch.ops.gnnpn.embed_concat(inputs.reshape(B * L, F), self.embedding1.weight.detach().float().contiguous())
             embedded = torch.ops.gnnpn.linear(flat, w["emb_w"], w["emb_b"])
             pregates = torch.ops.gnnpn.linear(embedded, w["enc_wih"], w["enc_bih"])
-            return {"pregates": pregates.view(B, L, 4 * self.hidden_size), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
-                embedded.view(B, L, self.hidden_size)
+            return {"pregates": pregates.view(B, L, 4 * self.hidden_size), "whh": w["enc_whh"], "bhh": w["enc_bhh"],
+                    "whh_split": w.get("enc_whh_split")}, embedded.view(B, L, self.hidden_size)
         if fold:
             return {"inputs": inputs, "w_in": w["enc_wfold"], "b_in": w["enc_bfold"], "whh": w["enc_whh"],
-                    "bhh": w["enc_bhh"]}, None
+                    "bhh": w["enc_bhh"], "whh_split": w.get("enc_whh_split")}, None
         embedded = torch.ops.gnnpn.linear(inputs.reshape(B * L, F), w["emb_w"], w["emb_b"])
         pregates = torch.ops.gnnpn.linear(embedded, w["enc_wih"], w["enc_bih"])
         H = self.hidden_size
-        return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"]}, \
+        return {"pregates": pregates.view(B, L, 4 * H), "whh": w["enc_whh"], "bhh": w["enc_bhh"], "whh_split": w.get("enc_whh_split")}, \
             embedded.view(B, L, H)
 
     def decode_args(self, embedded, enc_out, h_n, c_n, latent_win=None, latent_from=-1, fold=None, sample_seed=None):
@@ -231,7 +240,7 @@ class PointerNet(nn.Module):
         fold = FOLD_INPUT_PROJECTION if fold is None else fold
         d = {"embedded": embedded, "emb_w": w["emb_w"], "emb_b": w["emb_b"], "enc_out": enc_out, "h0": h_n,
              "c0": c_n, "start": w["start"], "wih": w["dec_wih"], "whh": w["dec_whh"], "bih": w["dec_bih"],
-             "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from}
+             "bhh": w["dec_bhh"], "latent_win": latent_win, "latent_from": latent_from, "whh_split": w.get("dec_whh_split")}
         if fold and embedded is None:
             d.update(xw_fold=w["dec_wfold"], xb_fold=w["dec_bfold"], start_fold=w["dec_sfold"])
         if sample_seed is not None:

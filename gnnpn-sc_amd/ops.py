@@ -392,6 +392,19 @@ def pack_lstm_weight(w):
     return w.reshape(4, H, H // 4, 4).permute(2, 0, 1, 3).contiguous()
 
 
+def pack_lstm_split_weights(whh_packed):
+    """The exact split ("split" precision) of a packed recurrent weight matrix [H/4, 4, H, 4], H = 256, made once per model
+    (gnnpn_lstm_pack_split_weights_f32): what every cooperative launch otherwise works out for itself from ``whh_packed`` —
+    same bits, 9-13 us less per launch.  -> uint8 buffer for the ``whh_split`` entry of lstm_encode's / pointer_decode's nets."""
+    if whh_packed.numel() != 4 * 256 * 256:
+        raise GnnpnError(f"pack_lstm_split_weights: a packed [64, 4, 256, 4] matrix (H = 256) expected, got {tuple(whh_packed.shape)}")
+    lib = _lib.load()
+    out = torch.empty(int(lib.gnnpn_lstm_split_weights_bytes()), dtype=U8, device=whh_packed.device)
+    check(lib.gnnpn_lstm_pack_split_weights_f32(dev_ptr(whh_packed.contiguous(), F32, "whh_packed"), dev_ptr(out, U8, "split"), stream_ptr()),
+          "gnnpn_lstm_pack_split_weights_f32")
+    return out
+
+
 # operand precision of the recurrent W_hh.h product -> GNNPN_PREC_* (include/gnnpn_hip.h)
 _PRECISIONS = {"f32": 0, "f16": 1, "split": 2}
 
@@ -423,6 +436,7 @@ class Workspaces:
         self._untracked = False           # a captured graph replays these launches without telling: the host count is unknown
         self._warned_untracked = False    # ... said once per object (_read)
         self.last_progress = None         # the counters the last poll / check read (diagnosis; bench.py's per_rank)
+        self.last_seats = None            # ... and the cumulative placement events (declined / off-canonical seats)
         self._encode = None
         self._decode = None
         self._retired = []
@@ -477,6 +491,9 @@ class Workspaces:
         word = w[0]
         if any(p["finished"] != p["expected"] or (not self._untracked and p["expected"] != p["host_expected"]) for p in prog.values()):
             word |= self.SHORTFALL
+        # placement events summed over every launch on this object since the status block was last cleared (GNNPN_STATUS_DECLINED_SEATS /
+        # _OFF_CANONICAL_SEATS, ABI 9): a slow multi-GPU line can then be read from the JSON alone (bench.py's per_rank)
+        self.last_seats = {"declined": w[1], "off_canonical": w[2]}
         if self._untracked and not self._warned_untracked:
             # a capture made outside ops.graph_replay replays cooperative launches without booking them: finished == expected is
             # still checked, expected == the host's own count is not (and stays off for this object) — say so, once
@@ -699,6 +716,7 @@ def lstm_encode(nets, precision="f32", impl=0, lds_kb=0, write_through=False, ws
             a.w_in = dev_ptr(d["w_in"], F32, f"nets[{i}].w_in").value
             a.b_in = dev_ptr(d["b_in"], F32, f"nets[{i}].b_in").value
         a.whh_packed = dev_ptr(d["whh"], F32, f"nets[{i}].whh").value
+        a.whh_split = dev_ptr(d.get("whh_split"), U8, f"nets[{i}].whh_split", True).value if d.get("whh_split") is not None else None
         a.bhh = dev_ptr(d["bhh"], F32, f"nets[{i}].bhh").value
         a.enc_out, a.h_n, a.c_n = (dev_ptr(t, F32, "out").value for t in (e, hn, cn))
     wsp = workspaces(dev, ws) if coop else None
@@ -749,6 +767,8 @@ def pointer_decode(nets, inputs, n_cat, n_per, tanh_c=10.0, use_tanh=True, want_
         for name, key in (("enc_out", "enc_out"), ("h0", "h0"), ("c0", "c0"), ("start", "start"),
                           ("wih_packed", "wih"), ("whh_packed", "whh"), ("bih", "bih"), ("bhh", "bhh")):
             setattr(a, name, dev_ptr(d[key], F32, f"nets[{i}].{key}").value)
+        if d.get("whh_split") is not None:
+            a.whh_split = dev_ptr(d["whh_split"], U8, f"nets[{i}].whh_split").value
         coop = coop_supported(H, n_per, impl)
         if d.get("xw_fold") is not None and coop:                          # folded input side (cooperative form)
             a.xw_fold = dev_ptr(d["xw_fold"], F32, f"nets[{i}].xw_fold").value

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNPN_ABI_VERSION 8   /* 8: gnnpn_decode_attn_train_{forward,backward}_f32 (training through 'Bahdanau' attention / glimpse rounds), gnnpn_attention_logits_bahdanau_f32; 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
+#define GNNPN_ABI_VERSION 9   /* 9: gnnpn_lstm_pack_split_weights_f32 / gnnpn_lstm_split_weights_bytes and the whh_split field (recurrent weights split once per model) at the END of the encoder's and the decoder's net structs, sticky_status words 1-2 (cumulative declined / off-canonical seats); 8: gnnpn_decode_attn_train_{forward,backward}_f32 (training through 'Bahdanau' attention / glimpse rounds), gnnpn_attention_logits_bahdanau_f32; 7: gnnpn_launch_opts_t.sticky_status is a block of GNNPN_STATUS_WORDS words (proof-of-work counters), the 16-member forms (impl 3) are gone; 6: gnnpn_gate_wait; 5: the exact-split GIN layer (gnnpn_pack_split_weights_f16, gnnpn_gin_layer_split); 4: the tiled aggregate (gnnpn_csr_tile_plan_*, gnnpn_csr_aggregate_tiled_f32); 3: row order of the blocks form */
 
 #define GNNPN_OK 0
 #define GNNPN_E_ARG (-1)     /* null pointer / bad size / misaligned */
@@ -284,6 +284,8 @@ typedef struct {
     float* enc_out;
     float* h_n;
     float* c_n;
+    const void* whh_split;   /* NULL, or whh_packed's exact split made once per model by gnnpn_lstm_pack_split_weights_f32 (ABI 9): used by
+                              * GNNPN_PREC_SPLIT instead of splitting whh_packed inside every launch — same bits, 9-13 us less per launch */
 } gnnpn_encode_net_t;
 
 /* precision: operands of the recurrent W_hh.h product (accumulation, cell, outputs are fp32 in every mode)
@@ -332,6 +334,8 @@ typedef struct {
  *                   made against the expected words). */
 #define GNNPN_STATUS_WORDS 8
 #define GNNPN_STATUS_CODE 0
+#define GNNPN_STATUS_DECLINED_SEATS 1       /* ABI 9: early arrivals that declined their seat because of their LDS position, summed over the launches */
+#define GNNPN_STATUS_OFF_CANONICAL_SEATS 2  /* ABI 9: seats the reserve took on another CU than the canonical one, summed over the launches */
 #define GNNPN_STATUS_ENC_EXPECTED 4
 #define GNNPN_STATUS_ENC_FINISHED 5
 #define GNNPN_STATUS_DEC_EXPECTED 6
@@ -349,6 +353,15 @@ typedef struct {
     int32_t paired_start;
     uint32_t* sticky_status;
 } gnnpn_launch_opts_t;
+
+/* The exact split (GNNPN_PREC_SPLIT) of a packed recurrent weight matrix [H/4][gate][H][4], H = 256, made ONCE per model instead of
+ * inside every cooperative launch: per group member the three fp16 pieces of its 128 gate columns in the order the lanes load them
+ * (csrc/coop_common.h: load_split_weights), the column scales included.  Written by the same device function the kernels otherwise
+ * run for themselves: results are bit-identical with and without it.  `split`: gnnpn_lstm_split_weights_bytes() bytes, 16-byte aligned;
+ * valid for encoder and decoder W_hh alike (gnnpn_encode_net_t.whh_split, gnnpn_decode_net_t.whh_split).  No counterpart in the
+ * reference (nn.LSTM weights, src/models/modelPN.py:157,165): a load-time layout change like whh_packed.  New in ABI version 9. */
+int64_t gnnpn_lstm_split_weights_bytes(void);
+int gnnpn_lstm_pack_split_weights_f32(const float* whh_packed, void* split, void* stream);
 
 int gnnpn_lstm_encode_f32(int n_nets, const gnnpn_encode_net_t* nets, int32_t B, int32_t L, int32_t H,
                           int32_t F, int32_t precision, const gnnpn_launch_opts_t* opts, void* workspace,
@@ -457,6 +470,7 @@ typedef struct {
     int32_t latent_from;
     int32_t sample;          /* 0: greedy, first-max argmax (modelPN.py:226); 1: multinomial draw (:228), see below */
     uint64_t sample_seed;    /* stream of the draws of this net in this call */
+    const void* whh_split;   /* NULL, or gnnpn_lstm_pack_split_weights_f32(whh_packed): as gnnpn_encode_net_t.whh_split (ABI 9) */
 } gnnpn_decode_net_t;
 
 /* precision: GNNPN_PREC_F32 or GNNPN_PREC_SPLIT (the decoder cell's W_hh.h product; cooperative, folded form). */

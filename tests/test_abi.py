@@ -26,7 +26,7 @@ def test_build_and_load():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gnnpn_hip.h but not exported"
     lib.gnnpn_abi_version.restype = ctypes.c_int
-    assert lib.gnnpn_abi_version() == 8
+    assert lib.gnnpn_abi_version() == 9
 
 
 def test_binding_covers_header():

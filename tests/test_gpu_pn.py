@@ -529,6 +529,45 @@ def test_split_precision_ragged_shapes(dev, B, T, K):
             assert float((out["R"][s] - ref["R"][s]).abs().max()) <= R_ATOL
 
 
+@pytest.mark.parametrize("B,T,K", [(40, 47, 5), (17, 9, 16)])
+def test_presplit_weights_change_nothing(dev, B, T, K):
+    """The recurrent weights split ONCE per model (ops.pack_lstm_split_weights -> whh_split of the nets, ABI 9) against the split
+    every "split" launch makes for itself when it is absent: the packed image is written by the same device function, so every
+    output of the encoder and of both cooperative decoder builds is bit-identical with and without it — and the image itself holds,
+    per lane, pieces that sum to the fp32 weight (spot check through gnnpn_recurrent_product's col_inv is test_split3's; here: the
+    two paths agree on everything they produce)."""
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.modelPN import two_level_greedy
+    cfg = {"hidden": 256, "n_cat": T, "n_per": K, "seed_low": 115 + B, "seed_high": 116 + B}
+    low, high = build(cfg, dev)
+    g = torch.Generator().manual_seed(B * T + 7)
+    x = torch.rand(B, T * K, 8, generator=g)
+    x[:, :, 2:4] = 0.9 + 0.1 * x[:, :, 2:4]
+    x = x.to(dev)
+    for m in (low, high):
+        w = m.actor.packed()
+        assert w["enc_whh_split"].numel() == w["dec_whh_split"].numel() == 8 * 10368 * 16 and w["enc_whh_split"].dtype == torch.uint8
+    with_split = [two_level_greedy(low, high, x, precision="split", decode_impl=impl) for impl in (2, 4)]
+    for m in (low, high):                                                # the same weights without the packed image: split in the kernels
+        m.actor.packed().pop("enc_whh_split")
+        m.actor.packed().pop("dec_whh_split")
+    without = [two_level_greedy(low, high, x, precision="split", decode_impl=impl) for impl in (2, 4)]
+    ops.check_status(dev)
+    for a, b in zip(with_split, without):
+        for k in ("idx_low", "idx_high", "R", "win_low", "win_high_raw", "actions"):
+            assert torch.equal(a[k], b[k]), k
+    # the encoder alone, enc_out / h_n / c_n bit for bit
+    args = low.actor.encode_args(x)[0]
+    assert args.get("whh_split") is None
+    e0, h0, c0 = ops.lstm_encode([args], precision="split")
+    args2 = dict(args, whh_split=ops.pack_lstm_split_weights(args["whh"]))
+    e1, h1, c1 = ops.lstm_encode([args2], precision="split")
+    ops.check_status(dev)
+    assert torch.equal(e0[0], e1[0]) and torch.equal(h0[0], h1[0]) and torch.equal(c0[0], c1[0])
+    with pytest.raises(ops.GnnpnError):
+        ops.pack_lstm_split_weights(torch.zeros(8, 4, 32, 4, device=dev))   # H = 32: the cooperative kernels are built for H = 256
+
+
 def test_split_precision_needs_the_cooperative_form(dev):
     from gnnpn_sc_amd import ops
     from gnnpn_sc_amd.modelPN import two_level_greedy

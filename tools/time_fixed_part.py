@@ -23,11 +23,14 @@ def timed(fn, reps=30):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / reps)
     return best
-for prec in ("split", "f32"):
+for prec in ("split+presplit", "split", "f32"):      # "+presplit": the weights split once per model (ops.pack_lstm_split_weights, round 6)
     rec = {}
     for L in (1, 2, 5, 20, 60, 235):
         nets = nets_for(256, L)
-        rec[L] = round(timed(lambda: ops.lstm_encode(nets, precision=prec)) * 1e3, 1)
+        if prec.endswith("+presplit"):
+            for d in nets:
+                d["whh_split"] = ops.pack_lstm_split_weights(d["whh"])
+        rec[L] = round(timed(lambda: ops.lstm_encode(nets, precision=prec.split("+")[0])) * 1e3, 1)
     # least squares: t = a + b L
     Ls = [20, 60, 235]; ts = [rec[l] for l in Ls]
     b = (ts[2] - ts[0]) / (Ls[2] - Ls[0]); a = ts[2] - b * Ls[2]
