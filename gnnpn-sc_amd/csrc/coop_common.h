@@ -263,9 +263,14 @@ __device__ __forceinline__ void coop_note_finished(unsigned* sticky, int word, u
 // count of launches that are staffing (status word 4: 0 not started, 1 counted, 2 staffed).  The seats are counted in ONE
 // word (status word 5) so that exactly one workgroup sees the total: two last seat-takers on two XCDs comparing the
 // per-XCD counters could each miss the other's increment, and the launch would stay in the count for good.
-__device__ __forceinline__ void coop_note_staffed(unsigned* status, const unsigned* count, unsigned target, unsigned* seats) {
-    (void)count;
-    if (atomicAdd(status + 5, 1u) + 1u == 8u * target && atomicCAS(status + 4, 1u, 2u) == 1u) atomicSub(seats + COOP_STAFFING_WORD, 1u);
+// Round 6: counted in two levels — the seat-taker adds to its XCD's counter (the one `staffed()` reads; 32-64 adds per word), the
+// XCD's LAST seat-taker (its add returned target - 1) adds the XCD to status word 5, and the one that makes it 8 closes the launch:
+// still exactly one workgroup sees the total, and no word takes an add from all 256 seat-takers any more.
+__device__ __forceinline__ void coop_note_staffed(unsigned* status, unsigned* count_xcc, unsigned target, unsigned* seats) {
+    // (an exchange, not a compare-and-swap: the launch can be complete before the first arrival of any XCD has marked it — that
+    // workgroup then finds 2, not 0, and takes its own add back)
+    if (atomicAdd(count_xcc, 1u) + 1u == target && atomicAdd(status + 5, 1u) + 1u == 8u && atomicExch(status + 4, 2u) == 1u)
+        atomicSub(seats + COOP_STAFFING_WORD, 1u);
 }
 template <int G>
 __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot, int& group, int& member, unsigned* seats,
@@ -294,20 +299,44 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         // workgroup (this wavefront), because the stale counters above are what a missing invalidate looks like
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
-        const bool staffed_at_entry = staffed();
-        unsigned arrival = 0;
+        // ONE round trip for everything a workgroup has to learn on arrival, and no word that all 768 workgroups of a launch hammer
+        // with atomics (round 6).  It used to be a chain of five dependent device-scope accesses — and every workgroup's
+        // compare-and-swap on status word 4 plus every seat-taker's add to status word 5: a single word takes ~88 atomics per us
+        // (MI355X_MICROARCH.md, price list: dequeue), so 768 of them alone are 9 us; the placement stamp of workgroup 0 read 25-28 k
+        // cycles with the chain and, unchanged, with the chain folded into one returning atomic of twelve lanes (which made the
+        // eight counter reads atomics too).  Now: one 11-lane sc1 LOAD — lanes 0..7 the eight XCDs' seat counters, lane 10 the
+        // per-device count of launches that are staffing, lane 11 this CU's canonical seat — beside one atomic add of lane 8 (the
+        // arrival index: 96 per word); the launch is marked as started (status word 4: 0 -> 1, and with it the per-device count)
+        // by the FIRST arrival of each XCD only (8 contenders instead of 768), the launch's first arrival being one of them; lane 9
+        // reads that word, so that everybody knows whether the launch is in the per-device count it reads beside it.
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
+        unsigned* staffing = seats + COOP_STAFFING_WORD;           // per device: launches that have started and are not staffed yet
+        const unsigned* word = lane < 8 ? count + lane : lane == 9 ? status + 4 : lane == 10 ? staffing : seats + key;
+        unsigned got = 0;
+        if (lane < 12 && lane != 8) got = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 8) got = atomicAdd(arrive + xcc, 1u);
+        const bool staffed_at_entry = __all(lane >= 8 || got >= target);
+        unsigned arrival = __shfl(got, 8, 64);
+        const bool marked = __shfl(got, 9, 64) != 0u;             // the launch was in the per-device count when this workgroup looked
+        const unsigned staffing_seen = __shfl(got, 10, 64);
+        const unsigned seat_seen = __shfl(got, 11, 64);
         if (lane == 0) {
-            arrival = atomicAdd(arrive + xcc, 1u);
+            // an XCD's first arrival puts the launch into the per-device count — add FIRST, then mark, and take the add back if
+            // another XCD's first arrival (or the launch's last seat-taker: coop_note_staffed) got there before: "marked" then
+            // implies "counted", and whoever un-marks the launch (1 -> 2) takes out an add that is certainly in
+            if (arrival == 0u && !marked) {
+                atomicAdd(staffing, 1u);
+                if (atomicCAS(status + 4, 0u, 1u) != 0u) atomicSub(staffing, 1u);
+            }
             if (arrival >= gridDim.x / 8 || (staffed_at_entry && arrival < target)) coop_raise(status, sticky, 8u);
         }
         if (!staffed_at_entry) {
             if (lane == 0) {
-                const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-                const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
                 atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);      // statistics: workgroups of this launch that reached the CU
-                unsigned* staffing = seats + COOP_STAFFING_WORD;           // per device: launches that have started and are not staffed yet
-                if (atomicCAS(status + 4, 0u, 1u) == 0u) atomicAdd(staffing, 1u);   // this launch's first arrival
-                const bool another_staffing = __hip_atomic_load(staffing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1u;
+                // another launch is staffing: the count beyond this launch's own entry — which is in it if the launch was marked when
+                // both words were read (errs towards "yes" in the few hundred ns around the mark: a decline too many, never one too few)
+                const bool another_staffing = staffing_seen > (marked ? 1u : 0u);
                 // Where in the CU's LDS did the dispatcher put this workgroup?  LDS is handed out in contiguous ranges, and a
                 // workgroup that lands ABOVE a short-lived neighbour (an ordinary kernel's few KB) stays there when the neighbour
                 // has gone: a 78 KB footprint at, say, [25 KB, 103 KB) leaves two holes of 25 and 57 KB, and the partner launch's
@@ -339,7 +368,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                     //                                              with the reserve below and takes an open seat only if nobody better placed has)
                     // the CU's canonical seat (process-wide table: the same CU sits in the same seat in every launch); whoever of
                     // this launch gets there first takes it (one compare-and-swap), every later arrival on the CU is surplus
-                    unsigned s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned s = seat_seen;
                     if (s == 0u) {
                         if (atomicCAS(seats + key, 0u, 0xffffffffu) == 0u) {
                             s = atomicAdd(seats + 8 * 256 + xcc, 1u) + 1u;
@@ -352,10 +381,9 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                         s = __hip_atomic_load(seats + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned seat = s - 1u;
                     if (seat < target && atomicCAS(taken + seat, 0u, 1u) == 0u) {
-                        atomicAdd(count + xcc, 1u);
                         g = (int)xcc * gpx + (int)(seat / G);
                         m = (int)(seat % G);
-                        coop_note_staffed(status, count, target, seats);
+                        coop_note_staffed(status, count + xcc, target, seats);
                     }
                 }
             }
@@ -378,10 +406,9 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                     if (lane == 0) {
                         for (unsigned seat = 0; seat < target && g < 0; ++seat) {
                             if (atomicCAS(taken + seat, 0u, 1u) == 0u) {
-                                atomicAdd(count + xcc, 1u);
                                 g = (int)xcc * gpx + (int)(seat / G);
                                 m = (int)(seat % G);
-                                coop_note_staffed(status, count, target, seats);
+                                coop_note_staffed(status, count + xcc, target, seats);
                                 atomicAdd(status + 2, 1u);       // statistics: seats taken off the canonical CU
                                 if (sticky) atomicAdd(sticky + GNNPN_STATUS_OFF_CANONICAL_SEATS, 1u);
                             }

@@ -11,7 +11,13 @@ for n in range(2):
                  "b_in": ((torch.rand(4 * H, generator=g) * 2 - 1) * 0.3).to(dev),
                  "whh": ops.pack_lstm_weight((torch.rand(4 * H, H, generator=g) * 2 - 1) / 16).to(dev),
                  "bhh": ((torch.rand(4 * H, generator=g) * 2 - 1) / 16).to(dev)})
-for prec in ("split", "f32"):
+# prof[7..9] of workgroup 0: placement (entry -> seated), weights into registers, first step — shader cycles
+for prec in ("split+presplit", "split", "f32"):
+    if prec.endswith("+presplit"):
+        for d in nets: d["whh_split"] = ops.pack_lstm_split_weights(d["whh"])
+    else:
+        for d in nets: d.pop("whh_split", None)
+    prec = prec.split("+")[0]
     for _ in range(3): ops.lstm_encode(nets, precision=prec)
     ops.set_option("lstm_ablate", 32)
     for rep in range(2):
