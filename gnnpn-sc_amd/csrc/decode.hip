@@ -9,6 +9,8 @@
 //                        product, 16 B per lane, fixed butterfly reduction
 //   C*tanh, + latent (High net), softmax over the window, first-max argmax (torch.max on CPU
 //   returns the first maximal index), gather of the next decoder input and of the action row.
+#include <atomic>
+
 #include "common.h"
 #include <string.h>
 #include "recurrent.h"
@@ -238,6 +240,11 @@ extern "C" int gnnpn_pointer_decode_f32(int n_nets, const gnnpn_decode_net_t* ne
         // cooperative sampling build does not cover) is served by the streaming form below instead of an error
         const bool fall_through = rc == GNNPN_E_UNSUP && impl == 0 && precision == GNNPN_PREC_F32;
         if (rc != GNNPN_OK && !fall_through) return rc;
+        if (fall_through) {                                  // said once per process: the form below is ~10 x slower per step
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "[gnnpn] pointer_decode: %s — taking the per-workgroup streaming form (about 10 x slower per step)\n", gnnpn_last_error());
+        }
         if (rc == GNNPN_OK) {
             GNNPN_CHECK_LAUNCH("pointer_decode_f32(coop)");
             return GNNPN_OK;

@@ -105,6 +105,32 @@ def half_batch_split(n_problems):
     return half if 0 < half < n_problems else 0
 
 
+_warned_partitioned = set()
+
+
+def warn_partitioned_device(device, precision):
+    """Say ONCE per device what a compute-partitioned GPU means for this path.  The cooperative recurrent
+    kernels — the ones every measured number of this package comes from — are placed for 8 XCDs x 32 CUs (MI355X in SPX mode:
+    csrc/coop_common.h::coop_place deals seats per XCD and assumes eight of them).  On a device that shows fewer than 256 compute
+    units (CPX / DPX / QPX partitions, or another GPU) their launchers return GNNPN_E_UNSUP: with precision "split" or "f16" the
+    recurrent calls then RAISE; with "f32" the decoder in auto mode (impl 0) takes the per-workgroup streaming form and the encoder
+    raises unless impl=1 is passed — the streaming forms re-stream the 1 MiB W_hh from L2 every step, about 10 x slower per step
+    (11 us against 2.4 us / 3.2 us at the QWS shape, csrc/lstm_coop.hip)."""
+    import warnings
+    if device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _warned_partitioned:
+        return
+    _warned_partitioned.add(idx)
+    n_cu = torch.cuda.get_device_properties(idx).multi_processor_count
+    if n_cu < 256:
+        warnings.warn(f"gnnpn: cuda:{idx} shows {n_cu} compute units; the cooperative recurrent kernels are built for 8 XCDs x 32 CUs (MI355X, SPX "
+                      f"mode). precision={precision!r}: " + ("the recurrent launches will raise GNNPN_E_UNSUP — " if precision != "f32" else "") +
+                      "only the per-workgroup streaming forms (precision='f32', impl=1) run here, about 10 x slower per recurrent step.",
+                      RuntimeWarning, stacklevel=3)
+
+
 class ML2PNPipeline:
     """net: modelML.Net; low/high: modelPN.CombinatorialRL (levels "Low"/"High")."""
 
@@ -116,6 +142,7 @@ class ML2PNPipeline:
         self.precision = default_precision(low, high) if precision is None else precision
         self.cache_service_embedding = True   # False: re-evaluate the GCN branch in every pass (round-1 behaviour)
         self._side_streams = {}
+        warn_partitioned_device(next(low.parameters()).device, self.precision)
 
     @torch.no_grad()
     def service_embedding(self, services):

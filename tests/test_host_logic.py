@@ -503,3 +503,25 @@ def test_oracle_and_product_candidate_reduction_agree():
         got = torch.tensor([reduce_from_ranking(rank[i], pb.local_bounds[i], pb.present[i], pb.global_bounds[i], cat_of, table.qos, K)
                             for i in range(5)], dtype=torch.float32)[:, :, 1:]
         assert torch.equal(got, want), (T, S, K)
+
+
+def test_partitioned_device_is_announced_once(monkeypatch):
+    """A device that shows fewer than 256 compute units (CPX / DPX / QPX partition) gets ONE RuntimeWarning per device from the
+    pipeline constructor, naming what will raise and what will run slowly; a full device gets none."""
+    import warnings
+    import torch
+    from gnnpn_sc_amd import pipeline as pl
+
+    class Props:
+        def __init__(self, n):
+            self.multi_processor_count = n
+    pl._warned_partitioned.clear()
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: Props(64 if i == 1 else 256))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pl.warn_partitioned_device(torch.device("cuda", 0), "split")
+        pl.warn_partitioned_device(torch.device("cuda", 1), "split")
+        pl.warn_partitioned_device(torch.device("cuda", 1), "split")
+        pl.warn_partitioned_device(torch.device("cpu"), "split")
+    assert len(w) == 1 and "64 compute units" in str(w[0].message) and "GNNPN_E_UNSUP" in str(w[0].message)
+    pl._warned_partitioned.clear()

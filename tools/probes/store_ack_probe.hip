@@ -23,7 +23,7 @@
 typedef unsigned long long u64;
 constexpr int ITERS = 2000;
 
-template <int MODE, bool SC1>   // MODE 0 ack, 1 ack+load, 2 load
+template <int MODE, bool SC1>   // MODE 0 ack, 1 ack+load, 2 load, 3 (round 6) load FIRST, then the stores, s_waitcnt vmcnt(2): the wait covers the load only
 __global__ __launch_bounds__(256) void probe(u64* __restrict__ slots, const u64* __restrict__ hot, u64* __restrict__ cycles) {
     u64* mine = slots + ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;   // two granules per lane, as the encoder publishes
     const u64* peer = hot + threadIdx.x * 2;                             // a line that stays in this XCD's L2 (read-only here)
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void probe(u64* __restrict__ slots, const u64*
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int i = 0; i < ITERS; ++i) {
         const u64 v = ((u64)(i + 1) << 32) | threadIdx.x;
+        if (MODE == 3) sink += __hip_atomic_load(peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (MODE != 2) {
             if (SC1) {
                 __hip_atomic_store(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -44,8 +45,15 @@ __global__ __launch_bounds__(256) void probe(u64* __restrict__ slots, const u64*
                 __hip_atomic_store(mine + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (MODE != 0) sink += __hip_atomic_load(peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE == 1 || MODE == 2) sink += __hip_atomic_load(peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 3) {
+            // vector memory operations retire in issue order: all but the two youngest (the stores) = the load.  The NEXT iteration's
+            // wait then also covers this iteration's stores, so a spacer of ~2 k clocks (a recurrent step is 6.5 k) keeps them out of it
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            for (int z = 0; z < 32; ++z) __builtin_amdgcn_s_sleep(1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     u64 t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -76,6 +84,8 @@ int main() {
         run("ack+load", "plain (stay in the XCD's L2)", probe<1, false>, wgs);
         run("ack+load", "sc1 (agent scope, write-through)", probe<1, true>, wgs);
         run("load", "-", probe<2, false>, wgs);
+        run("load first, stores behind it, vmcnt(2) [+ 2048 clocks of s_sleep per iteration]", "plain (stay in the XCD's L2)", probe<3, false>, wgs);
+        run("load first, stores behind it, vmcnt(2) [+ 2048 clocks of s_sleep per iteration]", "sc1 (agent scope, write-through)", probe<3, true>, wgs);
     }
     CK(hipGetLastError());
     return 0;
