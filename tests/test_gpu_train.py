@@ -25,7 +25,10 @@ def _E(fx):
 
 
 def _form(fx):
-    """(attention, n_glimpses) of a fixture: every pn_train_* file carries both (tests/golden/MANIFEST.json pins the key lists)."""
+    """(attention, n_glimpses) of a fixture: every pn_train_* FILE carries both (tests/golden/MANIFEST.json pins the key lists); a
+    live configuration (a plain dict, no fixture) that names neither is the shipped ('Dot', 0)."""
+    if isinstance(fx, dict) and "attention" not in fx:
+        return "Dot", 0
     return str(fx["attention"]), int(fx["n_glimpses"])
 
 
