@@ -213,11 +213,16 @@ def test_training_drivers_end_to_end(dev, tmp_path, monkeypatch):
     low_e = PNLow("QWS", 1, 1, T, 1, K, 256, 0, 10, 1, 0.9, 2.0, 1e-4, -1).start(n_epochs=1, device=str(dev), batch_size=4)
     e1 = low_e.model.actor.embedding1.weight.detach().cpu()
     assert low_e.actor_optim.steps == 3 and tuple(e1.shape) == (T, 20) and all(np.isfinite(v) for v in low_e.train_tour)
-    ck = torch.load("solutions/PNLow/QWS/epoch0.model", map_location="cpu")["model"]
+    # its artefacts live under <ds>/20embeddings/ (trainPNLow.py:190-191: self.dataset += "20embeddings/"), beside — not over — the
+    # embeddingTag=0 run's, and PNHigh(embeddingTag=1) finds its Low net there (trainPNHigh.py:197-198,237-240)
+    ck = torch.load("solutions/PNLow/QWS/20embeddings/epoch0.model", map_location="cpu")["model"]
     assert torch.equal(ck["actor.embedding1.weight"], e1)
+    assert "actor.embedding1.weight" not in torch.load("solutions/PNLow/QWS/epoch0.model", map_location="cpu")["model"]   # untouched
     high_e = PNHigh("QWS", 1, 1, T, 1, K, 256, 0, 10, 1, 0.9, 2.0, 0.5e-4, -1, 0).start(n_epochs=1, device=str(dev), batch_size=4)
     assert high_e.actor_optim.steps == 3 and all(np.isfinite(v) for v in high_e.train_tour)
     with open("solutions/PNHigh/QWS/allActions0.txt") as f:
+        assert len(json.load(f)[0][0]) == 8                                         # the embeddingTag=0 run's file: still 8 columns
+    with open("solutions/PNHigh/QWS/20embeddings/allActions0.txt") as f:
         acts_e = json.load(f)
     assert len(acts_e) == T and len(acts_e[0][0]) == 9                              # action rows WITH their category column
     # n_glimpses = 1 (environment.ini ships 0; the drivers pass it through, attention stays 'Dot': trainPNLow.py:205-210,
