@@ -158,10 +158,15 @@ __device__ __forceinline__ void coop_raise(unsigned* err, unsigned* sticky, unsi
 // next one.  The k-th claimant of an XCD becomes member k % G of the XCD's group k / G: groups sit on one XCD by
 // construction and no CU holds two members of a launch.  Two such launches on two streams then share every CU one
 // workgroup each.  The claim words live in the status area and are zeroed by the launch's own memset.
-constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [1024,1056) per-XCD seat counters, [1152,1184) arrivals, [2048,10240) CU claims
+constexpr int COOP_STATUS_BYTES = 16384;     // [0,256) status + stamps, [2048,10240) CU claims, [10240,12288) seat flags, [12288,13312) per-XCD seat counters, [13312,14336) arrivals, [14336,15360) seated workgroups
 constexpr unsigned COOP_LDS_UNITS = 640;    // a CU's 160 KB of LDS in the 256-byte units of HW_REG_LDS_ALLOC
-constexpr int COOP_XCDCNT_OFFSET = 1024;
-constexpr int COOP_ARRIVE_OFFSET = 1152;     // [1152,1184) per-XCD arrival counters
+// The per-XCD counters sit on cache lines of their OWN (round 6; they used to be eight adjacent words): every one of a launch's 768
+// workgroups adds to its XCD's arrival counter on entry, and atomics on one line are worked off one after the other by the line's
+// L2 channel (~88 per us): eight counters on one line made the arrivals of all eight XCDs one queue of 768.
+constexpr int COOP_XCD_STRIDE = 32;          // words between two XCDs' counters (128 bytes)
+constexpr int COOP_XCDCNT_OFFSET = 12288;    // word COOP_XCDCNT_OFFSET / 4 + COOP_XCD_STRIDE * xcd: seats taken on that XCD
+constexpr int COOP_ARRIVE_OFFSET = 13312;    // likewise: workgroups of the launch that have arrived on that XCD
+constexpr int COOP_PLACED_OFFSET = 14336;    // likewise: seated workgroups that run the L2-resident hand-off (statistics; used to be status word 1)
 constexpr int COOP_CLAIM_OFFSET = 2048;
 constexpr int COOP_TAKEN_OFFSET = 10240;     // [10240,12288) per-XCD seat flags (64 per XCD)
 constexpr int COOP_OVERREAD_BYTES = 4096;    // slack at the end of the decoder workspace: fixed-shape 16-byte sweeps may read (never use) that far past their data
@@ -284,7 +289,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         const unsigned target = (unsigned)(gpx * G);
         auto staffed = [&]() {
             bool ok = true;
-            if (lane < 8) ok = __hip_atomic_load(count + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+            if (lane < 8) ok = __hip_atomic_load(count + COOP_XCD_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
             return __all(ok);
         };
         int g = -1, m = 0;
@@ -312,10 +317,10 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
         unsigned* staffing = seats + COOP_STAFFING_WORD;           // per device: launches that have started and are not staffed yet
-        const unsigned* word = lane < 8 ? count + lane : lane == 9 ? status + 4 : lane == 10 ? staffing : seats + key;
+        const unsigned* word = lane < 8 ? count + COOP_XCD_STRIDE * lane : lane == 9 ? status + 4 : lane == 10 ? staffing : seats + key;
         unsigned got = 0;
         if (lane < 12 && lane != 8) got = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 8) got = atomicAdd(arrive + xcc, 1u);
+        if (lane == 8) got = atomicAdd(arrive + COOP_XCD_STRIDE * xcc, 1u);
         const bool staffed_at_entry = __all(lane >= 8 || got >= target);
         unsigned arrival = __shfl(got, 8, 64);
         const bool marked = __shfl(got, 9, 64) != 0u;             // the launch was in the per-device count when this workgroup looked
@@ -383,7 +388,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                     if (seat < target && atomicCAS(taken + seat, 0u, 1u) == 0u) {
                         g = (int)xcc * gpx + (int)(seat / G);
                         m = (int)(seat % G);
-                        coop_note_staffed(status, count + xcc, target, seats);
+                        coop_note_staffed(status, count + COOP_XCD_STRIDE * xcc, target, seats);
                     }
                 }
             }
@@ -408,7 +413,7 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                             if (atomicCAS(taken + seat, 0u, 1u) == 0u) {
                                 g = (int)xcc * gpx + (int)(seat / G);
                                 m = (int)(seat % G);
-                                coop_note_staffed(status, count + xcc, target, seats);
+                                coop_note_staffed(status, count + COOP_XCD_STRIDE * xcc, target, seats);
                                 atomicAdd(status + 2, 1u);       // statistics: seats taken off the canonical CU
                                 if (sticky) atomicAdd(sticky + GNNPN_STATUS_OFF_CANONICAL_SEATS, 1u);
                             }

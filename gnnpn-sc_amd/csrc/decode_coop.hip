@@ -51,8 +51,8 @@ __device__ __forceinline__ void decode_diag_record(int group, int member, int ti
         const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
         unsigned c0 = 0, c1 = 0;
         for (int x = 0; x < 4; ++x) {
-            c0 |= (cnt[x] & 0xffu) << (8 * x);
-            c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
+            c0 |= (cnt[COOP_XCD_STRIDE * x] & 0xffu) << (8 * x);
+            c1 |= (cnt[COOP_XCD_STRIDE * (4 + x)] & 0xffu) << (8 * x);
         }
         const unsigned long long t = __builtin_amdgcn_s_memrealtime();
         r[0] = group; r[1] = member; r[2] = tile; r[9] = c0; r[10] = c1; r[11] = (unsigned)t; r[12] = (unsigned)(t >> 32);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_coop_kernel(DecodeArg
     if (tid == 0) abort_flag = 0;
     __syncthreads();
     const bool same_xcd = !(ablate & 128);   // h and partial-dot granules stay inside the group's XCD
-    if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
+    if (tid == 0 && same_xcd) atomicAdd(err + COOP_PLACED_OFFSET / 4 + COOP_XCD_STRIDE * xcc_id(), 1u);   // statistics: workgroups on the same-XCD fast path (per XCD: its own line)
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;

@@ -68,8 +68,8 @@ __device__ __forceinline__ void record_failure(unsigned* diag, const unsigned* e
     const unsigned* cnt = err + COOP_XCDCNT_OFFSET / 4;
     unsigned c0 = 0, c1 = 0;
     for (int x = 0; x < 4; ++x) {
-        c0 |= (cnt[x] & 0xffu) << (8 * x);
-        c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
+        c0 |= (cnt[COOP_XCD_STRIDE * x] & 0xffu) << (8 * x);
+        c1 |= (cnt[COOP_XCD_STRIDE * (4 + x)] & 0xffu) << (8 * x);
     }
     const unsigned long long t = __builtin_amdgcn_s_memrealtime();
     rec[0] = group; rec[1] = member; rec[2] = tile; rec[3] = k; rec[4] = wave; rec[5] = tag;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, OCC) void pointer_decode_lean_kernel(DecodeArg
     if (tid == 0) abort_flag = 0;
     __syncthreads();
     const bool same_xcd = !(write_through & 1);
-    if (tid == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the same-XCD fast path
+    if (tid == 0 && same_xcd) atomicAdd(err + COOP_PLACED_OFFSET / 4 + COOP_XCD_STRIDE * xcc_id(), 1u);   // statistics: workgroups on the same-XCD fast path (per XCD: its own line)
 
     const int B = a.B, T = a.T, K = a.K, L = T * K;
     const bool latent_in_launch = net.latent_from >= 0;

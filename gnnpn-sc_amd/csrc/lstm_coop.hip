@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
     if (threadIdx.x == 0) abort_flag = 0;
     __syncthreads();
     const bool same_xcd = !(ablate & 128);
-    if (threadIdx.x == 0 && same_xcd) atomicAdd(err + 1, 1u);   // statistics: workgroups on the fast path
+    if (threadIdx.x == 0 && same_xcd) atomicAdd(err + COOP_PLACED_OFFSET / 4 + COOP_XCD_STRIDE * xcc_id(), 1u);   // statistics: workgroups on the fast path (per XCD: its own line)
 
     const float* __restrict__ pre = PRE ? nets.pregates[net] : nullptr;
     const float* __restrict__ xin = nets.inputs[net];     // used when pre == nullptr (F = 8)
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
                         const unsigned* arr = err + COOP_ARRIVE_OFFSET / 4;
                         unsigned c0 = 0, c1 = 0, a0 = 0, a1 = 0;
                         for (int x = 0; x < 4; ++x) {
-                            c0 |= (cnt[x] & 0xffu) << (8 * x);
-                            c1 |= (cnt[4 + x] & 0xffu) << (8 * x);
-                            a0 |= (arr[x] & 0xffu) << (8 * x);
-                            a1 |= (arr[4 + x] & 0xffu) << (8 * x);
+                            c0 |= (cnt[COOP_XCD_STRIDE * x] & 0xffu) << (8 * x);
+                            c1 |= (cnt[COOP_XCD_STRIDE * (4 + x)] & 0xffu) << (8 * x);
+                            a0 |= (arr[COOP_XCD_STRIDE * x] & 0xffu) << (8 * x);
+                            a1 |= (arr[COOP_XCD_STRIDE * (4 + x)] & 0xffu) << (8 * x);
                         }
                         rec[0] = group; rec[1] = member; rec[2] = tile; rec[3] = t; rec[4] = wave; rec[5] = step;
                         rec[6] = 0; rec[7] = 0xE0Cu; rec[8] = 0; rec[9] = c0; rec[10] = c1; rec[11] = a0; rec[12] = a1;
@@ -426,7 +426,7 @@ extern "C" int gnnpn_lstm_pack_split_weights_f32(const float* whh_packed, void* 
     return GNNPN_OK;
 }
 
-// workspace: COOP_STATUS_BYTES of status (word 0 = error, word 1 = workgroups on the same-XCD fast path,
+// workspace: COOP_STATUS_BYTES of status (word 0 = error; per-XCD counters on lines of their own: coop_common.h;
 // stamps, hello granules), then the exchange buffers
 extern "C" int64_t gnnpn_lstm_encode_workspace_bytes(void) {
     (void)gnnpn_cu_seat_table();   // callers size their workspace before the first launch and outside any capture: create the seat table here

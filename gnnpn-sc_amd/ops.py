@@ -528,7 +528,8 @@ class Workspaces:
         if self._encode is None:
             return None
         w = self._encode[:16].view(torch.int32).tolist()
-        return {"members_placed": w[1], "off_canonical_seats": w[2], "declined_seats": w[3]}
+        placed = self._encode[14336:15360].view(torch.int32)[::32].sum().item()     # per-XCD words on lines of their own (coop_common.h: COOP_PLACED_OFFSET)
+        return {"members_placed": int(placed), "off_canonical_seats": w[2], "declined_seats": w[3]}
 
     def check(self, what="cooperative kernel"):
         """Synchronise the device and raise if any launch since the last check reported a failed hand-off."""

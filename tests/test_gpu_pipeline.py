@@ -603,7 +603,7 @@ def test_two_slots_whichever_starts_first(dev):
     """Placement by claim (csrc/coop_common.h): every cooperative launch staffs all its groups one workgroup per CU no
     matter what else is resident.  Round 1's LDS-footprint steering only held while slot 0 led; here the two-slot runner
     is started with slot 1 first, then with slot 0 first, on an idle chip: every launch reports all its members placed
-    (workspace word 1), no hand-off failure, and the results equal the single-stream run."""
+    (ops.Workspaces.placement), no hand-off failure, and the results equal the single-stream run."""
     import gnnpn_sc_amd.synth as synth
     from bench import build_models
     from gnnpn_sc_amd import ops
@@ -628,10 +628,9 @@ def test_two_slots_whichever_starts_first(dev):
             o = runner.graphs[s].outputs
             assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
             w = runner.workspaces[s]
-            placed = int(w.encode()[4:8].view(torch.int32).item())
-            assert placed == 256, placed                         # 32 groups x 8 members, one per CU
-            off_seat = int(w.encode()[8:12].view(torch.int32).item())
-            assert off_seat == 0, off_seat                       # every member on its CU's canonical seat (no reserve take-over)
+            pl = w.placement()                                   # the last encoder launch's own counters (per-XCD words summed)
+            assert pl["members_placed"] == 256, pl               # 32 groups x 8 members, one per CU
+            assert pl["off_canonical_seats"] == 0, pl            # every member on its CU's canonical seat (no reserve take-over)
 
 
 def test_two_slots_beside_long_ordinary_kernels(dev):

@@ -615,13 +615,13 @@ def _poison(kind, words, gen):
     p = torch.zeros(words, dtype=torch.int32)
     if kind in ("previous_totals", "previous_totals_some_xcds"):
         xcds = range(8) if kind == "previous_totals" else (1, 4, 6)
-        for x in xcds:
-            p[256 + x] = 32                       # the XCD's 32 seats taken
-            p[288 + x] = 96                       # every workgroup of the 3 x over-subscribed launch arrived
+        for x in xcds:                            # (word offsets: csrc/coop_common.h, COOP_XCDCNT_OFFSET / COOP_ARRIVE_OFFSET / COOP_TAKEN_OFFSET)
+            p[3072 + 32 * x] = 32                 # the XCD's 32 seats taken
+            p[3328 + 32 * x] = 96                 # every workgroup of the 3 x over-subscribed launch arrived
             p[2560 + 64 * x:2560 + 64 * x + 32] = 1
-        p[4], p[5] = 2, 32 * len(list(xcds))     # "staffed", seats in all
+        p[4], p[5] = 2, len(list(xcds))          # "staffed", XCDs complete
     elif kind == "seat_counters_only":
-        p[256:264] = 32
+        p[3072:3072 + 256:32] = 32
     elif kind == "seat_flags_only":
         p[2560:2560 + 512:3] = 1                 # every third seat looks taken: those members can never be seated
     elif kind == "staffing_word":
