@@ -38,6 +38,13 @@ import os
 import sys
 import time
 
+# More hardware queues than HIP's default of 4, set before the runtime initialises (round 6, profiles/LOG_r06.md section 9): a rank's
+# streams — two slots, their side streams, the process group's collective stream — are dealt onto the hardware queues round robin,
+# and a hardware queue is in order: with 4 of them the all-gather's "wait for slot A's step" sat in front of slot B's launches
+# (head-of-line blocking: -6 % with a real RCCL collective every 8 steps, -1.7 % with 8 queues; nothing to do with the collective
+# itself — a plain copy on a side stream cost the same).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
