@@ -43,7 +43,23 @@ import time
 # and a hardware queue is in order: with 4 of them the all-gather's "wait for slot A's step" sat in front of slot B's launches
 # (head-of-line blocking: -6 % with a real RCCL collective every 8 steps, -1.7 % with 8 queues; nothing to do with the collective
 # itself — a plain copy on a side stream cost the same).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Only for a rank that has a collective stream: at N = 1 without a process group the default of 4 is kept — with 8 the PCIe-inclusive leg
+# of this file (pinned host arenas copied in and out on the slots' streams) fell from 0.95 to 0.62 of the resident rate.
+
+
+def _rank_has_collective_stream():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("GNNPN_FORCE_DIST") == "1":
+        return True
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            return int(sys.argv[i + 1]) > 1
+        if a.startswith("--gpus=") and a[7:].isdigit():
+            return int(a[7:]) > 1
+    return False
+
+
+if _rank_has_collective_stream():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 
