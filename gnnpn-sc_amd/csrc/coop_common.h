@@ -287,10 +287,14 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         unsigned* arrive = status + COOP_ARRIVE_OFFSET / 4;
         unsigned* taken = status + COOP_TAKEN_OFFSET / 4 + xcc * 64;
         const unsigned target = (unsigned)(gpx * G);
+        // what a waiting surplus workgroup polls: ONE word — status word 5, the number of XCDs whose last seat has been taken
+        // (coop_note_staffed) — not the eight per-XCD counters: those sit on eight lines now, and up to 500 waiting workgroups
+        // re-reading eight lines each every 0.2 us is traffic in front of the very atomics the launch is waiting for (measured:
+        // the every-step interferer soak lost 15-32 % with the eight-line poll against 6-13 % before the counters were spread)
         auto staffed = [&]() {
-            bool ok = true;
-            if (lane < 8) ok = __hip_atomic_load(count + COOP_XCD_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
-            return __all(ok);
+            unsigned v = 0;
+            if (lane == 0) v = __hip_atomic_load(status + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return __shfl(v, 0, 64) >= 8u;
         };
         int g = -1, m = 0;
         // Every workgroup takes an arrival index, also the ones that find the launch staffed — and with it checks that the status

@@ -816,7 +816,12 @@ def test_soak_beside_a_collective_shaped_interferer(dev, shape):
         json.dump(rec, f)
     assert bad0 == bad1 == bad2 == bad3 == 0, rec
     assert lib.gnnpn_coop_staffing_count() == 0
-    assert with_it >= 0.70 * ref_rate and with_8 >= 0.88 * ref_rate, rec           # measured at the QWS shape: 5-17 % / -1.5-6 % over the round's runs (600 steps are ~1 s: the rates themselves move by a few %)
+    # measured at the QWS shape: 5-17 % / -1.5-6 % over round 5's runs (600 steps are ~1 s: the rates themselves move by a few %).  Round 6:
+    # beside an interferer at EVERY step the rate is set by the interferer, not by the launches — 322-394 k on this round's tree, 331-397 k on
+    # round 5's, same box, alternating (tools/r06/ab_interferer.sh) — so against a base rate that rose from 424 k to 443 k the same absolute
+    # rate reads as a larger loss (11-32 % against 6-22 %): the bound on the every-step case is 0.60 now; every 8th step (the cadence of
+    # bench.py's bucketed all-gather) stays at 0.88
+    assert with_it >= 0.60 * ref_rate and with_8 >= 0.88 * ref_rate, rec
 
 
 def test_bench_line_contract(dev):
