@@ -64,39 +64,8 @@ def all_gather_indices_async(idx_local, out=None):
     if out is None:
         out = torch.empty((world * idx_local.shape[0],) + tuple(idx_local.shape[1:]), dtype=idx_local.dtype,
                           device=idx_local.device)
-    if os.environ.get("GNNPN_FAKE_GATHER") == "2" and world == 1:      # diagnosis: no data movement at all (what the staging alone costs)
-        return out, None
-    if os.environ.get("GNNPN_FAKE_GATHER") == "3" and world == 1:      # diagnosis: the copy on the CALLING stream, no event, no second stream
-        out.copy_(idx_local, non_blocking=True)
-        return out, None
-    if os.environ.get("GNNPN_FAKE_GATHER") == "1" and world == 1:      # diagnosis (tools/r06/dist_cost.sh): the same data movement and the
-        return _fake_gather(idx_local, out)                            # same stream choreography without the process group's collective
     work = td.all_gather_into_tensor(out, idx_local.contiguous(), async_op=True)
     return out, work
-
-
-class _FakeWork:
-    def __init__(self, event):
-        self.event = event
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.event)
-
-
-_fake_stream = {}
-
-
-def _fake_gather(idx_local, out):
-    dev = idx_local.device
-    side = _fake_stream.get(dev)
-    if side is None:
-        side = _fake_stream[dev] = torch.cuda.Stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        out.copy_(idx_local, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(side)
-    return out, _FakeWork(ev)
 
 
 def barrier(world):
