@@ -173,8 +173,7 @@ class PointerNet(nn.Module):
             # the exact split of the two recurrent matrices, once per set of weights (ops.pack_lstm_split_weights: what a "split"
             # launch otherwise works out for itself every time); not while a capture is recording (an allocation there would live in
             # the graph's pool) — the kernels then split for themselves, same bits
-            if self.hidden_size == 256 and self.embedding2.weight.is_cuda and not torch.cuda.is_current_stream_capturing() \
-                    and os.environ.get("GNNPN_PRESPLIT", "1") != "0":            # (GNNPN_PRESPLIT=0: A/B switch of tools/r06/presplit_ab.sh)
+            if self.hidden_size == 256 and self.embedding2.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
                 self._packed["enc_whh_split"] = ops.pack_lstm_split_weights(self._packed["enc_whh"])
                 self._packed["dec_whh_split"] = ops.pack_lstm_split_weights(self._packed["dec_whh"])
             if self.embedding_size != 0:     # the folded input side needs W_e [H, 8]: with the category embedding the literal order runs

@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B on ONE box, alternating fresh processes: the recurrent weights split once per model (default) against split in every launch
+# A/B on ONE box, alternating fresh processes: the recurrent weights split once per model (default) against split in every launch.
+# (GNNPN_PRESPLIT=0 was a temporary switch in modelPN.PointerNet.packed() at commit c6b6052; it is not in the product any more —
+#  to repeat the A/B, pop enc_whh_split / dec_whh_split from the packed dicts as test_presplit_weights_change_nothing does.)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r06presplit
