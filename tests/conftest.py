@@ -60,7 +60,7 @@ AGREEMENT_DIR = os.path.join(ROOT, "gpurun_out", "parity")
 def record_agreement(name, payload):
     """Write one measured-agreement record (robust / fragile counts, flips with their margins, max |dR| in 5-decimal
     units ...) to gpurun_out/parity/<name>.json on the GPU box; tools/collect_parity.py merges the records into the
-    committed tests/golden/agreement_r05.json (earlier rounds: agreement_r02 / r03.json)."""
+    committed tests/golden/agreement_r06.json (earlier rounds: agreement_r02 / r03 / r05.json)."""
     import json
     os.makedirs(AGREEMENT_DIR, exist_ok=True)
     clean = {k: v for k, v in payload.items() if k != "same_mask"}

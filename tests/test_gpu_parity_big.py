@@ -5,7 +5,7 @@ builds bench.py times (decode_impl 4, LDS-footprint placement, HIP-graph replay 
 full-batch properties and the whole pipeline (vocab > 100) against the live oracle at reduced B.
 
 Every test records its measured agreement (conftest.record_agreement -> gpurun_out/parity/*.json); the merged record
-of THIS round is committed as tests/golden/agreement_r05.json (tools/collect_parity.py; agreement_r02 / r03.json are the
+of THIS round is committed as tests/golden/agreement_r06.json (tools/collect_parity.py; agreement_r02 / r03 / r05.json are the
 earlier rounds') and the floors asserted here are the measured values."""
 import numpy as np
 import pytest
@@ -72,7 +72,7 @@ def _graph_pair(low, high, xs, precision):
     return outs
 
 
-# floors = the measured agreement (tests/golden/agreement_r02.json … agreement_r05.json: 512/512 and 1024/1024 problems identical, no
+# floors = the measured agreement (tests/golden/agreement_r02.json … agreement_r06.json: 512/512 and 1024/1024 problems identical, no
 # flips, on every build and under graph replay): every problem
 FLOORS = {"qws512": 1.0, "normal1024": 1.0}
 
