@@ -152,14 +152,27 @@ class GnnpnError(RuntimeError):
     pass
 
 
-def source_hash():
-    """sha256 (16 hex digits) over the device sources this library is built from — csrc/*.hip, csrc/*.h, csrc/torch_ops.cpp and
-    include/gnnpn_hip.h, names and contents in sorted order.  The committed counter summaries under profiles/ (PMC traffic, SQ
-    matrix-pipe utilisation) carry the hash of the tree they were measured on; bench.py quotes them beside freshly measured numbers
-    only while it equals this one (they used to be keyed by workload, batch and precision alone and went stale silently)."""
+SOURCE_GROUPS = {
+    # the sources a committed counter summary depends on: the kernels it measured and every header they include
+    "recurrent": ("lstm_coop.hip", "decode_lean.hip", "decode_coop.hip", "coop_common.h", "common.h", "recurrent.h", "lstm_shared.h",
+                  "decode_shared.h", "lstm.hip", "decode.hip"),
+    "aggregate": ("graph_tiled.hip", "graph.hip", "graph_lds.h", "common.h"),
+}
+
+
+def source_hash(group=None):
+    """sha256 (16 hex digits) over the device sources this library is built from, names and contents in sorted order: all of
+    csrc/*.hip, *.h, torch_ops.cpp and include/gnnpn_hip.h, or (``group``: "recurrent" | "aggregate") the files one family of kernels
+    is compiled from.  The committed counter summaries under profiles/ (PMC traffic, SQ matrix-pipe utilisation) carry the hash of
+    the sources they were measured on; bench.py quotes them beside freshly measured numbers only while it equals the loaded
+    tree's (they used to be keyed by workload, batch and precision alone and went stale silently)."""
     import hashlib
     root = os.path.dirname(_HERE)
-    files = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".hip", ".h", ".cpp")))
+    csrc = os.path.join(_HERE, "csrc")
+    if group is None:
+        files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    else:
+        files = sorted(os.path.join(csrc, f) for f in SOURCE_GROUPS[group])
     files.append(os.path.join(root, "include", "gnnpn_hip.h"))
     h = hashlib.sha256()
     for f in files:

@@ -16,7 +16,7 @@ for d in sorted(glob.glob(os.path.join(O, "*_*_[0-9]"))):
                     agg[(wl, pr, short)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnpn_sc_amd._lib import source_hash   # noqa: E402  (the tree the passes were measured on: summarise BEFORE editing csrc/)
-out = {"source_hash": source_hash(), "method": "rocprofv3 --kernel-trace --pmc <3 counters per pass> -- python3 bench.py --workload W --precision P --graph 0 --inflight 1 "
+out = {"source_group": "recurrent", "source_hash": source_hash("recurrent"), "method": "rocprofv3 --kernel-trace --pmc <3 counters per pass> -- python3 bench.py --workload W --precision P --graph 0 --inflight 1 "
                  "(eager, one stream, one launch at a time); mean per dispatch; tools/r05_recurrent_sq.sh",
        "units": "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles as reported; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
                 "GRBM_GUI_ACTIVE summed over 8 XCDs", "kernels": {}}
