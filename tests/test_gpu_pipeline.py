@@ -860,6 +860,14 @@ def test_bench_line_contract(dev):
     pr = d["per_rank"]
     assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["degraded"] is None and "degraded" not in d
     assert all(p["members_placed"] == 256 for p in pr[0]["placement_last_launch"])            # 32 groups x 8 members per slot
+    # round 6: placement events summed over EVERY launch of the run (sticky status words 1-2, ABI 9) — none on an idle chip — with the
+    # booked encoder tiles they are summed over; no process group at N = 1, so no collective latency; and the committed counter
+    # summaries are either quoted as "current" or named as stale (never silently quoted)
+    assert pr[0]["seats"]["declined"] == 0 and pr[0]["seats"]["off_canonical"] == 0 and pr[0]["seats"]["encoder_tiles_booked"] > 0
+    assert pr[0]["collective_ms"] is None
+    files = rf["counters_from"]["files"]
+    assert files and all(v == "current" or v.startswith("stale") for v in files.values())
+    assert (rf["traffic"] is not None) == all(v == "current" for k, v in files.items() if "pmc_traffic" in k and "aggregate" not in k)
     assert d["timing"]["untimed_settling_rounds"] == 0                                        # --min-time 0: the contract's bare region
     # a hand-off status during the timed rounds (forced) does not end the run: this rank switches, in process, to the degraded
     # form — one step in flight, write-through hand-off, the collective (RCCL, world 1) waited for before the next launch — the
@@ -872,6 +880,8 @@ def test_bench_line_contract(dev):
     dd = json.loads([ln for ln in rd.stdout.splitlines() if ln.strip()][-1])
     assert dd["degraded"][0]["phase"] == "timed rounds" and dd["degraded"][0]["status"] == 0x40 and dd["per_rank"][0]["degraded"]
     assert dd["value"] > 0
+    cm = dd["per_rank"][0]["collective_ms"]                                                   # the process group's first and second all-gather, host clock
+    assert cm["first"] > 0 and cm["second"] > 0
     # the self-launching multi-rank entry, FOUR ranks on this one GPU over gloo (launch path only: rank environment, port,
     # rank-0-only stdout, NUMA binding, all-gather shape [N * B, T]; the box allows six GPU processes, pytest is one of them;
     # the N = 8 logic is rehearsed with eight gloo ranks on the CPU in tests/test_host_logic.py) — weak, then strong scaling
