@@ -38,13 +38,10 @@ def _compile(src):
     return obj
 
 
-# The same-XCD hand-off of the cooperative kernels (coop_common.h: granule_store_l2) publishes with workgroup-scope
-# relaxed atomic stores that the toolchain lowers to plain global stores (no sc bits) — what the measurements and the
-# both-paths tests were made with.  A different compiler may lower them differently: say so loudly, and use
-# gnnpn_launch_opts_t.write_through = 1 (agent-scope stores, placement independent) until the tests have been re-run.
-MEASURED_WITH = "HIP version: 7.2"
-
-
+# The same-XCD hand-off of the cooperative kernels publishes with plain global stores — since round 6 WRITTEN as that instruction
+# (coop_common.h: granule_store_l2_bits, inline asm; decode_lean.hip: raw buffer stores with explicit cache-policy bits), not asked
+# for as workgroup-scope atomics that this toolchain happened to lower that way: the form no longer depends on the compiler, and the
+# warning rounds 3-5 printed under another hipcc is gone.  The compiler's identity is still recorded beside the objects.
 def _check_compiler():
     try:
         out = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, check=True).stdout
@@ -52,9 +49,6 @@ def _check_compiler():
         return
     with open(os.path.join(HERE, "build", "compiler.txt"), "w") as f:
         f.write(out)
-    if MEASURED_WITH not in out:
-        print(f"[gnnpn build] WARNING: this hipcc is not the one the L2-resident hand-off was validated with ({MEASURED_WITH}); "
-              "re-run `pytest -m gpu` (both hand-off forms are tested) or pass write_through=True", file=sys.stderr)
 
 
 def build(force=False):

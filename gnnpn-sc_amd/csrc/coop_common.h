@@ -178,8 +178,17 @@ __device__ __forceinline__ unsigned xcc_id() {
     return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;   // hwreg(HW_REG_XCC_ID, 0, 4)
 }
 
+// The L2-resident publish, WRITTEN as the instruction it is (round 6): one global_store_dwordx2 without cache-policy bits — the
+// granule goes to the XCD's L2, the point the group's peers read at with sc1 loads (a group sits on one XCD by placement).  Rounds
+// 1-5 asked for it as a workgroup-scope relaxed atomic store and relied on this toolchain lowering that to exactly this instruction
+// (build.py used to warn under another hipcc); the form is a statement about the hardware — which level a plain store lands in,
+// MI355X_MICROARCH.md "stores of each flavour" — not about the HIP memory model, so the source now says which instruction it means.
+// No destination register: nothing for the compiler to track (the sweeps' own asm statements wait vmcnt(0) before they read).
+__device__ __forceinline__ void granule_store_l2_bits(u64* p, u64 g) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(g) : "memory");
+}
 __device__ __forceinline__ void granule_store_l2(u64* p, unsigned tag, float v) {
-    __hip_atomic_store(p, ((u64)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    granule_store_l2_bits(p, ((u64)tag << 32) | __float_as_uint(v));
 }
 __device__ __forceinline__ void granule_publish(u64* p, unsigned tag, float v, bool same_xcd) {
     if (same_xcd) granule_store_l2(p, tag, v);
@@ -545,7 +554,7 @@ __device__ __forceinline__ u64 split_granule(unsigned tag, float h) {
 }
 __device__ __forceinline__ void split_granule_store(u64* p, unsigned tag, float h, bool same_xcd) {
     const u64 g = split_granule(tag, h);
-    if (same_xcd) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (same_xcd) granule_store_l2_bits(p, g);
     else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // both granules of a 16-byte pair {A.d0, A.d1, B.d0, B.d1} carry `tag`?
