@@ -38,28 +38,13 @@ import os
 import sys
 import time
 
-# More hardware queues than HIP's default of 4, set before the runtime initialises (round 6, profiles/LOG_r06.md section 9): a rank's
-# streams — two slots, their side streams, the process group's collective stream — are dealt onto the hardware queues round robin,
-# and a hardware queue is in order: with 4 of them the all-gather's "wait for slot A's step" sat in front of slot B's launches
-# (head-of-line blocking: -6 % with a real RCCL collective every 8 steps, -1.7 % with 8 queues; nothing to do with the collective
-# itself — a plain copy on a side stream cost the same).
-# Only for a rank that has a collective stream: at N = 1 without a process group the default of 4 is kept — with 8 the PCIe-inclusive leg
-# of this file (pinned host arenas copied in and out on the slots' streams) fell from 0.95 to 0.62 of the resident rate.
-
-
-def _rank_has_collective_stream():
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("GNNPN_FORCE_DIST") == "1":
-        return True
-    for i, a in enumerate(sys.argv):
-        if a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
-            return int(sys.argv[i + 1]) > 1
-        if a.startswith("--gpus=") and a[7:].isdigit():
-            return int(a[7:]) > 1
-    return False
-
-
-if _rank_has_collective_stream():
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Hardware queues (round 6, profiles/LOG_r06.md section 9): HIP deals a process's streams onto GPU_MAX_HW_QUEUES (default 4) in-order
+# hardware queues round robin, and in a rank of a process group the all-gather's "wait for slot A's step" sat in front of slot B's
+# launches (head-of-line blocking: -6 % with a real RCCL collective every 8 steps).  Nothing is set here: PipelinedRunner gives its
+# slots' streams a priority of their own wherever a collective stream exists (pipeline.py), which keeps them out of the process
+# group's queue with the default 4 queues — asking for 8 queues does the same (and this file did, until the library learnt to),
+# but 8 queues AND the priority is far worse than either (-22 %), and 8 queues without a process group cost the PCIe-inclusive
+# leg a third of its rate.
 
 import torch
 
@@ -1120,6 +1105,7 @@ def main():
                    "weights": "random-init (PyTorch defaults, seed 0)", "parallelism": f"dp{world}",
                    "collective": (None if not use_dist else "one asynchronous all-gather of the selected indices per step" if bucket == 1 else
                                   f"one asynchronous all-gather per {bucket} steps of a slot (the selected indices of those steps, staged on the device)"),
+                   **({"slot_stream_priority": runner.stream_priority} if runner is not None else {}),
                    **({"rank0_cpu_affinity": affinity} if affinity is not None else {}),
                    **({"NOT_A_MEASUREMENT": "GNNPN_BENCH_SHARE_GPU=1: all ranks share one GPU over gloo (launch-path check)"}
                       if share else {})},

@@ -264,6 +264,17 @@ class ML2PNPipeline:
         return ranking, [float(v) for v in pk.mean(0).tolist()]
 
 
+def _has_collective_stream():
+    """True in a rank of an RCCL ("nccl") process group: its collectives run on a stream of the process group's own."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()):
+        return False
+    try:
+        return "nccl" in str(td.get_backend()).lower()
+    except Exception:       # a backend object without a name: assume it brings a stream
+        return True
+
+
 class PipelinedRunner:
     """Throughput mode: ``slots`` independent batches in flight on ``slots`` HIP streams — or, for batches of 512 problems
     and more, ONE batch in flight whose recurrent part runs as two half-batches side by side (``halves``: the ``slots``
@@ -280,7 +291,8 @@ class PipelinedRunner:
     tensors on the slot's stream (``batch=None`` re-runs the resident one, as bench.py does).
     """
 
-    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=None, auto_degrade=True):
+    def __init__(self, pipe, services, example_batch, slots=2, halves=None, write_through=None, auto_degrade=True,
+                 stream_priority=None):
         # Batches of 512 problems and more: ONE batch in flight, its recurrent part as two half-batches side by side
         # (ML2PNPipeline.run with a pair of workspaces).  A cooperative launch has one workgroup per CU and two of them
         # fill a CU's registers, so nothing else runs beside a co-resident pair; with two WHOLE batches in flight on two
@@ -296,7 +308,19 @@ class PipelinedRunner:
         # step in flight, so its slots' graphs replay one after the other on one stream.
         self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
         self.n_streams = 1 if self.halves else self.n_slots
-        self.streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
+        # Stream priority of the slots: HIP deals a process's streams onto a few in-order hardware queues (GPU_MAX_HW_QUEUES,
+        # default 4) round robin, PER PRIORITY.  In a rank of an RCCL process group the collective's stream waits for one slot's
+        # step; when that wait shares a hardware queue with the other slot's stream it sits in front of that slot's launches
+        # (forced world-1 all-gather at the QWS shape: 449 k problems/s against 480 k without a process group).  Slot streams of a
+        # priority of their own never share a queue with the process group's (normal-priority) stream: 470 k, the same as 8
+        # hardware queues give (467 k) but without an environment variable that has to be set before the runtime starts — and
+        # the two do NOT add up (8 queues AND high priority: 367-378 k).  Without a process group high priority costs 0.35 %
+        # (477.8-478.2 k against 479.5-479.7 k), so it is used only where a collective stream exists.  profiles/LOG_r06.md §9.
+        if stream_priority is None:
+            env = os.environ.get("GNNPN_PIPE_STREAM_PRIORITY")
+            stream_priority = int(env) if env is not None else (-1 if _has_collective_stream() else 0)
+        self.stream_priority = int(stream_priority)
+        self.streams = [torch.cuda.Stream(priority=self.stream_priority) for _ in range(self.n_streams)]
         # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
         # 228 k vs 221 k problems/s in fp32, 353 k vs 316 k with the split precision.
         shared = 4

@@ -864,7 +864,7 @@ def test_bench_line_contract(dev):
     # booked encoder tiles they are summed over; no process group at N = 1, so no collective latency; and the committed counter
     # summaries are either quoted as "current" or named as stale (never silently quoted)
     assert pr[0]["seats"]["declined"] == 0 and pr[0]["seats"]["off_canonical"] == 0 and pr[0]["seats"]["encoder_tiles_booked"] > 0
-    assert pr[0]["collective_ms"] is None
+    assert pr[0]["collective_ms"] is None and d["config"]["slot_stream_priority"] == 0         # normal-priority slot streams without a process group
     files = rf["counters_from"]["files"]
     assert files and all(v == "current" or v.startswith("stale") for v in files.values())
     assert (rf["traffic"] is not None) == all(v == "current" for k, v in files.items() if "pmc_traffic" in k and "aggregate" not in k)
@@ -882,6 +882,7 @@ def test_bench_line_contract(dev):
     assert dd["value"] > 0
     cm = dd["per_rank"][0]["collective_ms"]                                                   # the process group's first and second all-gather, host clock
     assert cm["first"] > 0 and cm["second"] > 0
+    assert dd["config"]["slot_stream_priority"] == -1     # beside RCCL's stream the slots take hardware queues of their own (LOG_r06 9a)
     # the self-launching multi-rank entry, FOUR ranks on this one GPU over gloo (launch path only: rank environment, port,
     # rank-0-only stdout, NUMA binding, all-gather shape [N * B, T]; the box allows six GPU processes, pytest is one of them;
     # the N = 8 logic is rehearsed with eight gloo ranks on the CPU in tests/test_host_logic.py) — weak, then strong scaling

@@ -525,3 +525,11 @@ def test_partitioned_device_is_announced_once(monkeypatch):
         pl.warn_partitioned_device(torch.device("cpu"), "split")
     assert len(w) == 1 and "64 compute units" in str(w[0].message) and "GNNPN_E_UNSUP" in str(w[0].message)
     pl._warned_partitioned.clear()
+
+
+def test_slot_streams_keep_normal_priority_without_an_rccl_process_group():
+    """pipeline._has_collective_stream: only an RCCL ("nccl") process group brings a stream of its own that the slots' streams must
+    not share a hardware queue with (profiles/LOG_r06.md 9a); no process group — and gloo, whose collectives run on the host — do not."""
+    from gnnpn_sc_amd import pipeline
+    import torch.distributed as td
+    assert not td.is_initialized() and pipeline._has_collective_stream() is False
