@@ -24,12 +24,12 @@ svc = DeviceServices.from_table(table, dev)
 n_var = 12
 batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, w["B"], seed=100 + i, tasks_per_problem=w["n_t"]), dev)
            for i in range(n_var)]
-runner = PipelinedRunner(pipe, svc, batches[0], slots=2, auto_degrade=False)
 poll_every = int(os.environ.get("SOAK_POLL_EVERY", 500))
 use_dist = os.environ.get("SOAK_DIST") == "1"
-if use_dist:
+if use_dist:                                          # before the runner: beside a process group its slots' streams take a priority of their own
     from gnnpn_sc_amd import dist as gdist
     gdist.init_process_group("nccl", dev)
+runner = PipelinedRunner(pipe, svc, batches[0], slots=2, auto_degrade=False)
 gathers, polls, bad_polls = {}, 0, 0
 refs = [pipe.run(svc, b, decode_impl=runner.decode_impl) for b in batches]           # single stream, same kernels
 torch.cuda.synchronize()
@@ -86,7 +86,7 @@ ops.check_status(dev)
 import json
 print(json.dumps({"steps": N, "precision": prec, "workload": sys.argv[3] if len(sys.argv) > 3 else "qws", "batch": w["B"], "rccl_world1_all_gather_per_step": use_dist,
                   "mismatching_steps": bad, "polls": polls, "polls_with_status_or_shortfall": bad_polls, "progress_at_end": runner.progress() if polls else None,
-                  "write_through": runner.write_through, "front_lds_kb": runner.front_lds_kb, "seconds": round(time.time() - t0, 1)}))
+                  "write_through": runner.write_through, "front_lds_kb": runner.front_lds_kb, "slot_stream_priority": runner.stream_priority, "seconds": round(time.time() - t0, 1)}))
 if use_dist:
     gdist.destroy(2)
 sys.exit(1 if (bad or bad_polls) else 0)
