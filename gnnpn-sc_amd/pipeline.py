@@ -316,6 +316,7 @@ class PipelinedRunner:
         # hardware queues give (467 k) but without an environment variable that has to be set before the runtime starts — and
         # the two do NOT add up (8 queues AND high priority: 367-378 k).  Without a process group high priority costs 0.35 %
         # (477.8-478.2 k against 479.5-479.7 k), so it is used only where a collective stream exists.  profiles/LOG_r06.md §9.
+        self._priority_chosen = stream_priority is None and os.environ.get("GNNPN_PIPE_STREAM_PRIORITY") is None
         if stream_priority is None:
             env = os.environ.get("GNNPN_PIPE_STREAM_PRIORITY")
             stream_priority = int(env) if env is not None else (-1 if _has_collective_stream() else 0)
@@ -465,6 +466,11 @@ class PipelinedRunner:
         (each replay waits for both), so that the pair still starts together; ``after`` of the leader runs at that moment.
         Touching ``stream(slot)``, ``poll`` or ``synchronize`` enqueues a waiting leader at once (alone)."""
         s = self.count % self.n_slots
+        if self.count == 0 and self._priority_chosen and self.stream_priority == 0 and self.n_streams > 1 and _has_collective_stream():
+            import warnings                                # the process group came AFTER this runner: its streams were created at normal priority
+            warnings.warn("PipelinedRunner was created before the RCCL process group: its slots' streams share hardware queues with the "
+                          "collective's stream (about 6 % slower with one all-gather per 8 steps at the QWS shape); create the runner after "
+                          "init_process_group, or pass stream_priority=-1", RuntimeWarning, stacklevel=2)
         self.count += 1
         if self._deferred is not None and self._deferred[0] == s:
             self._flush_deferred()

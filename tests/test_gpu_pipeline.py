@@ -463,6 +463,19 @@ def test_all_gather_indices_rccl_world1(dev):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    # round 6 (profiles/LOG_r06.md 9a): beside a process group's stream the slots' streams take a priority — hardware queues — of their own
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd import ops
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 48
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=20 + i, tasks_per_problem=10), dev) for i in range(4)]
+    early = PipelinedRunner(pipe, svc, batches[0], slots=2)       # created BEFORE the process group: normal priority ...
+    assert early.stream_priority == 0
     try:
         rank, world = gdist.init_process_group("nccl", dev)
         assert (rank, world) == (0, 1)
@@ -470,6 +483,24 @@ def test_all_gather_indices_rccl_world1(dev):
         assert torch.equal(gdist.all_gather_indices(idx), idx)
         assert torch.equal(gdist.all_gather_indices(idx, sizes=[4]), idx)
         assert gdist.max_over_ranks(1.5, dev, 2) == 1.5          # the all-reduce(MAX) bench.py uses, forced through RCCL
+        with pytest.warns(RuntimeWarning, match="before the RCCL process group"):    # ... and it says so at its first submit
+            early.submit(batches[0])
+        early.synchronize()
+        runner = PipelinedRunner(pipe, svc, batches[0], slots=2)
+        assert runner.stream_priority == -1 and PipelinedRunner(pipe, svc, batches[0], slots=2, stream_priority=0).stream_priority == 0
+        got, gathers = [], {}
+        for b in batches:
+            out, slot = runner.submit(b)
+            with torch.cuda.stream(runner.stream(slot)):          # the path's collective behind the step, on the group's own stream
+                gathers[slot] = gdist.all_gather_indices_async(out["idx_high"], gathers.get(slot, (None, None))[0])
+                if gathers[slot][1] is not None:
+                    gathers[slot][1].wait()
+                got.append((gathers[slot][0].clone(), out["R"].clone()))
+        runner.synchronize()
+        ops.check_status(dev)
+        for b, (gi, R) in zip(batches, got):
+            ref = eager_reference(pipe, svc, b, decode_impl=runner.decode_impl)
+            assert torch.equal(gi.view_as(ref["idx_high"]), ref["idx_high"]) and torch.equal(R, ref["R"])
     finally:
         if td.is_initialized():
             td.destroy_process_group()
