@@ -319,7 +319,9 @@ class PipelinedRunner:
         self._priority_chosen = stream_priority is None and os.environ.get("GNNPN_PIPE_STREAM_PRIORITY") is None
         if stream_priority is None:
             env = os.environ.get("GNNPN_PIPE_STREAM_PRIORITY")
-            stream_priority = int(env) if env is not None else (-1 if _has_collective_stream() else 0)
+            # (a process started with 8 or more hardware queues has the separation already — and must not get both)
+            many_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 8
+            stream_priority = int(env) if env is not None else (-1 if _has_collective_stream() and not many_queues else 0)
         self.stream_priority = int(stream_priority)
         self.streams = [torch.cuda.Stream(priority=self.stream_priority) for _ in range(self.n_streams)]
         # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
@@ -466,7 +468,8 @@ class PipelinedRunner:
         (each replay waits for both), so that the pair still starts together; ``after`` of the leader runs at that moment.
         Touching ``stream(slot)``, ``poll`` or ``synchronize`` enqueues a waiting leader at once (alone)."""
         s = self.count % self.n_slots
-        if self.count == 0 and self._priority_chosen and self.stream_priority == 0 and self.n_streams > 1 and _has_collective_stream():
+        if self.count == 0 and self._priority_chosen and self.stream_priority == 0 and self.n_streams > 1 and _has_collective_stream() \
+                and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
             import warnings                                # the process group came AFTER this runner: its streams were created at normal priority
             warnings.warn("PipelinedRunner was created before the RCCL process group: its slots' streams share hardware queues with the "
                           "collective's stream (about 6 % slower with one all-gather per 8 steps at the QWS shape); create the runner after "
