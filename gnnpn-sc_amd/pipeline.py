@@ -321,7 +321,12 @@ class PipelinedRunner:
             env = os.environ.get("GNNPN_PIPE_STREAM_PRIORITY")
             # (a process started with 8 or more hardware queues has the separation already — and must not get both)
             many_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 8
-            stream_priority = int(env) if env is not None else (-1 if _has_collective_stream() and not many_queues else 0)
+            # Only for free-running slots on streams of their own: the half-batch mode keeps ONE step in flight on one stream (nothing of
+            # another slot for the collective's wait to sit in front of), and there high priority COSTS — Normal shape, forced RCCL:
+            # 199 k problems/s against 234-238 k at normal priority (238 k without a process group); 1000-task shape 22.8 k against 23.8 k
+            # (tools/r06/dist_priority_shapes.sh)
+            free_running = self.n_streams > 1
+            stream_priority = int(env) if env is not None else (-1 if free_running and _has_collective_stream() and not many_queues else 0)
         self.stream_priority = int(stream_priority)
         self.streams = [torch.cuda.Stream(priority=self.stream_priority) for _ in range(self.n_streams)]
         # decoder form beside another slot's kernels: the 8-member build sized for two workgroups per CU (decode_impl 4).  Measured at QWS B=256 against the 16-member form (3):
