@@ -281,8 +281,8 @@ __device__ __forceinline__ void coop_note_finished(unsigned* sticky, int word, u
 // XCD's LAST seat-taker (its add returned target - 1) adds the XCD to status word 5, and the one that makes it 8 closes the launch:
 // still exactly one workgroup sees the total, and no word takes an add from all 256 seat-takers any more.
 __device__ __forceinline__ void coop_note_staffed(unsigned* status, unsigned* count_xcc, unsigned target, unsigned* seats) {
-    // (an exchange, not a compare-and-swap: the launch can be complete before the first arrival of any XCD has marked it — that
-    // workgroup then finds 2, not 0, and takes its own add back)
+    // (an exchange, not a compare-and-swap: should the launch be complete before the first arrival of any XCD has marked it, that
+    // workgroup finds 2, not 0, and adds nothing)
     if (atomicAdd(count_xcc, 1u) + 1u == target && atomicAdd(status + 5, 1u) + 1u == 8u && atomicExch(status + 4, 2u) == 1u)
         atomicSub(seats + COOP_STAFFING_WORD, 1u);
 }
@@ -322,39 +322,36 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
         // compare-and-swap on status word 4 plus every seat-taker's add to status word 5: a single word takes ~88 atomics per us
         // (MI355X_MICROARCH.md, price list: dequeue), so 768 of them alone are 9 us; the placement stamp of workgroup 0 read 25-28 k
         // cycles with the chain and, unchanged, with the chain folded into one returning atomic of twelve lanes (which made the
-        // eight counter reads atomics too).  Now: one 11-lane sc1 LOAD — lanes 0..7 the eight XCDs' seat counters, lane 10 the
-        // per-device count of launches that are staffing, lane 11 this CU's canonical seat — beside one atomic add of lane 8 (the
-        // arrival index: 96 per word); the launch is marked as started (status word 4: 0 -> 1, and with it the per-device count)
-        // by the FIRST arrival of each XCD only (8 contenders instead of 768), the launch's first arrival being one of them; lane 9
-        // reads that word, so that everybody knows whether the launch is in the per-device count it reads beside it.
+        // eight counter reads atomics too).  Now: one 10-lane sc1 LOAD — lanes 0..7 the eight XCDs' seat counters, lane 9 the
+        // launch's mark, lane 11 this CU's canonical seat — beside one atomic add of lane 8 (the arrival index: 96 per word); the
+        // launch is marked as started (status word 4: 0 -> 1, and with it the per-device count of launches that are staffing) by
+        // the FIRST arrival of each XCD only (8 contenders instead of 768, the ones that already see the mark do not even try),
+        // the launch's first arrival being one of them.
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);
         unsigned* staffing = seats + COOP_STAFFING_WORD;           // per device: launches that have started and are not staffed yet
-        const unsigned* word = lane < 8 ? count + COOP_XCD_STRIDE * lane : lane == 9 ? status + 4 : lane == 10 ? staffing : seats + key;
+        const unsigned* word = lane < 8 ? count + COOP_XCD_STRIDE * lane : lane == 9 ? status + 4 : seats + key;
         unsigned got = 0;
-        if (lane < 12 && lane != 8) got = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 12 && lane != 8 && lane != 10) got = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 8) got = atomicAdd(arrive + COOP_XCD_STRIDE * xcc, 1u);
         const bool staffed_at_entry = __all(lane >= 8 || got >= target);
         unsigned arrival = __shfl(got, 8, 64);
         const bool marked = __shfl(got, 9, 64) != 0u;             // the launch was in the per-device count when this workgroup looked
-        const unsigned staffing_seen = __shfl(got, 10, 64);
         const unsigned seat_seen = __shfl(got, 11, 64);
         if (lane == 0) {
-            // an XCD's first arrival puts the launch into the per-device count — add FIRST, then mark, and take the add back if
-            // another XCD's first arrival (or the launch's last seat-taker: coop_note_staffed) got there before: "marked" then
-            // implies "counted", and whoever un-marks the launch (1 -> 2) takes out an add that is certainly in
-            if (arrival == 0u && !marked) {
-                atomicAdd(staffing, 1u);
-                if (atomicCAS(status + 4, 0u, 1u) != 0u) atomicSub(staffing, 1u);
-            }
+            // an XCD's first arrival puts the launch into the per-device count: mark (0 -> 1), and the ONE that wins the mark adds.
+            // (Not "add, mark, take the add back if beaten", as this round first had it: eight first arrivals then hold the
+            // per-device count up to eight too high for the microsecond in which most of the launch arrives, every workgroup that
+            // reads it takes ANOTHER launch to be staffing, the badly placed ones decline their seats one after the other until only the
+            // reserve is left, which takes seats off their CUs 2 ms later — and from the first group with two members on one CU on,
+            // the partner launch finds that CU full.  Found with slot 1 held back by 400 us (tools/probes/stagger_probe.py): a third of
+            // the 100-step rounds ended in a hand-off time-out; profiles/LOG_r06.md section 16.)
+            if (arrival == 0u && !marked && atomicCAS(status + 4, 0u, 1u) == 0u) atomicAdd(staffing, 1u);
             if (arrival >= gridDim.x / 8 || (staffed_at_entry && arrival < target)) coop_raise(status, sticky, 8u);
         }
         if (!staffed_at_entry) {
             if (lane == 0) {
                 atomicAdd(status + COOP_CLAIM_OFFSET / 4 + key, 1u);      // statistics: workgroups of this launch that reached the CU
-                // another launch is staffing: the count beyond this launch's own entry — which is in it if the launch was marked when
-                // both words were read (errs towards "yes" in the few hundred ns around the mark: a decline too many, never one too few)
-                const bool another_staffing = staffing_seen > (marked ? 1u : 0u);
                 // Where in the CU's LDS did the dispatcher put this workgroup?  LDS is handed out in contiguous ranges, and a
                 // workgroup that lands ABOVE a short-lived neighbour (an ordinary kernel's few KB) stays there when the neighbour
                 // has gone: a 78 KB footprint at, say, [25 KB, 103 KB) leaves two holes of 25 and 57 KB, and the partner launch's
@@ -375,8 +372,17 @@ __device__ __forceinline__ bool coop_place(unsigned* status, int gpx, int* slot,
                 // strict (every badly placed early arrival leaves) where the caller says that a partner launch starts TOGETHER with
                 // this one (gnnpn_launch_opts_t.paired_start: half-batches, slots started in pairs — nothing but the tails of the
                 // front halves is around then); otherwise only while another launch is staffing at this moment
-                const bool fragments = (paired_start || another_staffing) && lds_base != 0u && lds_base < lds_size &&
-                                       lds_base + 2u * lds_size > COOP_LDS_UNITS;
+                const bool badly_placed = lds_base != 0u && lds_base < lds_size && lds_base + 2u * lds_size > COOP_LDS_UNITS;
+                // "another launch is staffing" is asked only by the few workgroups it decides something for, and exactly, as rounds
+                // 3-5 asked it: this launch is marked first (whoever wins the mark adds it to the count), then the count is read
+                // afresh — more than this launch's own entry means another one.  (The snapshot every workgroup takes on arrival is
+                // too early for this question: see the note at the mark above.)
+                bool another_staffing = false;
+                if (badly_placed && !paired_start) {
+                    if (atomicCAS(status + 4, 0u, 1u) == 0u) atomicAdd(staffing, 1u);
+                    another_staffing = __hip_atomic_load(staffing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1u;
+                }
+                const bool fragments = (paired_start || another_staffing) && badly_placed;
                 const bool reserve_arrival = arrival + target >= gridDim.x / 8;
                 if (fragments && !reserve_arrival) {
                     atomicAdd(status + 3, 1u);                                // statistics: arrivals that left because of their LDS position

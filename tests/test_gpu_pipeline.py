@@ -664,6 +664,68 @@ def test_two_slots_whichever_starts_first(dev):
             assert pl["off_canonical_seats"] == 0, pl            # every member on its CU's canonical seat (no reserve take-over)
 
 
+@pytest.mark.parametrize("delay_us", [200, 400, 535])
+def test_two_slots_out_of_phase(dev, delay_us):
+    """Two free-running slots that do NOT start together (round 6, profiles/LOG_r06.md section 16).  Slot 1's first replay of every round
+    is held back by a spin kernel, so the slots run out of phase for the whole round and their cooperative launches start beside the
+    other slot's ORDINARY kernels (small LDS ranges at the bottom of a CU) and, as the phases drift, beside each other.  The first
+    one-round-trip placement of this round counted a launch into the per-device "staffing" count up to eight times for a microsecond;
+    every workgroup that read the count then took another launch to be staffing, badly placed ones declined their seats until only the
+    reserve was left, seats went off their canonical CUs 2 ms later, and a third of such rounds ended in a hand-off time-out (0.3 s
+    each).  Here: every round status 0, no seat off its CU, results equal to the single-stream run, no round slower than 1.5 x the median."""
+    import statistics
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 2507, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=32)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=4, tasks_per_problem=T), dev)
+    runner = PipelinedRunner(pipe, svc, batch, slots=2, auto_degrade=False)
+    ref = eager_reference(pipe, svc, batch, decode_impl=runner.decode_impl)
+    for _ in range(8):
+        runner.submit()
+    runner.synchronize(check=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(10_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    cyc_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
+    ms, words, off = [], [], 0
+    for _ in range(12):
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for s_ in range(2):
+            runner.stream(s_).wait_event(t0)
+        with torch.cuda.stream(runner.stream(1)):
+            torch.cuda._sleep(int(delay_us * cyc_per_us))
+        for _ in range(60):
+            runner.submit()
+        cur = torch.cuda.current_stream()
+        for s_ in range(2):
+            cur.wait_stream(runner.stream(s_))
+        t1.record()
+        torch.cuda.synchronize()
+        ms.append(t0.elapsed_time(t1))
+        off += sum((w.last_seats or {}).get("off_canonical", 0) for w in runner.workspaces)
+        words.append(runner.poll())
+        for s_ in range(2):
+            o = runner.graphs[s_].outputs
+            assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
+    assert not any(words), [hex(v) for v in words]
+    med = statistics.median(ms)
+    assert max(ms) < 1.5 * med, ms
+    seats = [w.last_seats for w in runner.workspaces]
+    assert all((st or {}).get("off_canonical", 0) == 0 for st in seats), seats
+    from conftest import record_agreement
+    record_agreement(f"two_slots_out_of_phase_{delay_us}us", {"rounds": len(ms), "steps_per_round": 60, "round_ms_median": round(med, 3),
+                                                           "round_ms_max": round(max(ms), 3), "status_words": words, "seats": seats})
+
+
 def test_two_slots_beside_long_ordinary_kernels(dev):
     """The staffing reserve of coop_place (csrc/coop_common.h).  At 1000 tasks x 5000 candidates x 512 problems the other
     slot's front-end kernels fill whole CUs for longer than the early surplus workgroups of a cooperative launch last; before
@@ -913,7 +975,8 @@ def test_bench_line_contract(dev):
     assert dd["value"] > 0
     cm = dd["per_rank"][0]["collective_ms"]                                                   # the process group's first and second all-gather, host clock
     assert cm["first"] > 0 and cm["second"] > 0
-    assert dd["config"]["slot_stream_priority"] == -1     # beside RCCL's stream the slots take hardware queues of their own (LOG_r06 9a)
+    assert dd["config"]["slot_stream_priority"] == 0      # the DEGRADED form's: one step in flight on one stream keeps normal priority (the two-slot
+    #                                                        runner beside RCCL takes -1: test_all_gather_indices_rccl_world1; LOG_r06 9a)
     # the self-launching multi-rank entry, FOUR ranks on this one GPU over gloo (launch path only: rank environment, port,
     # rank-0-only stdout, NUMA binding, all-gather shape [N * B, T]; the box allows six GPU processes, pytest is one of them;
     # the N = 8 logic is rehearsed with eight gloo ranks on the CPU in tests/test_host_logic.py) — weak, then strong scaling

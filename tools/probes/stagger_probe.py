@@ -24,7 +24,7 @@ pb = synth.make_problem_batch(table, B, seed=1, tasks_per_problem=T)
 net, low, high = build_models(T, S, K, dev, w["n_gcn"])
 pipe = ML2PNPipeline(net, low, high, K, precision=a.precision)
 svc, batch = DeviceServices.from_table(table, dev), DeviceBatch.from_problems(pb, dev)
-runner = PipelinedRunner(pipe, svc, batch, slots=2)
+runner = PipelinedRunner(pipe, svc, batch, slots=2, auto_degrade=False)      # a failed hand-off is reported per round, the form is not switched
 assert runner.n_slots == 2 and not runner.lockstep
 for _ in range(8):
     runner.submit(batch)
@@ -78,8 +78,19 @@ for spec in a.delays.split(",") * 2:
     d, _, x = spec.partition(":")                      # "d" or "d:x": x = extra microseconds for slot 1 behind a common gate (d < 0)
     d, x = int(d), int(x or 0)
     one_round(d, x)
-    ms = [one_round(d, x) for _ in range(a.rounds)]
+    ms, words = [], []
+    for _ in range(a.rounds):
+        ms.append(one_round(d, x))
+        words.append(runner.poll())                     # the slots' sticky status words, OR-ed (0: every launch of the round did its work)
+    if any(words):
+        print(f"delay {d:4d} us: status words per round {[hex(v) for v in words]}; progress {runner.progress()}", flush=True)
     med = statistics.median(ms)
     print(f"delay {d:4d} us extra {x:3d}: round median {med:.3f} ms  min {min(ms):.3f}  p90 {sorted(ms)[int(0.9 * len(ms))]:.3f}  "
           f"slow rounds (> 1.02 x median) {sum(1 for v in ms if v > 1.02 * med)} of {len(ms)}  -> {B * a.steps / med:.0f} k problems/s", flush=True)
-runner.synchronize(check=True)
+try:
+    runner.synchronize(check=True)
+except Exception as err:                              # report, then fail
+    from gnnpn_sc_amd import ops
+    print("FAILED:", str(err)[:600], flush=True)
+    print("failure record:", ops.decode_failure_record(clear=False), flush=True)
+    sys.exit(1)
