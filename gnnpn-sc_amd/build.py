@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "dense.hip", "graph.hip", "graph_tiled.hip", "gin_layer.hi
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "graph_lds.h"), os.path.join(CSRC, "recurrent.h"), os.path.join(CSRC, "lstm_shared.h"), os.path.join(CSRC, "decode_shared.h"), os.path.join(CSRC, "coop_common.h"), os.path.join(CSRC, "train_common.h"),
            os.path.join(ROOT, "include", "gnnpn_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("GNNPN_EXTRA_HIPCC_FLAGS", "").split()   # (experiments only)
 
 
 def _stale(target, deps):

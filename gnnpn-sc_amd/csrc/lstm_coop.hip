@@ -30,6 +30,7 @@ constexpr int ROWS = 16;          // problems per tile (MFMA M)
 constexpr int UNITS = H / G;      // hidden units per member
 constexpr unsigned SPIN_LIMIT = 400000;   // sweep passes before giving up (~0.3 s)
 constexpr int GROUP_GRANULES = 2 * ROWS * H + 2 * 4 * G;   // h granules (2 parities) + 64 spare
+constexpr int ENC_LOOP_PAD_NOPS = 13;      // see the anchor in front of the step loop
 }  // namespace
 
 // Sweep this wave's quarter (rows 4w..4w+3, all 256 units) of one parity buffer until every
@@ -206,6 +207,18 @@ __global__ __launch_bounds__(256, 2) void lstm_encode_coop_kernel(LstmNets nets,
             }
         };
         load_input(0, pg_next, ax_next);
+        // Where the step loop lies in the instruction stream decides 5 % of a solo step (round 6, profiles/LOG_r06.md section 17): the
+        // same loop, moved in 4-byte steps through a 64-byte line, takes 559-560 us per QWS launch at two positions 32 bytes apart and
+        // 578-590 us at the other fourteen (instruction fetch of a latency-bound wave: one wavefront per SIMD, nothing to hide a
+        // fetch bubble behind) — and every change to the placement code in front of it used to move it.  So the loop is anchored:
+        // aligned to 64 bytes here, then ENC_LOOP_PAD_NOPS no-ops put its product phase (the first v_mfma_f32_16x16x32_f16 of
+        // the disassembly) at 44 bytes into a 64-byte line — 12 and 44 are the two good positions solo, and with two slots in flight
+        // (which care little: +-0.3 %) 44 measured a shade better (tools/r06/loop_alignment_scan.sh).  Re-tune when the loop body
+        // changes: tools/r06/loop_anchor_check.sh prints the offset.
+#ifndef GNNPN_ENC_PAD_NOPS
+#define GNNPN_ENC_PAD_NOPS ENC_LOOP_PAD_NOPS
+#endif
+        if constexpr (SPLIT && !DIAG) asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(GNNPN_ENC_PAD_NOPS) : "memory");
         for (int t = 0; t < L; ++t, ++step) {
             const bool stamps = ablate & 32;
             u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;

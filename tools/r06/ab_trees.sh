@@ -7,7 +7,7 @@ O=$R/gpurun_out/r06ab
 mkdir -p $O
 for i in 1 2 3 4; do
 for tree in new prev; do
-  d=$R; [ $tree = prev ] && d=$R/_prev
+  d=$R; [ $tree = prev ] && d=$R/${PREV:-_prev}
   cd $d
   timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-precision > $O/${tree}_$i.json 2> $O/${tree}_$i.err
   python3 -c "
