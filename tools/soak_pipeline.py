@@ -3,6 +3,10 @@ single-stream run of the same batch (bit for bit), hand-off status checked at th
 Usage: soak_pipeline.py [N] [precision] [workload] [batch]   (batches of 512 and more exercise the half-batch pairing)
 Environment: SOAK_POLL_EVERY=n  the runner's poll() every n steps (default 500): status 0 and the proof of work — workgroup-tiles
                                 finished == expected == the host's count — at EVERY poll, or the soak fails;
+             SOAK_JITTER_US=n   before every submit a spin kernel of 0..n us (seeded) on that slot's stream: the two slots drift through
+                                every phase relation — cooperative launches beside the other slot's ordinary kernels, beside each
+                                other, staffing at the same moment (round 6: the placement regression of LOG_r06 section 16 only showed
+                                out of phase);
              SOAK_DIST=1        a real RCCL process group of world size 1 and the path's single collective, the asynchronous
                                 all-gather of the selected indices, behind every step on the group's own stream (what a rank of
                                 `bench.py --gpus N` does)."""
@@ -36,8 +40,18 @@ torch.cuda.synchronize()
 keys = ("idx_low", "idx_high", "R", "actions", "win_low", "win_high_raw")
 bad, t0 = 0, time.time()
 pending = []                                          # (step, slot, variant, event)
+jitter_us = int(os.environ.get("SOAK_JITTER_US", 0))
+if jitter_us:
+    import random
+    rng = random.Random(12345)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
+    cyc_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
 for i in range(N):
     v = (i * 7 + i // 5) % n_var
+    if jitter_us and rng.random() < 0.5:
+        with torch.cuda.stream(runner.stream(runner.count % runner.n_slots)):
+            torch.cuda._sleep(int(rng.uniform(0, jitter_us) * cyc_per_us))
     if use_dist and gathers.get(runner.count % runner.n_slots, (None, None))[1] is not None:
         with torch.cuda.stream(runner.stream(runner.count % runner.n_slots)):
             gathers[runner.count % runner.n_slots][1].wait()          # the previous gather out of this slot's index buffer is done
@@ -86,7 +100,7 @@ ops.check_status(dev)
 import json
 print(json.dumps({"steps": N, "precision": prec, "workload": sys.argv[3] if len(sys.argv) > 3 else "qws", "batch": w["B"], "rccl_world1_all_gather_per_step": use_dist,
                   "mismatching_steps": bad, "polls": polls, "polls_with_status_or_shortfall": bad_polls, "progress_at_end": runner.progress() if polls else None,
-                  "write_through": runner.write_through, "front_lds_kb": runner.front_lds_kb, "slot_stream_priority": runner.stream_priority, "seconds": round(time.time() - t0, 1)}))
+                  "write_through": runner.write_through, "front_lds_kb": runner.front_lds_kb, "slot_stream_priority": runner.stream_priority, "jitter_us": jitter_us, "seconds": round(time.time() - t0, 1)}))
 if use_dist:
     gdist.destroy(2)
 sys.exit(1 if (bad or bad_polls) else 0)
