@@ -264,6 +264,10 @@ class ML2PNPipeline:
         return ranking, [float(v) for v in pk.mean(0).tolist()]
 
 
+# device index -> weak reference to the PipelinedRunner whose replays were enqueued last on that device (PipelinedRunner._take_turn)
+_last_runner_on_device = {}
+
+
 def _has_collective_stream():
     """True in a rank of an RCCL ("nccl") process group: its collectives run on a stream of the process group's own."""
     import torch.distributed as td
@@ -479,6 +483,7 @@ class PipelinedRunner:
             warnings.warn("PipelinedRunner was created before the RCCL process group: its slots' streams share hardware queues with the "
                           "collective's stream (about 6 % slower with one all-gather per 8 steps at the QWS shape); create the runner after "
                           "init_process_group, or pass stream_priority=-1", RuntimeWarning, stacklevel=2)
+        self._take_turn()
         self.count += 1
         if self._deferred is not None and self._deferred[0] == s:
             self._flush_deferred()
@@ -621,6 +626,30 @@ class PipelinedRunner:
             lead, after_lead = self._deferred
             self._deferred = None
             self._replay(lead, after_lead)
+
+    def _take_turn(self):
+        """Two runners of one process take TURNS on a device.  A CU holds two cooperative workgroups, which is what ONE runner's two
+        launches in flight use; two runners fed alternately (two models served from one process) put four launches in front of those
+        two slots, launches stay half-staffed behind each other and the bounded waits give up — loud, and very slow (round 6,
+        tools/probes/dbg_two_runners.py: 200 alternating steps 3.6 s with status 0x13 against 0.11 s one runner after the other).
+        So the first submit after ANOTHER runner of the device was the last to submit waits (stream-side: events, no host
+        synchronisation) for everything that runner has enqueued.  Switching runners therefore drains the pipeline — a caller who
+        alternates per step runs one step at a time — but every launch finds the slots it was built for."""
+        import weakref
+        dev = self.batches[0].x.device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ref = _last_runner_on_device.get(key)
+        other = ref() if ref is not None else None
+        if other is not self:
+            if other is not None:
+                other._flush_deferred()
+                other._open_gate()
+                for ost in other.streams:
+                    ev = torch.cuda.Event()
+                    ev.record(ost)
+                    for st in self.streams:
+                        st.wait_event(ev)
+            _last_runner_on_device[key] = weakref.ref(self)
 
     def _stream(self, slot):
         return self.streams[slot % self.n_streams]

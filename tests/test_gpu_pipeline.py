@@ -726,6 +726,37 @@ def test_two_slots_out_of_phase(dev, delay_us):
                                                            "round_ms_max": round(max(ms), 3), "status_words": words, "seats": seats})
 
 
+def test_two_runners_take_turns(dev):
+    """Two PipelinedRunners of one process, fed alternately (round 6, tools/probes/dbg_two_runners.py): four cooperative launches in front
+    of the two workgroup slots of every CU used to end in half-staffed launches and bounded-wait time-outs (status 0x13, 18 ms per step).
+    PipelinedRunner._take_turn makes a runner's first submit after another runner's wait, stream-side, for what that runner has
+    enqueued: every launch finds the slots it was built for.  Status 0, no seat off its CU, results equal to the single-stream runs."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    svc = DeviceServices.from_table(table, dev)
+    runners, refs = [], []
+    for seed in (0, 1):
+        net, low, high = build_models(T, S, K, dev, seed=seed)
+        pipe = ML2PNPipeline(net, low, high, K)
+        batch = DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=5 + seed, tasks_per_problem=10), dev)
+        r = PipelinedRunner(pipe, svc, batch, slots=2, auto_degrade=False)
+        runners.append(r)
+        refs.append(eager_reference(pipe, svc, batch, decode_impl=r.decode_impl))
+    for pattern in ([0, 1] * 40, [0, 0, 0, 1, 1, 0, 1, 1, 1, 0] * 8):
+        for i in pattern:
+            runners[i].submit()
+        words = [r.poll() for r in runners]
+        assert words == [0, 0], [hex(v) for v in words]
+        for r, ref in zip(runners, refs):
+            assert all((w.last_seats or {}).get("off_canonical", 0) == 0 for w in r.workspaces), [w.last_seats for w in r.workspaces]
+            for s_ in range(2):
+                o = r.graphs[s_].outputs
+                assert torch.equal(o["idx_high"], ref["idx_high"]) and torch.equal(o["R"], ref["R"])
+
+
 def test_two_slots_beside_long_ordinary_kernels(dev):
     """The staffing reserve of coop_place (csrc/coop_common.h).  At 1000 tasks x 5000 candidates x 512 problems the other
     slot's front-end kernels fill whole CUs for longer than the early surplus workgroups of a cooperative launch last; before
