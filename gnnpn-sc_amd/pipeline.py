@@ -311,7 +311,11 @@ class PipelinedRunner:
         # outputs the next replay was already overwriting).  ``n_streams`` = steps in flight: the half-batch mode keeps ONE
         # step in flight, so its slots' graphs replay one after the other on one stream.
         self.pipe, self.services, self.n_slots = pipe, services, max(1, int(slots))
-        self.n_streams = 1 if self.halves else self.n_slots
+        # ... and never more than TWO: a CU holds two cooperative workgroups, so two replays in flight are what the chip has room for —
+        # a third free-running stream put three launches in front of those two slots and ended in half-staffed launches and
+        # bounded-wait time-outs (round 6, tools/probes/dbg_three_slots.py: slots=3 ran 24 k problems/s with status 0x13).  More slots
+        # than two are more static input / output sets (a longer reuse distance), dealt onto the two streams in turn.
+        self.n_streams = 1 if self.halves else min(self.n_slots, 2)
         # Stream priority of the slots: HIP deals a process's streams onto a few in-order hardware queues (GPU_MAX_HW_QUEUES,
         # default 4) round robin, PER PRIORITY.  In a rank of an RCCL process group the collective's stream waits for one slot's
         # step; when that wait shares a hardware queue with the other slot's stream it sits in front of that slot's launches
@@ -371,8 +375,8 @@ class PipelinedRunner:
         # tail by which the two replays differ (2 % at that shape); short steps (QWS, Normal) keep running free.
         env = os.environ.get("GNNPN_PIPE_LOCKSTEP")
         long_steps = int(getattr(pipe.low.actor, "seq_len", 0)) >= 2000          # recurrent steps per problem (T * K)
-        self.lockstep = self.n_streams == 2 and (env == "1" or (env is None and long_steps))
-        self._open_leader, self._last_done = None, [None, None]
+        self.lockstep = self.n_slots == 2 and self.n_streams == 2 and (env == "1" or (env is None and long_steps))
+        self._open_leader, self._last_done = None, [None] * max(2, self.n_slots)
         self._slot_done = [None] * self.n_slots
         self._deferred = None                    # (slot, after): a leader whose replay waits for its partner's submission (submit)
         self._copy_streams = [torch.cuda.Stream() for _ in range(self.n_slots)]   # host-to-device transfers of pinned arenas (submit)
@@ -425,7 +429,7 @@ class PipelinedRunner:
         warnings.warn(f"gnnpn: PipelinedRunner: cooperative launches reported status {word:#x}; switching this runner to the "
                       f"write-through hand-off (the batches since the last poll / synchronize must be submitted again)", RuntimeWarning)
         self.write_through, self.degraded = True, word
-        self._open_leader, self._last_done = None, [None, None]
+        self._open_leader, self._last_done = None, [None] * max(2, self.n_slots)
         self._slot_done = [None] * self.n_slots
         self._capture_graphs()
 

@@ -726,6 +726,33 @@ def test_two_slots_out_of_phase(dev, delay_us):
                                                            "round_ms_max": round(max(ms), 3), "status_words": words, "seats": seats})
 
 
+def test_more_than_two_slots_still_two_in_flight(dev):
+    """``slots`` > 2 = more static input / output sets, NOT more replays in flight: a CU holds two cooperative workgroups, and a third
+    free-running stream ended in half-staffed launches and time-outs (round 6, tools/probes/dbg_three_slots.py: status 0x13, 24 k problems/s).
+    The slots are dealt onto two streams in turn; every slot's outputs equal the single-stream run, status 0."""
+    import gnnpn_sc_amd.synth as synth
+    from bench import build_models
+    from gnnpn_sc_amd.pipeline import DeviceBatch, DeviceServices, ML2PNPipeline, PipelinedRunner
+    T, S, K, B = 47, 940, 5, 256
+    table = synth.make_service_table(T, S, seed=0, degree=16)
+    net, low, high = build_models(T, S, K, dev)
+    pipe = ML2PNPipeline(net, low, high, K)
+    svc = DeviceServices.from_table(table, dev)
+    batches = [DeviceBatch.from_problems(synth.make_problem_batch(table, B, seed=30 + i, tasks_per_problem=10), dev) for i in range(4)]
+    for slots in (3, 4):
+        runner = PipelinedRunner(pipe, svc, batches[0], slots=slots, auto_degrade=False)
+        assert runner.n_slots == slots and runner.n_streams == 2 and not runner.lockstep
+        refs = [eager_reference(pipe, svc, b, decode_impl=runner.decode_impl) for b in batches]
+        got = []
+        for i in range(24):
+            out, s_ = runner.submit(batches[i % 4])
+            with torch.cuda.stream(runner.stream(s_)):
+                got.append((i % 4, out["idx_high"].clone(), out["R"].clone()))
+        assert runner.poll() == 0
+        for j, idx, R in got:
+            assert torch.equal(idx, refs[j]["idx_high"]) and torch.equal(R, refs[j]["R"])
+
+
 def test_two_runners_take_turns(dev):
     """Two PipelinedRunners of one process, fed alternately (round 6, tools/probes/dbg_two_runners.py): four cooperative launches in front
     of the two workgroup slots of every CU used to end in half-staffed launches and bounded-wait time-outs (status 0x13, 18 ms per step).
