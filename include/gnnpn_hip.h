@@ -331,7 +331,11 @@ typedef struct {
  *                   that did its work; a shortfall means that a launch left outputs it never wrote — whatever the failure codes
  *                   say (a launch whose workgroups all leave as surplus raises none).  The host reports it as
  *                   GNNPN_COOP_SHORTFALL (ops.Workspaces.check / poll, which also hold their own count of the launches they
- *                   made against the expected words). */
+ *                   made against the expected words).
+ * In flight: a CU holds TWO cooperative workgroups, so at most two cooperative launches (on two streams, with a workspace each)
+ * may be in flight on a device at a time; three or more stay half-staffed behind each other until the bounded waits give up
+ * (GNNPN_COOP_ENC_TIMEOUT / _DEC_TIMEOUT — loud, and very slow).  A caller with more streams orders them with events
+ * (pipeline.PipelinedRunner does: two replays in flight whatever its number of slots, runners of one process take turns). */
 #define GNNPN_STATUS_WORDS 8
 #define GNNPN_STATUS_CODE 0
 #define GNNPN_STATUS_DECLINED_SEATS 1       /* ABI 9: early arrivals that declined their seat because of their LDS position, summed over the launches */
