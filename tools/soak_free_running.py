@@ -2,7 +2,9 @@
 a round), each round started with a random delay (0..max_delay us, spin kernel) on a random slot so that the slots run through every
 phase relation; after every round the sticky status words are polled and both slots' outputs compared with the single-stream run.
 tools/soak_pipeline.py checks every step and thereby paces the slots from the host — the placement regression of round 6
-(profiles/LOG_r06.md section 16) passed it and fails here.
+(profiles/LOG_r06.md section 16) left no trace in it; here the old library shows the symptom within 150 rounds (78 declined and 22
+off-canonical seats where the fixed library has none in 2000), though not yet a time-out: the fixed delays of
+tools/probes/stagger_probe.py and tests/test_gpu_pipeline.py::test_two_slots_out_of_phase are what provokes those.
     python tools/soak_free_running.py [rounds=1000] [precision=split] [steps=100] [max_delay_us=800] [workload=qws]"""
 import json, os, random, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
